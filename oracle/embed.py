@@ -1,0 +1,65 @@
+"""CPU restatement of the embedding-table tower and its row updates
+(TEST INFRASTRUCTURE).  **Parity unpinned**: the reference's tower is a BERT text
+encoder ending in L2-normalisation (xfmr_rec/models.py:42-63) and its optimiser is
+dense ``torch.optim.AdamW`` (xfmr_rec/lightning.py:238-239); embedding tables, SGD
+and row-wise (lazy) Adam are the north-star's replacement and have no reference
+implementation, so this file is our spec in plain torch ops.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def gather(table: torch.Tensor, idx: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+    """rows = table[idx]; optionally L2-normalised like models.Normalize() (models.py:59)."""
+    rows = table[idx]
+    if normalize:
+        rows = rows / rows.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    return rows
+
+
+def normalize_backward(rows_raw: torch.Tensor, grad_out: torch.Tensor) -> torch.Tensor:
+    """d/d raw of (raw / max(||raw||, 1e-12)) applied to grad_out (row-wise)."""
+    nrm = rows_raw.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    unit = rows_raw / nrm
+    return (grad_out - unit * (grad_out * unit).sum(-1, keepdim=True)) / nrm
+
+
+def coalesce(idx: torch.Tensor, grad: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """Sum gradient rows of duplicate indices (batch order inside a duplicate group)."""
+    uniq, inv = torch.unique(idx, return_inverse=True)
+    acc = torch.zeros(uniq.numel(), grad.shape[1], dtype=grad.dtype)
+    acc.index_add_(0, inv, grad)
+    return uniq, acc
+
+
+def sgd_update(table: torch.Tensor, idx: torch.Tensor, grad: torch.Tensor, lr: float,
+               weight_decay: float = 0.0) -> None:
+    """In place: table[r] -= lr * (sum of grads of r + wd * table[r]) for touched rows."""
+    uniq, acc = coalesce(idx, grad)
+    rows = table[uniq]
+    table[uniq] = rows - lr * (acc + weight_decay * rows)
+
+
+def adam_update(table, m, v, idx, grad, *, step: int, lr: float, beta1: float = 0.9,
+                beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0) -> None:
+    """Row-wise lazy AdamW: only touched rows move; moments decay only when touched;
+    bias correction uses the global ``step`` (1-based); decoupled weight decay as in
+    torch.optim.AdamW (the reference's optimiser class, lightning.py:238-239)."""
+    uniq, g = coalesce(idx, grad)
+    p = table[uniq] * (1.0 - lr * weight_decay)
+    mm = m[uniq] * beta1 + (1.0 - beta1) * g
+    vv = v[uniq] * beta2 + (1.0 - beta2) * g * g
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = (vv / bc2).sqrt() + eps
+    table[uniq] = p - (lr / bc1) * mm / denom
+    m[uniq] = mm
+    v[uniq] = vv
+
+
+def logq_from_counts(counts: torch.Tensor) -> torch.Tensor:
+    """log of the empirical sampling probability of each item (Yi et al. 2019; the
+    README cites it, README.md:29-30, but the reference never implements it)."""
+    p = counts.to(torch.float64).clamp_min(1.0)
+    return (p / p.sum()).log().to(torch.float32)
