@@ -1,0 +1,156 @@
+/*
+ * mf_hip.h -- C ABI of libmf_hip.so, the gfx950 (MI355X / CDNA4) implementation of
+ * the two-tower matrix-factorization hot path.
+ *
+ * The reference (yxtay/matrix-factorization-torch, package xfmr_rec) is pure Python
+ * and has no FFI layer; its boundary for this path is a torch.nn.Module call
+ * (SURVEY.md 8b).  Each entry point below names the reference interface it
+ * replaces (file:line under /root/reference).  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   * every pointer is a DEVICE pointer (hipMalloc / torch.cuda storage) unless
+ *     its name ends in _host; all float data is fp32, all ids are int64;
+ *   * matrices are dense row-major, rows 16-byte aligned; the embedding width d
+ *     must be one of 32, 64, 128, 256 (callers zero-pad other widths; zero columns
+ *     change no value, see mf_numerics.h);
+ *   * `stream` is a hipStream_t (NULL = default stream); no entry point allocates,
+ *     frees or synchronises -- scratch comes from the caller (`ws`, sized by the
+ *     matching *_ws_bytes query), so every call can be captured in a hipGraph;
+ *   * return value 0 = ok, otherwise a negative MF_E* code; mf_last_error() gives
+ *     the text (thread-local).
+ */
+#ifndef MF_HIP_H
+#define MF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mf_stream_t; /* hipStream_t */
+
+enum {
+    MF_OK = 0,
+    MF_EINVAL = -1,   /* bad argument (shape, width, NULL pointer) */
+    MF_ENOSPC = -2,   /* workspace too small */
+    MF_ELAUNCH = -3,  /* HIP launch error */
+    MF_ENOTSUP = -4   /* valid request outside the implemented range */
+};
+
+/* Loss classes, in the order of get_loss_fns (xfmr_rec/lightning.py:267-287). */
+enum mf_loss_kind {
+    MF_ALIGNMENT = 0,             /* AlignmentLoss                  losses.py:249-259 */
+    MF_CONTRASTIVE = 1,           /* ContrastiveLoss                losses.py:262-274 */
+    MF_ALIGNMENT_CONTRASTIVE = 2, /* AlignmentContrastiveLoss       losses.py:277-291 */
+    MF_INFONCE = 3,               /* InfomationNoiseContrastive...  losses.py:294-306 */
+    MF_MINE = 4,                  /* MutualInformationNeuralEst...  losses.py:309-321 */
+    MF_PAIRWISE_HINGE = 5,        /* PairwiseHingeLoss              losses.py:357-359 */
+    MF_PAIRWISE_LOGISTIC = 6,     /* PairwiseLogisticLoss           losses.py:352-354 */
+    MF_NUM_KINDS = 7
+};
+
+const char* mf_last_error(void);
+int mf_version(void);
+
+/* ------------------------------------------------------------------ towers ---
+ * Replaces the tower forward `MatrixFactorizationLitModule.forward`
+ * (xfmr_rec/lightning.py:60-74: text -> BERT -> mean-pool -> L2-normalise) by an
+ * embedding-table row gather (north-star; no reference implementation):
+ *   out[r, :] = table[idx[r], :]            (normalize == 0)
+ *   out[r, :] = table[idx[r], :] / max(||.||, 1e-12)   (normalize != 0, mirrors
+ *               sentence_transformers Normalize, xfmr_rec/models.py:59)
+ * out_inv_norm (nullable) receives 1 / max(||row||, 1e-12). */
+int mf_gather_rows(const float* table, int64_t n_rows, int d, const int64_t* idx, int64_t n,
+                   int normalize, float* out, float* out_inv_norm, mf_stream_t stream);
+
+/* out[r] = chain-ordered ||x_r||^2 (mf_numerics.h); helper of the loss path. */
+int mf_row_sqnorm(const float* x, int64_t n, int d, float* out, mf_stream_t stream);
+
+/* Raw score tile engine exposed for tests: out[i][j] = chain dot(u_i, v_j) computed
+ * by the fp32 MFMA path (must equal oracle/chain.c bit for bit). */
+int mf_scores(const float* u, int64_t B, const float* v, int64_t N, int d, float* out,
+              mf_stream_t stream);
+
+/* --------------------------------------------------------------- batch ids ---
+ * Stable sort of n int64 keys (0 <= key < 2^39, n < 2^24): perm[p] = original
+ * position of the p-th smallest key, sorted_keys[p] = its key (nullable).
+ * Used for duplicate-row handling and for the positive-mask range search that
+ * replaces the B x N x P comparison of negative_masks (xfmr_rec/losses.py:108). */
+size_t mf_sort_ws_bytes(int64_t n);
+int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64_t* sorted_keys, void* ws,
+                 size_t ws_bytes, mf_stream_t stream);
+
+/* ------------------------------------------------------------------ losses ---
+ * Replaces `EmbeddingLoss.forward` for all seven classes
+ * (xfmr_rec/losses.py:39-52; call site xfmr_rec/lightning.py:137-146):
+ *   u[B,d] user_embed, v[N,d] item_embed (N >= B; row j < B is the positive of
+ *   user j), target[B] (fp32 copy of the rating), item_idx[N], pos_idx[B,P]
+ *   (0-padded, nullable with P = 0), logq[N] (nullable; our logQ correction
+ *   L_ij -= logq[j]).
+ * kind_mask selects which losses to evaluate in the one pass (bit k = kind k);
+ * out_losses[7] receives them (others are left untouched).  The workspace keeps
+ * the per-row statistics / mined negatives for mf_loss_bwd and must stay intact
+ * between the two calls.  out_mask_bits (nullable, B x ceil(N/32) uint32, bit c of
+ * word [i][w] = column 32w+c) receives the post-mining negative mask
+ * (negative_masks + semi_hard_mining, losses.py:92-162) for tests.
+ * num_negatives follows losses.py:137-141: <= 0 or >= N disables mining.
+ * Mining supports num_negatives <= 64 (MF_ENOTSUP beyond). */
+size_t mf_loss_ws_bytes(int64_t B, int64_t N, int d, int P, int num_negatives);
+int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
+                int kind_mask, const float* u, const float* v, const float* target,
+                const int64_t* item_idx, const int64_t* pos_idx, const float* logq, void* ws,
+                size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits, mf_stream_t stream);
+
+/* Backward of one loss of the preceding mf_loss_fwd (same shapes/hyper-parameters,
+ * same ws): du[B,d] = grad_out * dloss/du, dv[N,d] = grad_out * dloss/dv, with
+ * grad_out a device scalar.  Masks and mining are constants of the backward
+ * (@torch.no_grad in the reference, losses.py:92,134). */
+int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
+                int kind, const float* u, const float* v, const float* target, const float* logq,
+                void* ws, size_t ws_bytes, const float* grad_out, float* du, float* dv,
+                mf_stream_t stream);
+
+/* --------------------------------------------------------------- optimiser ---
+ * Replaces `configure_optimizers` (xfmr_rec/lightning.py:238-239, dense AdamW) by
+ * sparse row updates of an embedding table (north-star; our spec):
+ * duplicate ids are summed first (batch order), then each touched row is updated
+ * once.  `normalized` != 0 means grad is w.r.t. the L2-normalised row and is first
+ * mapped through the normalisation Jacobian of the raw row.
+ *   sgd : row -= lr * (g + wd * row)
+ *   adam: lazy row-wise AdamW (moments of touched rows only, global step for the
+ *         bias correction, decoupled weight decay). */
+size_t mf_update_ws_bytes(int64_t n, int d);
+int mf_update_sgd(float* table, int64_t n_rows, int d, const int64_t* idx, int64_t n,
+                  const float* grad, int normalized, float lr, float weight_decay, void* ws,
+                  size_t ws_bytes, mf_stream_t stream);
+int mf_update_adam(float* table, float* exp_avg, float* exp_avg_sq, int64_t n_rows, int d,
+                   const int64_t* idx, int64_t n, const float* grad, int normalized, int64_t step,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, void* ws,
+                   size_t ws_bytes, mf_stream_t stream);
+
+/* --------------------------------------------------------------- retrieval ---
+ * Replaces `ItemProcessor.search` (xfmr_rec/data/lightning.py:237-259; LanceDB
+ * cosine ANN with prefilter) by EXACT brute-force top-k over the indexed item
+ * matrix: score = chain dot(q, item) (= 1 - cosine distance for unit-norm rows),
+ * exclusion prefilter by per-query sorted id lists (CSR: excl_off[Q+1],
+ * excl_idx[], GLOBAL item row indices; both nullable), best first, ties by lowest
+ * item index.  `idx_base` is the global index of items[0] (row-sharded catalogs).
+ * out_scores[Q,k] fp32, out_idx[Q,k] int64 global indices (-1 / -inf padding when
+ * fewer than k candidates).  k <= 64. */
+size_t mf_topk_ws_bytes(int64_t Q, int64_t N, int d, int k);
+int mf_topk(const float* q, int64_t Q, const float* items, int64_t N, int d, int k,
+            const int64_t* excl_off, const int64_t* excl_idx, int64_t idx_base, void* ws,
+            size_t ws_bytes, float* out_scores, int64_t* out_idx, mf_stream_t stream);
+
+/* Merge G partial results (e.g. the all-gathered per-shard top-k of a row-sharded
+ * catalog) part_*[G,Q,k] into the global top-k with the same order. */
+int mf_topk_merge(const float* part_scores, const int64_t* part_idx, int G, int64_t Q, int k,
+                  float* out_scores, int64_t* out_idx, mf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MF_HIP_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of ``libmf_hip.so`` (C ABI: ``include/mf_hip.h``).
+
+The product path has no CPU fallback: if the library is missing, or a tensor is not
+a contiguous fp32/int64 tensor on the GPU, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import pathlib
+import subprocess
+
+import torch
+
+_PKG = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libmf_hip.so"
+
+c_i64, c_int, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/mf_hip.h declares
+SIGNATURES = {
+    "mf_last_error": (ctypes.c_char_p, []),
+    "mf_version": (c_int, []),
+    "mf_gather_rows": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "mf_row_sqnorm": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "mf_scores": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp]),
+    "mf_sort_ws_bytes": (c_sz, [c_i64]),
+    "mf_sort_keys": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mf_loss_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int, c_int]),
+    "mf_loss_fwd": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp,
+                            c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "mf_loss_bwd": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp,
+                            c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
+    "mf_update_ws_bytes": (c_sz, [c_i64, c_int]),
+    "mf_update_sgd": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_f32, c_f32, c_vp, c_sz, c_vp]),
+    "mf_update_adam": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_i64, c_f32, c_f32,
+                               c_f32, c_f32, c_f32, c_vp, c_sz, c_vp]),
+    "mf_topk_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int]),
+    "mf_topk": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "mf_topk_merge": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
+}
+
+_lib: ctypes.CDLL | None = None
+
+
+class MfHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> pathlib.Path:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", str(_PKG / "csrc"), "-j4", "-s"] + (["-B"] if force else [])
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise MfHipError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(this package has no CPU fallback)")
+        handle = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise MfHipError(f"libmf_hip error {rc}: {lib().mf_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    """Contiguous fp32 CUDA view of ``t`` (copy only if needed); raises on CPU tensors."""
+    if not t.is_cuda:
+        raise MfHipError(f"{name} must live on the GPU (got {t.device}); this package has no CPU path")
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+def dev_i64(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise MfHipError(f"{name} must live on the GPU (got {t.device}); this package has no CPU path")
+    if t.dtype != torch.int64:
+        t = t.to(torch.int64)
+    return t.contiguous()
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+SUPPORTED_WIDTHS = (32, 64, 128, 256)
+
+
+def padded_width(d: int) -> int:
+    for w in SUPPORTED_WIDTHS:
+        if d <= w:
+            return w
+    raise MfHipError(f"embedding width {d} > {SUPPORTED_WIDTHS[-1]} is not supported")

@@ -1,0 +1,287 @@
+// mf_embed.hip -- embedding-table rows: gather (tower forward), chain norms, the
+// stable id sort and the sparse SGD / row-wise Adam updates.  All HBM-bound:
+// every row moves as 16-byte lane accesses, d/4 consecutive lanes per row, so one
+// wave-instruction covers whole 128..1024-byte rows (coalesced).
+//
+// Reference interfaces replaced: xfmr_rec/lightning.py:60-74 (tower forward),
+// :238-239 (optimiser).  Neither has a table-based implementation upstream; the
+// spec is oracle/embed.py.
+#include "mf_common.h"
+
+// ------------------------------------------------------------------ gather ----
+template <int D>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table,
+                                                          int64_t n_rows,
+                                                          const int64_t* __restrict__ idx, int64_t n,
+                                                          int normalize, float* __restrict__ out,
+                                                          float* __restrict__ out_inv) {
+    constexpr int LPR = D / 4;        // lanes per row
+    constexpr int RPW = 64 / LPR;     // rows per wave
+    const int lane = mf_lane();
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t r = wave * RPW + lane / LPR;
+    const int c = lane % LPR;
+    const bool valid = r < n;
+    int64_t row = valid ? idx[r] : 0;
+    const bool in_range = row >= 0 && row < n_rows;
+    row = in_range ? row : 0;
+    f32x4 x = reinterpret_cast<const f32x4*>(table + row * D)[c];
+    if (!in_range) x = f32x4{0.f, 0.f, 0.f, 0.f};
+    float inv = 1.f;
+    if (normalize) {
+        float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+        ss = mf_group_sum(ss, LPR);
+        inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+        x = x * inv;
+    }
+    if (valid) {
+        reinterpret_cast<f32x4*>(out + r * D)[c] = x;
+        if (out_inv && c == 0) out_inv[r] = inv;
+    }
+}
+
+extern "C" int mf_gather_rows(const float* table, int64_t n_rows, int d, const int64_t* idx,
+                              int64_t n, int normalize, float* out, float* out_inv_norm,
+                              mf_stream_t stream) {
+    if (!table || !idx || !out || n < 0 || n_rows <= 0) return mf_set_error(MF_EINVAL, "mf_gather_rows: bad argument");
+    if (n == 0) return MF_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MF_DISPATCH_D(d, {
+        constexpr int RPB = (64 / (D / 4)) * 4;  // rows per 256-thread block
+        dim3 grid((unsigned)((n + RPB - 1) / RPB));
+        gather_rows_kernel<D><<<grid, 256, 0, s>>>(table, n_rows, idx, n, normalize, out, out_inv_norm);
+    });
+    return mf_check_launch("mf_gather_rows");
+}
+
+// ------------------------------------------------------------- chain norms ----
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                         float* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(x + r * d);
+    float acc = 0.f;
+    for (int g = 0; g < d / 8; ++g) {   // same k order as mf_dot_chain
+        f32x4 a = p[2 * g], b = p[2 * g + 1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc = __builtin_fmaf(a[t], a[t], acc);
+            acc = __builtin_fmaf(b[t], b[t], acc);
+        }
+    }
+    out[r] = acc;
+}
+
+extern "C" int mf_row_sqnorm(const float* x, int64_t n, int d, float* out, mf_stream_t stream) {
+    if (!x || !out || n < 0 || d <= 0 || d % 8) return mf_set_error(MF_EINVAL, "mf_row_sqnorm: bad argument");
+    if (n == 0) return MF_OK;
+    row_sqnorm_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, static_cast<hipStream_t>(stream)>>>(x, n, d, out);
+    return mf_check_launch("mf_row_sqnorm");
+}
+
+// ------------------------------------------------------- raw MFMA score tiles --
+template <int D>
+__global__ __launch_bounds__(64) void scores_kernel(const float* __restrict__ u, int64_t B,
+                                                    const float* __restrict__ v, int64_t N,
+                                                    float* __restrict__ out) {
+    const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + c;
+    const int64_t j0 = (int64_t)blockIdx.y * 32;
+    RowFrag<D> xf, yf;
+    mf_load_frag<D>(xf, u, i, i < B);
+    mf_load_frag<D>(yf, v, j0 + c, j0 + c < N);
+    f32x16 acc = mf_tile_scores<D>(yf, xf);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int64_t j = j0 + mf_acc_row(e, h);
+        if (i < B && j < N) out[i * N + j] = acc[e];
+    }
+}
+
+extern "C" int mf_scores(const float* u, int64_t B, const float* v, int64_t N, int d, float* out,
+                         mf_stream_t stream) {
+    if (!u || !v || !out || B <= 0 || N <= 0) return mf_set_error(MF_EINVAL, "mf_scores: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MF_DISPATCH_D(d, {
+        dim3 grid((unsigned)((B + 31) / 32), (unsigned)((N + 31) / 32));
+        scores_kernel<D><<<grid, 64, 0, s>>>(u, B, v, N, out);
+    });
+    return mf_check_launch("mf_scores");
+}
+
+// ---------------------------------------------------------------- id sort ----
+// Stable rank sort: rank(r) = #{r' : (key[r'], r') < (key[r], r)}, an O(n^2)
+// all-pairs count spread over the whole chip.  n is a batch (<= a few 10^4 ids)
+// and the count is integer-exact and order-free, so the result is deterministic;
+// it costs 1/(6 d) of the score contraction of the same batch.
+static constexpr int SORT_TILE = 2048;
+
+__global__ __launch_bounds__(256) void rank_count_kernel(const int64_t* __restrict__ keys, int n,
+                                                         int32_t* __restrict__ rank) {
+    __shared__ unsigned long long tile[SORT_TILE];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int base = blockIdx.y * SORT_TILE;
+    for (int t = threadIdx.x; t < SORT_TILE; t += 256) {
+        const int q = base + t;
+        tile[t] = q < n ? (((unsigned long long)keys[q] << 24) | (unsigned)q) : ~0ull;
+    }
+    __syncthreads();
+    if (r >= n) return;
+    const unsigned long long mine = ((unsigned long long)keys[r] << 24) | (unsigned)r;
+    int cnt = 0;
+#pragma unroll 8
+    for (int t = 0; t < SORT_TILE; ++t) cnt += tile[t] < mine ? 1 : 0;
+    if (cnt) atomicAdd(&rank[r], cnt);
+}
+
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const int64_t* __restrict__ keys, int n,
+                                                           const int32_t* __restrict__ rank,
+                                                           int32_t* __restrict__ perm,
+                                                           int64_t* __restrict__ sorted_keys) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int p = rank[r];
+    perm[p] = r;
+    if (sorted_keys) sorted_keys[p] = keys[r];
+}
+
+extern "C" size_t mf_sort_ws_bytes(int64_t n) { return mf_align_up((size_t)(n > 0 ? n : 1) * 4, 256); }
+
+extern "C" int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64_t* sorted_keys,
+                            void* ws, size_t ws_bytes, mf_stream_t stream) {
+    if (!keys || !perm || !ws || n < 0) return mf_set_error(MF_EINVAL, "mf_sort_keys: bad argument");
+    if (n >= (1 << 24)) return mf_set_error(MF_ENOTSUP, "mf_sort_keys: n = %lld >= 2^24", (long long)n);
+    if (ws_bytes < mf_sort_ws_bytes(n)) return mf_set_error(MF_ENOSPC, "mf_sort_keys: workspace too small");
+    if (n == 0) return MF_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int32_t* rank = static_cast<int32_t*>(ws);
+    if (hipMemsetAsync(rank, 0, (size_t)n * 4, s) != hipSuccess) return mf_set_error(MF_ELAUNCH, "mf_sort_keys: memset failed");
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)((n + SORT_TILE - 1) / SORT_TILE));
+    rank_count_kernel<<<grid, 256, 0, s>>>(keys, (int)n, rank);
+    rank_scatter_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, s>>>(keys, (int)n, rank, perm, sorted_keys);
+    return mf_check_launch("mf_sort_keys");
+}
+
+// ---------------------------------------------------------- sparse updates ----
+struct AdamHyper {
+    float lr, beta1, beta2, eps, wd, bc1, bc2;
+};
+
+// One d/4-lane group per sorted position; the head of each run of equal ids sums
+// the run's gradient rows in batch order (deterministic) and updates the row once.
+template <int D, bool ADAM>
+__global__ __launch_bounds__(256) void update_rows_kernel(float* __restrict__ table,
+                                                          float* __restrict__ exp_avg,
+                                                          float* __restrict__ exp_avg_sq,
+                                                          int64_t n_rows,
+                                                          const int32_t* __restrict__ perm,
+                                                          const int64_t* __restrict__ skeys, int64_t n,
+                                                          const float* __restrict__ grad,
+                                                          int normalized, AdamHyper hp) {
+    constexpr int LPR = D / 4;
+    constexpr int RPW = 64 / LPR;
+    const int lane = mf_lane();
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t p = wave * RPW + lane / LPR;
+    const int c = lane % LPR;
+    int64_t row = 0;
+    bool head = false;
+    if (p < n) {
+        row = skeys[p];
+        head = (p == 0 || skeys[p - 1] != row) && row >= 0 && row < n_rows;
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (head) {
+        for (int64_t q = p; q < n && skeys[q] == row; ++q)
+            acc += reinterpret_cast<const f32x4*>(grad + (int64_t)perm[q] * D)[c];
+    }
+    const int64_t rr = head ? row : 0;
+    f32x4 w = reinterpret_cast<const f32x4*>(table + rr * D)[c];
+    f32x4 g = acc;
+    if (normalized) {   // grad is w.r.t. w / max(||w||, 1e-12): apply the Jacobian
+        float ss = mf_group_sum(w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3], LPR);
+        const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+        const f32x4 uh = w * inv;
+        float pr = mf_group_sum(acc[0] * uh[0] + acc[1] * uh[1] + acc[2] * uh[2] + acc[3] * uh[3], LPR);
+        g = (acc - uh * pr) * inv;
+    }
+    if (!head) return;
+    if (!ADAM) {
+        w = w - hp.lr * (g + hp.wd * w);
+    } else {
+        f32x4 m = reinterpret_cast<const f32x4*>(exp_avg + rr * D)[c];
+        f32x4 v = reinterpret_cast<const f32x4*>(exp_avg_sq + rr * D)[c];
+        w = w * (1.f - hp.lr * hp.wd);
+        m = m * hp.beta1 + (1.f - hp.beta1) * g;
+        v = v * hp.beta2 + (1.f - hp.beta2) * g * g;
+        f32x4 den;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) den[t] = sqrtf(v[t] / hp.bc2) + hp.eps;
+        w = w - (hp.lr / hp.bc1) * m / den;
+        reinterpret_cast<f32x4*>(exp_avg + rr * D)[c] = m;
+        reinterpret_cast<f32x4*>(exp_avg_sq + rr * D)[c] = v;
+    }
+    reinterpret_cast<f32x4*>(table + rr * D)[c] = w;
+}
+
+struct UpdateWs {
+    int32_t* perm;
+    int64_t* skeys;
+    void* sort_ws;
+    size_t total;
+};
+static UpdateWs update_ws(void* ws, int64_t n) {
+    MfArena a(ws);
+    UpdateWs w;
+    w.perm = a.take<int32_t>((size_t)n);
+    w.skeys = a.take<int64_t>((size_t)n);
+    w.sort_ws = a.take<char>(mf_sort_ws_bytes(n));
+    w.total = a.used();
+    return w;
+}
+
+extern "C" size_t mf_update_ws_bytes(int64_t n, int d) {
+    (void)d;
+    return update_ws(nullptr, n > 0 ? n : 1).total;
+}
+
+template <bool ADAM>
+static int update_common(float* table, float* m, float* v, int64_t n_rows, int d, const int64_t* idx,
+                         int64_t n, const float* grad, int normalized, AdamHyper hp, void* ws,
+                         size_t ws_bytes, mf_stream_t stream, const char* what) {
+    if (!table || !idx || !grad || !ws || n < 0 || n_rows <= 0 || (ADAM && (!m || !v)))
+        return mf_set_error(MF_EINVAL, "%s: bad argument", what);
+    if (n_rows >= (1ll << 39)) return mf_set_error(MF_ENOTSUP, "%s: table too large", what);
+    if (ws_bytes < mf_update_ws_bytes(n, d)) return mf_set_error(MF_ENOSPC, "%s: workspace too small", what);
+    if (n == 0) return MF_OK;
+    UpdateWs w = update_ws(ws, n);
+    int rc = mf_sort_keys(idx, n, w.perm, w.skeys, w.sort_ws, mf_sort_ws_bytes(n), stream);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MF_DISPATCH_D(d, {
+        constexpr int RPB = (64 / (D / 4)) * 4;
+        dim3 grid((unsigned)((n + RPB - 1) / RPB));
+        update_rows_kernel<D, ADAM><<<grid, 256, 0, s>>>(table, m, v, n_rows, w.perm, w.skeys, n, grad, normalized, hp);
+    });
+    return mf_check_launch(what);
+}
+
+extern "C" int mf_update_sgd(float* table, int64_t n_rows, int d, const int64_t* idx, int64_t n,
+                             const float* grad, int normalized, float lr, float weight_decay,
+                             void* ws, size_t ws_bytes, mf_stream_t stream) {
+    AdamHyper hp{lr, 0.f, 0.f, 0.f, weight_decay, 1.f, 1.f};
+    return update_common<false>(table, nullptr, nullptr, n_rows, d, idx, n, grad, normalized, hp, ws,
+                                ws_bytes, stream, "mf_update_sgd");
+}
+
+extern "C" int mf_update_adam(float* table, float* exp_avg, float* exp_avg_sq, int64_t n_rows, int d,
+                              const int64_t* idx, int64_t n, const float* grad, int normalized,
+                              int64_t step, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, void* ws, size_t ws_bytes, mf_stream_t stream) {
+    if (step < 1) return mf_set_error(MF_EINVAL, "mf_update_adam: step must be >= 1");
+    AdamHyper hp{lr, beta1, beta2, eps, weight_decay,
+                 (float)(1.0 - pow((double)beta1, (double)step)),
+                 (float)(1.0 - pow((double)beta2, (double)step))};
+    return update_common<true>(table, exp_avg, exp_avg_sq, n_rows, d, idx, n, grad, normalized, hp, ws,
+                               ws_bytes, stream, "mf_update_adam");
+}

@@ -1,0 +1,824 @@
+// mf_loss.hip -- the in-batch score matrix and the seven xfmr_rec/losses.py losses,
+// forward and backward, without ever materialising the B x N logits or the
+// B x N x P positive-mask temp of the reference (xfmr_rec/losses.py:108).
+//
+// Pipeline (all on the caller's stream, no allocation, no sync):
+//   fwd : chain norms -> diagonal (L_ii) -> sort item ids -> hit bitmask
+//         (B x N BITS, both orientations) ->
+//           dense : score tiles + per-row statistics (split over item ranges)
+//           mined : streaming per-row top-k of mining keys -> merge -> statistics
+//         -> per-row losses -> fixed-order reduction to the 7 scalars
+//   bwd : per-row coefficients of dloss/dL -> dense: dU pass + dV pass (each a
+//         recompute-and-contract sweep over score tiles), or mined: sparse rows.
+//
+// Reference restated: negative_masks :92-110, semi_hard_mining :134-162,
+// alignment/contrastive/infonce/mine :164-246, pairwise :324-359, reduction
+// `(loss * target.abs()).sum()`.  Formulas: SURVEY.md Appendix A.
+#include <cfloat>
+
+#include "mf_common.h"
+#include "mf_select.h"
+
+static constexpr int NSTAT = 8;  // cnt, A(contrastive), mx, se, H, Hc, Lg, Ls
+enum { ST_CNT = 0, ST_A = 1, ST_MX = 2, ST_SE = 3, ST_H = 4, ST_HC = 5, ST_LG = 6, ST_LS = 7 };
+enum { NEED_CONTR = 1, NEED_LSE = 2, NEED_HINGE = 4, NEED_LOGI = 8 };
+enum { G_EXP = 0, G_STEP = 1, G_SIGM = 2 };
+static constexpr int KSEL_MAX = 64;
+
+static int need_flags(int kind_mask) {
+    int f = 0;
+    if (kind_mask & ((1 << MF_CONTRASTIVE) | (1 << MF_ALIGNMENT_CONTRASTIVE))) f |= NEED_CONTR;
+    if (kind_mask & ((1 << MF_INFONCE) | (1 << MF_MINE))) f |= NEED_LSE;
+    if (kind_mask & (1 << MF_PAIRWISE_HINGE)) f |= NEED_HINGE;
+    if (kind_mask & (1 << MF_PAIRWISE_LOGISTIC)) f |= NEED_LOGI;
+    return f;
+}
+
+// ------------------------------------------------------------------ workspace --
+struct LossWs {
+    int64_t B, N, Bp, Np;
+    int BT, NT, d;
+    bool mined;
+    int nsplit_f, tps_f;          // dense fwd: item-range splits
+    int nsplit_u, tps_u;          // dU pass: item-range splits
+    int nsplit_v, tps_v;          // dV pass: user-range splits
+    int T, CAP, nchunk, tpc;      // mining select geometry
+    float *nu, *nv, *lii, *dii, *sgn, *logq;
+    int32_t* perm;
+    int64_t* skeys;
+    void* sort_ws;
+    uint32_t *maskW, *maskTW;
+    float *part, *stats, *rowloss, *rowc, *dpart;
+    unsigned long long* cand;
+    int32_t *cand_cnt, *sel, *sel_cnt;
+    float* sel_L;
+    size_t total;
+};
+
+static void split_geometry(int x_tiles, int y_tiles, int* nsplit, int* tps) {
+    int want = (2048 + x_tiles - 1) / x_tiles;
+    if (want < 1) want = 1;
+    if (want > y_tiles) want = y_tiles;
+    *tps = (y_tiles + want - 1) / want;
+    *nsplit = (y_tiles + *tps - 1) / *tps;
+}
+
+static bool mining_on(int num_negatives, int64_t N) { return num_negatives > 0 && num_negatives < N; }
+
+static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_negatives) {
+    (void)P;
+    LossWs w{};
+    w.B = B; w.N = N; w.d = d;
+    w.Bp = mf_pad32(B); w.Np = mf_pad32(N);
+    w.BT = (int)(w.Bp / 32); w.NT = (int)(w.Np / 32);
+    w.mined = mining_on(num_negatives, N);
+    split_geometry(w.BT, w.NT, &w.nsplit_f, &w.tps_f);
+    w.nsplit_u = w.nsplit_f; w.tps_u = w.tps_f;
+    split_geometry(w.NT, w.BT, &w.nsplit_v, &w.tps_v);
+    const int k = num_negatives;
+    w.T = k <= 4 ? 2 : k <= 8 ? 4 : k <= 16 ? 8 : k <= 24 ? 12 : k <= 32 ? 16 : 32;
+    w.CAP = k <= 24 ? 64 : 128;
+    {
+        int maxchunk = (64 * 1024) / (w.CAP * 8);
+        int want = (2048 + w.BT - 1) / w.BT;
+        if (want > maxchunk) want = maxchunk;
+        if (want > w.NT) want = w.NT;
+        if (want < 1) want = 1;
+        w.tpc = (w.NT + want - 1) / want;
+        w.nchunk = (w.NT + w.tpc - 1) / w.tpc;
+    }
+    MfArena a(base);
+    w.nu = a.take<float>(w.Bp); w.nv = a.take<float>(w.Np);
+    w.lii = a.take<float>(w.Bp); w.dii = a.take<float>(w.Bp); w.sgn = a.take<float>(w.Bp);
+    w.logq = a.take<float>(w.Np);
+    w.perm = a.take<int32_t>(N); w.skeys = a.take<int64_t>(N);
+    w.sort_ws = a.take<char>(mf_sort_ws_bytes(N));
+    w.maskW = a.take<uint32_t>((size_t)w.NT * w.Bp);
+    w.maskTW = a.take<uint32_t>((size_t)w.BT * w.Np);
+    w.part = a.take<float>((size_t)w.nsplit_f * NSTAT * w.Bp);
+    w.stats = a.take<float>((size_t)NSTAT * w.Bp);
+    w.rowloss = a.take<float>((size_t)MF_NUM_KINDS * w.Bp);
+    w.rowc = a.take<float>((size_t)4 * w.Bp);
+    if (w.mined) {
+        w.cand = a.take<unsigned long long>((size_t)w.nchunk * w.Bp * w.CAP);
+        w.cand_cnt = a.take<int32_t>((size_t)w.nchunk * w.Bp);
+        w.sel = a.take<int32_t>((size_t)w.Bp * KSEL_MAX);
+        w.sel_cnt = a.take<int32_t>(w.Bp);
+        w.sel_L = a.take<float>((size_t)w.Bp * KSEL_MAX);
+        w.dpart = nullptr;
+    } else {
+        size_t rows = (size_t)w.nsplit_u * w.Bp;
+        size_t rows_v = (size_t)w.nsplit_v * w.Np;
+        if (rows_v > rows) rows = rows_v;
+        w.dpart = a.take<float>(rows * d);
+    }
+    w.total = a.used();
+    return w;
+}
+
+extern "C" size_t mf_loss_ws_bytes(int64_t B, int64_t N, int d, int P, int num_negatives) {
+    if (B <= 0 || N < B) return 0;
+    return loss_ws(nullptr, B, N, d, P, num_negatives).total;
+}
+
+// ------------------------------------------------------------------ diagonal ---
+__global__ __launch_bounds__(256) void diag_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                   const float* __restrict__ target,
+                                                   const float* __restrict__ logq,
+                                                   const float* __restrict__ nu, const float* __restrict__ nv,
+                                                   int64_t B, int64_t Bp, int d, float sigma,
+                                                   float* __restrict__ lii, float* __restrict__ dii,
+                                                   float* __restrict__ sgn) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Bp) return;
+    if (i >= B) {
+        lii[i] = 0.f; dii[i] = 0.f; sgn[i] = 0.f;
+        return;
+    }
+    const float dot = mf_dot_chain(u + i * d, v + i * d, d);
+    const float s = mf_sign(target[i]);
+    dii[i] = mf_half_sqdist(nu[i], nv[i], dot);
+    lii[i] = mf_logit(nu[i], nv[i], dot, s, sigma, logq ? logq[i] : 0.f);
+    sgn[i] = s;
+}
+
+// ------------------------------------------------------------------ hit masks --
+// maskW [tj][i]  bit c : item column 32 tj + c is NOT a valid negative of user i
+// maskTW[ti][j]  bit r : user 32 ti + r  x  item j   (same bit, transposed words)
+__global__ __launch_bounds__(256) void mask_pad_kernel(uint32_t* __restrict__ maskW, uint32_t* __restrict__ maskTW,
+                                                       int64_t B, int64_t N, int64_t Bp, int64_t Np, int BT, int NT) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int nc = (int)(N - (int64_t)(NT - 1) * 32);   // valid columns in the last item tile (1..32)
+    const int nr = (int)(B - (int64_t)(BT - 1) * 32);
+    if (t < Bp && nc < 32) maskW[(int64_t)(NT - 1) * Bp + t] = ~0u << nc;
+    if (t < Np && nr < 32) maskTW[(int64_t)(BT - 1) * Np + t] = ~0u << nr;
+}
+
+__global__ __launch_bounds__(256) void mask_build_kernel(const int64_t* __restrict__ item_idx,
+                                                         const int64_t* __restrict__ pos_idx,
+                                                         const int32_t* __restrict__ perm,
+                                                         const int64_t* __restrict__ skeys, int64_t B, int64_t N,
+                                                         int P, int64_t Bp, int64_t Np,
+                                                         uint32_t* __restrict__ maskW, uint32_t* __restrict__ maskTW) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = t / (P + 1);
+    const int p = (int)(t % (P + 1));
+    if (i >= B) return;
+    const int64_t key = (p == P) ? item_idx[i] : pos_idx[i * P + p];
+    int64_t lo = 0, hi = N;   // lower_bound
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (skeys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    for (int64_t q = lo; q < N && skeys[q] == key; ++q) {
+        const int64_t j = perm[q];
+        atomicOr(&maskW[(j >> 5) * Bp + i], 1u << (j & 31));
+        atomicOr(&maskTW[(i >> 5) * Np + j], 1u << (i & 31));
+    }
+}
+
+// ---------------------------------------------------------- dense forward ------
+struct FwdParams {
+    const float *u, *v, *nu, *nv, *lii, *sgn, *logq;
+    const uint32_t* maskW;
+    float* part;
+    int64_t B, N, Bp;
+    int NT, tps, need;
+    float sigma, margin;
+};
+
+struct RowStats {
+    float cnt, A, mx, se, H, Hc, Lg, Ls;
+};
+
+__device__ __forceinline__ void stats_init(RowStats& s) {
+    s.cnt = s.A = s.se = s.H = s.Hc = s.Lg = s.Ls = 0.f;
+    s.mx = -FLT_MAX;
+}
+__device__ __forceinline__ void lse_merge(float& mx, float& se, float mx2, float se2) {
+    const float m = fmaxf(mx, mx2);
+    se = se * __expf(mx - m) + se2 * __expf(mx2 - m);
+    mx = m;
+}
+// softplus(x) and sigmoid(x) from one exp:  e = exp(-|x|)
+__device__ __forceinline__ void softplus_sigmoid(float x, float& sp, float& sg) {
+    const float e = __expf(-fabsf(x));
+    const float r = 1.f / (1.f + e);
+    sp = fmaxf(x, 0.f) + __logf(1.f + e);
+    sg = x >= 0.f ? r : e * r;
+}
+// accumulate one valid logit into the per-row statistics (mx handled by caller)
+__device__ __forceinline__ void stats_add(RowStats& s, int need, float L, float sm, float lii, float margin) {
+    s.cnt += 1.f;
+    if (need & NEED_CONTR) s.A += fmaxf(L + sm, 0.f);
+    if (need & (NEED_HINGE | NEED_LOGI)) {
+        const float x = (L - lii) + margin;
+        if (need & NEED_HINGE) {
+            s.H += fmaxf(x, 0.f);
+            s.Hc += x > 0.f ? 1.f : 0.f;
+        }
+        if (need & NEED_LOGI) {
+            float sp, sg;
+            softplus_sigmoid(x, sp, sg);
+            s.Lg += sp;
+            s.Ls += sg;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void loss_fwd_dense_kernel(FwdParams p) {
+    const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + c;
+    const int t0 = blockIdx.y * p.tps, t1 = min(p.NT, t0 + p.tps);
+    RowFrag<D> xf;
+    mf_load_frag<D>(xf, p.u, i, i < p.B);
+    const float nu_i = p.nu[i], s_i = p.sgn[i], lii = p.lii[i];
+    const float sm = s_i * p.margin;
+    RowStats st;
+    stats_init(st);
+    for (int tj = t0; tj < t1; ++tj) {
+        const int64_t j0 = (int64_t)tj * 32;
+        RowFrag<D> yf;
+        mf_load_frag<D>(yf, p.v, j0 + c, j0 + c < p.N);
+        const f32x16 acc = mf_tile_scores<D>(yf, xf);
+        const uint32_t mw = p.maskW[(int64_t)tj * p.Bp + i];
+        f32x4 nv4[4], lq4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            nv4[q] = *reinterpret_cast<const f32x4*>(p.nv + j0 + 8 * q + 4 * h);
+            lq4[q] = p.logq ? *reinterpret_cast<const f32x4*>(p.logq + j0 + 8 * q + 4 * h)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float L[16];
+        float tmax = -FLT_MAX;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            L[e] = mf_logit(nu_i, nv4[e >> 2][e & 3], acc[e], s_i, p.sigma, lq4[e >> 2][e & 3]);
+            const bool ok = !((mw >> mf_acc_row(e, h)) & 1u);
+            if (ok) tmax = fmaxf(tmax, L[e]);
+        }
+        float nmx = fmaxf(st.mx, tmax);
+        if (p.need & NEED_LSE) st.se *= __expf(st.mx - nmx);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool ok = !((mw >> mf_acc_row(e, h)) & 1u);
+            if (ok) {
+                stats_add(st, p.need, L[e], sm, lii, p.margin);
+                if (p.need & NEED_LSE) st.se += __expf(L[e] - nmx);
+            }
+        }
+        st.mx = nmx;
+    }
+    // the row's other half of the columns lives in lane ^ 32
+    {
+        const float mx2 = mf_shfl_xor32(st.mx), se2 = mf_shfl_xor32(st.se);
+        lse_merge(st.mx, st.se, mx2, se2);
+        st.cnt += mf_shfl_xor32(st.cnt); st.A += mf_shfl_xor32(st.A);
+        st.H += mf_shfl_xor32(st.H); st.Hc += mf_shfl_xor32(st.Hc);
+        st.Lg += mf_shfl_xor32(st.Lg); st.Ls += mf_shfl_xor32(st.Ls);
+    }
+    if (h == 0) {
+        float* o = p.part + (int64_t)blockIdx.y * NSTAT * p.Bp + i;
+        o[ST_CNT * p.Bp] = st.cnt; o[ST_A * p.Bp] = st.A; o[ST_MX * p.Bp] = st.mx; o[ST_SE * p.Bp] = st.se;
+        o[ST_H * p.Bp] = st.H; o[ST_HC * p.Bp] = st.Hc; o[ST_LG * p.Bp] = st.Lg; o[ST_LS * p.Bp] = st.Ls;
+    }
+}
+
+// merge the item-range splits in split order (deterministic)
+__global__ __launch_bounds__(256) void stats_merge_kernel(const float* __restrict__ part, int nsplit,
+                                                          int64_t Bp, float* __restrict__ stats) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Bp) return;
+    float acc[NSTAT];
+    for (int s = 0; s < NSTAT; ++s) acc[s] = part[(int64_t)s * Bp + i];
+    for (int sp = 1; sp < nsplit; ++sp) {
+        const float* q = part + (int64_t)sp * NSTAT * Bp + i;
+        lse_merge(acc[ST_MX], acc[ST_SE], q[ST_MX * Bp], q[ST_SE * Bp]);
+        acc[ST_CNT] += q[ST_CNT * Bp]; acc[ST_A] += q[ST_A * Bp]; acc[ST_H] += q[ST_H * Bp];
+        acc[ST_HC] += q[ST_HC * Bp]; acc[ST_LG] += q[ST_LG * Bp]; acc[ST_LS] += q[ST_LS * Bp];
+    }
+    for (int s = 0; s < NSTAT; ++s) stats[(int64_t)s * Bp + i] = acc[s];
+}
+
+// per-row losses of all seven classes from the row statistics
+__global__ __launch_bounds__(256) void rowloss_kernel(const float* __restrict__ stats, const float* __restrict__ target,
+                                                      const float* __restrict__ lii, const float* __restrict__ dii,
+                                                      int64_t B, int64_t Bp, float sigma, float* __restrict__ rowloss) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Bp) return;
+    float out[MF_NUM_KINDS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < B) {
+        const float t = target[i], w = fabsf(t), l = lii[i];
+        const float cnt = stats[ST_CNT * Bp + i], mx = stats[ST_MX * Bp + i], se = stats[ST_SE * Bp + i];
+        const float den = cnt + 1e-10f;
+        const float align = dii[i] * t * sigma;                       // losses.py:164-170
+        const float contr = (stats[ST_A * Bp + i] / den) * w;         // losses.py:172-193
+        const float m2 = fmaxf(mx, l);
+        const float se2 = se * __expf(mx - m2) + __expf(l - m2);
+        const float lse_all = m2 + __logf(se2);                       // diagonal forced in, :213-215
+        const float lse_neg = cnt > 0.f ? mx + __logf(se) : -INFINITY;  // :242 (no valid negative: -inf)
+        out[MF_ALIGNMENT] = align;
+        out[MF_CONTRASTIVE] = contr;
+        out[MF_ALIGNMENT_CONTRASTIVE] = align + contr;
+        out[MF_INFONCE] = (lse_all - l) * w;
+        out[MF_MINE] = (-l + lse_neg) * w;
+        out[MF_PAIRWISE_HINGE] = (stats[ST_H * Bp + i] / den) * w;
+        out[MF_PAIRWISE_LOGISTIC] = (stats[ST_LG * Bp + i] / den) * w;
+    }
+    for (int k = 0; k < MF_NUM_KINDS; ++k) rowloss[(int64_t)k * Bp + i] = out[k];
+}
+
+// fixed-order sum over the batch: one block per loss kind
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ rowloss, int64_t B, int64_t Bp,
+                                                          int kind_mask, float* __restrict__ out) {
+    __shared__ float sh[256];
+    const int k = blockIdx.x;
+    if (!((kind_mask >> k) & 1)) return;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < B; i += 256) acc += rowloss[(int64_t)k * Bp + i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void mask_export_dense_kernel(const uint32_t* __restrict__ maskW, int64_t B,
+                                                                int64_t N, int64_t Bp, int NT,
+                                                                uint32_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * NT) return;
+    const int64_t i = t / NT;
+    const int w = (int)(t % NT);
+    uint32_t bits = ~maskW[(int64_t)w * Bp + i];
+    const int64_t rem = N - (int64_t)w * 32;
+    if (rem < 32) bits &= (1u << rem) - 1u;
+    out[i * NT + w] = bits;
+}
+
+// ------------------------------------------------------------- mined forward ---
+struct MiningPolicy {
+    struct Params {
+        const float *nu, *nv, *lii, *sgn, *logq;
+        const uint32_t* maskW;
+        int64_t Bp, N;
+        float sigma;
+    };
+    struct Row {
+        float nu, sgn, lii;
+    };
+    struct Tile {
+        uint32_t mw;
+        f32x4 nv4[4], lq4[4];
+    };
+    static __device__ __forceinline__ Row row_init(const Params& p, int64_t x, bool) {
+        return Row{p.nu[x], p.sgn[x], p.lii[x]};
+    }
+    static __device__ __forceinline__ Tile tile_init(const Params& p, const Row&, int64_t y0, int64_t x) {
+        Tile t;
+        const int h = mf_lane() >> 5;
+        t.mw = p.maskW[(y0 >> 5) * p.Bp + x];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t.nv4[q] = *reinterpret_cast<const f32x4*>(p.nv + y0 + 8 * q + 4 * h);
+            t.lq4[q] = p.logq ? *reinterpret_cast<const f32x4*>(p.logq + y0 + 8 * q + 4 * h)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return t;
+    }
+    static __device__ __forceinline__ unsigned long long key(const Params& p, const Row& r, const Tile& t,
+                                                            float score, int e, int h, int64_t y) {
+        if ((t.mw >> mf_acc_row(e, h)) & 1u) return 0ull;   // hit, diagonal or padding column
+        const float L = mf_logit(r.nu, t.nv4[e >> 2][e & 3], score, r.sgn, p.sigma, t.lq4[e >> 2][e & 3]);
+        return mf_key_mining(L - r.lii, (unsigned)y);
+    }
+    static __device__ __forceinline__ bool excluded(const Params&, const Row&, int64_t) { return false; }
+};
+
+// one wave per user: exact ordered top-k of the chunk candidates -> sel[i][0..cnt)
+__global__ __launch_bounds__(64) void mined_merge_kernel(const unsigned long long* __restrict__ cand,
+                                                         const int32_t* __restrict__ cand_cnt, int nchunk,
+                                                         int64_t Bp, int CAP, int k, int32_t* __restrict__ sel,
+                                                         int32_t* __restrict__ sel_cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+    const int64_t i = blockIdx.x;
+    const int lane = mf_lane();
+    int total = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int n = cand_cnt[(int64_t)ch * Bp + i];
+        const unsigned long long* src = cand + ((int64_t)ch * Bp + i) * CAP;
+        for (int t = lane; t < n; t += 64) s_keys[total + t] = src[t];
+        total += n;
+    }
+    __syncthreads();
+    int32_t* out = sel + i * KSEL_MAX;
+    int found = 0;
+    mf_wave_select(s_keys, total, k, [&](int t, unsigned long long key) {
+        if (key != 0ull) {
+            out[t] = (int32_t)mf_key_mining_col(key);
+            found = t + 1;
+        }
+    });
+    if (lane == 0) sel_cnt[i] = found;
+}
+
+// statistics of the mined negatives (thread per user, selection order)
+__global__ __launch_bounds__(256) void mined_stats_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                          const float* __restrict__ nu, const float* __restrict__ nv,
+                                                          const float* __restrict__ lii, const float* __restrict__ sgn,
+                                                          const float* __restrict__ logq,
+                                                          const int32_t* __restrict__ sel,
+                                                          const int32_t* __restrict__ sel_cnt, int64_t B, int64_t Bp,
+                                                          int d, float sigma, float margin, int need,
+                                                          float* __restrict__ sel_L, float* __restrict__ stats) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Bp) return;
+    RowStats st;
+    stats_init(st);
+    if (i < B) {
+        const int n = sel_cnt[i];
+        const float s_i = sgn[i], l = lii[i], sm = s_i * margin;
+        for (int t = 0; t < n; ++t) {
+            const int64_t j = sel[i * KSEL_MAX + t];
+            const float dot = mf_dot_chain(u + i * d, v + j * d, d);
+            const float L = mf_logit(nu[i], nv[j], dot, s_i, sigma, logq ? logq[j] : 0.f);
+            sel_L[i * KSEL_MAX + t] = L;
+            stats_add(st, need, L, sm, l, margin);
+            if (need & NEED_LSE) lse_merge(st.mx, st.se, L, 1.f);
+        }
+    }
+    float* o = stats + i;
+    o[ST_CNT * Bp] = st.cnt; o[ST_A * Bp] = st.A; o[ST_MX * Bp] = st.mx; o[ST_SE * Bp] = st.se;
+    o[ST_H * Bp] = st.H; o[ST_HC * Bp] = st.Hc; o[ST_LG * Bp] = st.Lg; o[ST_LS * Bp] = st.Ls;
+}
+
+__global__ __launch_bounds__(256) void mask_export_mined_kernel(const int32_t* __restrict__ sel,
+                                                                const int32_t* __restrict__ sel_cnt, int64_t B,
+                                                                int NT, uint32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const int n = sel_cnt[i];
+    for (int t = 0; t < n; ++t) {
+        const int j = sel[i * KSEL_MAX + t];
+        out[i * NT + (j >> 5)] |= 1u << (j & 31);   // one thread owns the whole row
+    }
+}
+
+// ------------------------------------------------------------------ backward ---
+// rowc[0] = a, rowc[1] = b, rowc[2] = coefG, rowc[3] = gdiag  with, for element (i, j),
+//   G'_ij = coefG_i * g((L_ij - a_i) + b_i)   (valid negatives),  G'_ii = gdiag_i,
+//   du_i = sum_j G'_ij (v_j - u_i),  dv_j = sum_i G'_ij (u_i - v_j).
+__global__ __launch_bounds__(256) void rowc_kernel(const float* __restrict__ stats, const float* __restrict__ target,
+                                                   const float* __restrict__ lii, const float* __restrict__ sgn,
+                                                   const float* __restrict__ grad_out, int64_t B, int64_t Bp, int kind,
+                                                   float sigma, float margin, float* __restrict__ rowc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Bp) return;
+    float a = 0.f, b = 0.f, cg = 0.f, gd = 0.f;
+    if (i < B) {
+        const float w = fabsf(target[i]), s = sgn[i], l = lii[i];
+        const float base = grad_out[0] * sigma * s * w;
+        const float cnt = stats[ST_CNT * Bp + i], mx = stats[ST_MX * Bp + i], se = stats[ST_SE * Bp + i];
+        const float den = cnt + 1e-10f;
+        switch (kind) {
+            case MF_ALIGNMENT: gd = -base; break;
+            case MF_CONTRASTIVE: b = s * margin; cg = base / den; break;
+            case MF_ALIGNMENT_CONTRASTIVE: b = s * margin; cg = base / den; gd = -base; break;
+            case MF_INFONCE: {
+                const float m2 = fmaxf(mx, l);
+                const float lse = m2 + __logf(se * __expf(mx - m2) + __expf(l - m2));
+                a = lse; cg = base; gd = base * (__expf(l - lse) - 1.f);
+            } break;
+            case MF_MINE: a = cnt > 0.f ? mx + __logf(se) : 0.f; cg = cnt > 0.f ? base : 0.f; gd = -base; break;
+            case MF_PAIRWISE_HINGE: a = l; b = margin; cg = base / den; gd = -cg * stats[ST_HC * Bp + i]; break;
+            case MF_PAIRWISE_LOGISTIC: a = l; b = margin; cg = base / den; gd = -cg * stats[ST_LS * Bp + i]; break;
+        }
+    }
+    rowc[0 * Bp + i] = a; rowc[1 * Bp + i] = b; rowc[2 * Bp + i] = cg; rowc[3 * Bp + i] = gd;
+}
+
+static int gmode_of(int kind) {
+    switch (kind) {
+        case MF_INFONCE: case MF_MINE: return G_EXP;
+        case MF_PAIRWISE_LOGISTIC: return G_SIGM;
+        default: return G_STEP;
+    }
+}
+
+__device__ __forceinline__ float g_of(int gmode, float x) {
+    if (gmode == G_EXP) return __expf(x);
+    if (gmode == G_STEP) return x > 0.f ? 1.f : 0.f;
+    const float e = __expf(-fabsf(x));
+    const float r = 1.f / (1.f + e);
+    return x >= 0.f ? r : e * r;
+}
+
+struct BwdParams {
+    const float *u, *v, *nu, *nv, *sgn, *logq, *rowc;
+    const uint32_t *maskW, *maskTW;
+    float* dpart;
+    int64_t B, N, Bp, Np;
+    int YT, tps, gmode;
+    float sigma;
+};
+
+// XU = true : lanes hold users, item tiles stream, result d loss / d u
+// XU = false: lanes hold items, user tiles stream, result d loss / d v
+template <int D, bool XU>
+__global__ __launch_bounds__(64) void loss_bwd_dense_kernel(BwdParams p) {
+    const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
+    const int64_t x = (int64_t)blockIdx.x * 32 + c;
+    const int64_t nX = XU ? p.B : p.N, nY = XU ? p.N : p.B;
+    const int64_t Xp = XU ? p.Bp : p.Np;
+    const float* X = XU ? p.u : p.v;
+    const float* Y = XU ? p.v : p.u;
+    const int t0 = blockIdx.y * p.tps, t1 = min(p.YT, t0 + p.tps);
+    RowFrag<D> xf;
+    mf_load_frag<D>(xf, X, x, x < nX);
+    // per-lane constants of the X row
+    float xa = 0.f, xb = 0.f, xc = 0.f, xd = 0.f, xn, xs = 0.f, xq = 0.f;
+    if (XU) {
+        xn = p.nu[x]; xs = p.sgn[x];
+        xa = p.rowc[x]; xb = p.rowc[p.Bp + x]; xc = p.rowc[2 * p.Bp + x]; xd = p.rowc[3 * p.Bp + x];
+    } else {
+        xn = p.nv[x]; xq = p.logq ? p.logq[x] : 0.f;
+    }
+    f32x16 dacc[D / 32];
+#pragma unroll
+    for (int mb = 0; mb < D / 32; ++mb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dacc[mb][e] = 0.f;
+    float rsum = 0.f;
+
+    for (int ty = t0; ty < t1; ++ty) {
+        const int64_t y0 = (int64_t)ty * 32;
+        RowFrag<D> yf;
+        mf_load_frag<D>(yf, Y, y0 + c, y0 + c < nY);
+        const f32x16 acc = mf_tile_scores<D>(yf, xf);
+        const uint32_t mw = XU ? p.maskW[(int64_t)ty * p.Bp + x] : p.maskTW[(int64_t)ty * p.Np + x];
+        f32x4 yn4[4], yq4[4], ys4[4], ya4[4], yb4[4], yc4[4], yd4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t o = y0 + 8 * q + 4 * h;
+            if (XU) {
+                yn4[q] = *reinterpret_cast<const f32x4*>(p.nv + o);
+                yq4[q] = p.logq ? *reinterpret_cast<const f32x4*>(p.logq + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                yn4[q] = *reinterpret_cast<const f32x4*>(p.nu + o);
+                ys4[q] = *reinterpret_cast<const f32x4*>(p.sgn + o);
+                ya4[q] = *reinterpret_cast<const f32x4*>(p.rowc + o);
+                yb4[q] = *reinterpret_cast<const f32x4*>(p.rowc + p.Bp + o);
+                yc4[q] = *reinterpret_cast<const f32x4*>(p.rowc + 2 * p.Bp + o);
+                yd4[q] = *reinterpret_cast<const f32x4*>(p.rowc + 3 * p.Bp + o);
+            }
+        }
+        float G[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int q = e >> 2, t = e & 3;
+            const int64_t y = y0 + mf_acc_row(e, h);
+            float L, a, b, cg, gd;
+            if (XU) {
+                L = mf_logit(xn, yn4[q][t], acc[e], xs, p.sigma, yq4[q][t]);
+                a = xa; b = xb; cg = xc; gd = xd;
+            } else {
+                L = mf_logit(yn4[q][t], xn, acc[e], ys4[q][t], p.sigma, xq);
+                a = ya4[q][t]; b = yb4[q][t]; cg = yc4[q][t]; gd = yd4[q][t];
+            }
+            float g = cg * g_of(p.gmode, (L - a) + b);
+            if ((mw >> mf_acc_row(e, h)) & 1u) g = 0.f;
+            if (x == y) g = gd;
+            G[e] = g;
+            rsum += g;
+        }
+        // dX[m][x] += sum_y Y[y][m] * G[y][x]   (the G tile is already a B operand)
+#pragma unroll
+        for (int mb = 0; mb < D / 32; ++mb) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                int64_t y = y0 + mf_acc_row(t, h);
+                y = y < nY ? y : 0;                      // G is 0 there (padding bit)
+                const float yv = Y[y * D + mb * 32 + c];
+                dacc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv, G[t], dacc[mb], 0, 0, 0);
+            }
+        }
+    }
+    rsum += mf_shfl_xor32(rsum);
+    // dX[x][m] = dacc - rsum * X[x][m];  register e of block mb is m = 8 (4 mb + (e>>2)) + 4 h + (e&3)
+    if (x < nX) {
+        float* o = p.dpart + ((int64_t)blockIdx.y * Xp + x) * D;
+#pragma unroll
+        for (int mb = 0; mb < D / 32; ++mb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = 4 * mb + q;
+                f32x4 r;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) r[t] = dacc[mb][4 * q + t] - rsum * xf.v[g][t];
+                *reinterpret_cast<f32x4*>(o + 8 * g + 4 * h) = r;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ dpart, int nsplit, int64_t rows,
+                                                        int64_t rows_p, int d, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one float4 each
+    const int64_t per_row = d / 4;
+    if (t >= rows * per_row) return;
+    const int64_t r = t / per_row, cidx = t % per_row;
+    f32x4 acc = reinterpret_cast<const f32x4*>(dpart + r * d)[cidx];
+    for (int s = 1; s < nsplit; ++s) acc += reinterpret_cast<const f32x4*>(dpart + ((int64_t)s * rows_p + r) * d)[cidx];
+    reinterpret_cast<f32x4*>(out + r * d)[cidx] = acc;
+}
+
+// alignment-only backward: only the diagonal carries gradient
+template <int D>
+__global__ __launch_bounds__(256) void diag_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                       const float* __restrict__ rowc, int64_t B, int64_t N, int64_t Bp,
+                                                       float* __restrict__ du, float* __restrict__ dv) {
+    constexpr int LPR = D / 4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = t / LPR;
+    const int c = (int)(t % LPR);
+    if (r >= N) return;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (r < B) {
+        const float gd = rowc[3 * Bp + r];
+        const f32x4 ui = reinterpret_cast<const f32x4*>(u + r * D)[c];
+        const f32x4 vi = reinterpret_cast<const f32x4*>(v + r * D)[c];
+        reinterpret_cast<f32x4*>(du + r * D)[c] = gd * (vi - ui);
+        reinterpret_cast<f32x4*>(dv + r * D)[c] = gd * (ui - vi);
+    } else {
+        reinterpret_cast<f32x4*>(dv + r * D)[c] = z;
+    }
+}
+
+// mined backward: a d/4-lane group per user walks its selected negatives
+template <int D>
+__global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                        const float* __restrict__ rowc, const int32_t* __restrict__ sel,
+                                                        const int32_t* __restrict__ sel_cnt,
+                                                        const float* __restrict__ sel_L, int64_t B, int64_t Bp,
+                                                        int gmode, float* __restrict__ du, float* __restrict__ dv) {
+    constexpr int LPR = D / 4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = t / LPR;
+    const int c = (int)(t % LPR);
+    if (i >= B) return;
+    const float a = rowc[i], b = rowc[Bp + i], cg = rowc[2 * Bp + i], gd = rowc[3 * Bp + i];
+    const f32x4 ui = reinterpret_cast<const f32x4*>(u + i * D)[c];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int n = sel_cnt[i];
+    for (int s = -1; s < n; ++s) {
+        int64_t j;
+        float g;
+        if (s < 0) { j = i; g = gd; }
+        else { j = sel[i * KSEL_MAX + s]; g = cg * g_of(gmode, (sel_L[i * KSEL_MAX + s] - a) + b); }
+        const f32x4 vj = reinterpret_cast<const f32x4*>(v + j * D)[c];
+        acc += g * (vj - ui);
+        const f32x4 dvj = g * (ui - vj);
+        float* o = dv + j * D + 4 * c;
+        atomicAdd(o + 0, dvj[0]); atomicAdd(o + 1, dvj[1]); atomicAdd(o + 2, dvj[2]); atomicAdd(o + 3, dvj[3]);
+    }
+    reinterpret_cast<f32x4*>(du + i * D)[c] = acc;
+}
+
+// ------------------------------------------------------------------ C ABI ------
+static int check_loss_args(const char* what, int64_t B, int64_t N, int d, int P, int num_negatives,
+                           const void* u, const void* v, const void* target, void* ws, size_t ws_bytes) {
+    if (B <= 0 || N < B) return mf_set_error(MF_EINVAL, "%s: need 0 < B <= N (B=%lld N=%lld)", what, (long long)B, (long long)N);
+    if (!mf_width_ok(d)) return mf_set_error(MF_EINVAL, "%s: embedding width %d not in {32,64,128,256}", what, d);
+    if (P < 0 || !u || !v || !target || !ws) return mf_set_error(MF_EINVAL, "%s: bad argument", what);
+    if (N >= (1 << 24)) return mf_set_error(MF_ENOTSUP, "%s: N >= 2^24", what);
+    if (mining_on(num_negatives, N) && num_negatives > KSEL_MAX)
+        return mf_set_error(MF_ENOTSUP, "%s: mining with num_negatives = %d > %d", what, num_negatives, KSEL_MAX);
+    if (ws_bytes < mf_loss_ws_bytes(B, N, d, P, num_negatives))
+        return mf_set_error(MF_ENOSPC, "%s: workspace too small (%zu < %zu)", what, ws_bytes,
+                            mf_loss_ws_bytes(B, N, d, P, num_negatives));
+    return MF_OK;
+}
+
+template <int D>
+static void launch_mining_select(const LossWs& w, const MiningPolicy::Params& mp, const SelectCommon& sc,
+                                 hipStream_t s) {
+    dim3 grid((unsigned)w.BT, (unsigned)w.nchunk);
+#define MF_SEL(TT, CC) select_kernel<D, TT, CC, MiningPolicy><<<grid, 64, 0, s>>>(mp, sc)
+    switch (w.T) {
+        case 2: MF_SEL(2, 64); break;
+        case 4: MF_SEL(4, 64); break;
+        case 8: MF_SEL(8, 64); break;
+        case 12: MF_SEL(12, 64); break;
+        case 16: MF_SEL(16, 128); break;
+        default: MF_SEL(32, 128); break;
+    }
+#undef MF_SEL
+}
+
+extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
+                           int kind_mask, const float* u, const float* v, const float* target,
+                           const int64_t* item_idx, const int64_t* pos_idx, const float* logq, void* ws,
+                           size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits, mf_stream_t stream) {
+    int rc = check_loss_args("mf_loss_fwd", B, N, d, P, num_negatives, u, v, target, ws, ws_bytes);
+    if (rc) return rc;
+    if (!item_idx || !out_losses || (P > 0 && !pos_idx) || !(kind_mask & 0x7F))
+        return mf_set_error(MF_EINVAL, "mf_loss_fwd: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LossWs w = loss_ws(ws, B, N, d, P, num_negatives);
+    const int need = need_flags(kind_mask);
+    const bool scores_needed = (kind_mask & ~(1 << MF_ALIGNMENT)) != 0 || out_mask_bits;
+
+    (void)hipMemsetAsync(w.nu, 0, (size_t)w.Bp * 4, s);
+    (void)hipMemsetAsync(w.nv, 0, (size_t)w.Np * 4, s);
+    if ((rc = mf_row_sqnorm(u, B, d, w.nu, stream))) return rc;
+    if ((rc = mf_row_sqnorm(v, N, d, w.nv, stream))) return rc;
+    diag_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(u, v, target, logq, w.nu, w.nv, B, w.Bp, d, sigma,
+                                                                     w.lii, w.dii, w.sgn);
+    if (scores_needed) {
+        if ((rc = mf_sort_keys(item_idx, N, w.perm, w.skeys, w.sort_ws, mf_sort_ws_bytes(N), stream))) return rc;
+        (void)hipMemsetAsync(w.maskW, 0, (size_t)w.NT * w.Bp * 4, s);
+        (void)hipMemsetAsync(w.maskTW, 0, (size_t)w.BT * w.Np * 4, s);
+        const int64_t mx = w.Bp > w.Np ? w.Bp : w.Np;
+        mask_pad_kernel<<<dim3((unsigned)((mx + 255) / 256)), 256, 0, s>>>(w.maskW, w.maskTW, B, N, w.Bp, w.Np, w.BT, w.NT);
+        const int64_t nthreads = B * (P + 1);
+        mask_build_kernel<<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(item_idx, pos_idx, w.perm, w.skeys, B, N, P,
+                                                                                   w.Bp, w.Np, w.maskW, w.maskTW);
+    }
+    // logq is read by whole float4s up to the padded width: keep a zero-padded copy in ws
+    const float* logq_p = nullptr;
+    if (logq) {
+        (void)hipMemsetAsync(w.logq, 0, (size_t)w.Np * 4, s);
+        (void)hipMemcpyAsync(w.logq, logq, (size_t)N * 4, hipMemcpyDeviceToDevice, s);
+        logq_p = w.logq;
+    }
+    if (scores_needed && !w.mined) {
+        FwdParams fp{u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.part, B, N, w.Bp, w.NT, w.tps_f, need, sigma, margin};
+        MF_DISPATCH_D(d, {
+            dim3 grid((unsigned)w.BT, (unsigned)w.nsplit_f);
+            loss_fwd_dense_kernel<D><<<grid, 64, 0, s>>>(fp);
+        });
+        stats_merge_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(w.part, w.nsplit_f, w.Bp, w.stats);
+        if (out_mask_bits)
+            mask_export_dense_kernel<<<dim3((unsigned)((B * w.NT + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, w.NT, out_mask_bits);
+    } else if (scores_needed) {
+        MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
+        SelectCommon sc{u, B, v, N, w.NT, w.tpc, w.Bp, num_negatives, w.cand, w.cand_cnt};
+        MF_DISPATCH_D(d, { launch_mining_select<D>(w, mp, sc, s); });
+        mined_merge_kernel<<<dim3((unsigned)B), 64, (size_t)w.nchunk * w.CAP * 8, s>>>(w.cand, w.cand_cnt, w.nchunk, w.Bp, w.CAP,
+                                                                                      num_negatives, w.sel, w.sel_cnt);
+        mined_stats_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.sel,
+                                                                                w.sel_cnt, B, w.Bp, d, sigma, margin, need,
+                                                                                w.sel_L, w.stats);
+        if (out_mask_bits) {
+            (void)hipMemsetAsync(out_mask_bits, 0, (size_t)B * w.NT * 4, s);
+            mask_export_mined_kernel<<<dim3((unsigned)((B + 255) / 256)), 256, 0, s>>>(w.sel, w.sel_cnt, B, w.NT, out_mask_bits);
+        }
+    } else {
+        (void)hipMemsetAsync(w.stats, 0, (size_t)NSTAT * w.Bp * 4, s);
+    }
+    rowloss_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(w.stats, target, w.lii, w.dii, B, w.Bp, sigma, w.rowloss);
+    loss_reduce_kernel<<<dim3(MF_NUM_KINDS), 256, 0, s>>>(w.rowloss, B, w.Bp, kind_mask, out_losses);
+    return mf_check_launch("mf_loss_fwd");
+}
+
+extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
+                           int kind, const float* u, const float* v, const float* target, const float* logq,
+                           void* ws, size_t ws_bytes, const float* grad_out, float* du, float* dv,
+                           mf_stream_t stream) {
+    int rc = check_loss_args("mf_loss_bwd", B, N, d, P, num_negatives, u, v, target, ws, ws_bytes);
+    if (rc) return rc;
+    if (kind < 0 || kind >= MF_NUM_KINDS || !grad_out || !du || !dv)
+        return mf_set_error(MF_EINVAL, "mf_loss_bwd: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LossWs w = loss_ws(ws, B, N, d, P, num_negatives);
+    rowc_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(w.stats, target, w.lii, w.sgn, grad_out, B, w.Bp, kind,
+                                                                     sigma, margin, w.rowc);
+    const int gmode = gmode_of(kind);
+    if (kind == MF_ALIGNMENT) {
+        MF_DISPATCH_D(d, {
+            const int64_t nthreads = N * (D / 4);
+            diag_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, B, N, w.Bp, du, dv);
+        });
+    } else if (w.mined) {
+        (void)hipMemsetAsync(dv, 0, (size_t)N * d * 4, s);
+        MF_DISPATCH_D(d, {
+            const int64_t nthreads = B * (D / 4);
+            mined_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, w.sel, w.sel_cnt, w.sel_L, B,
+                                                                                        w.Bp, gmode, du, dv);
+        });
+    } else {
+        BwdParams bp{u, v, w.nu, w.nv, w.sgn, logq ? w.logq : nullptr, w.rowc, w.maskW, w.maskTW, w.dpart, B, N, w.Bp, w.Np, 0, 0, gmode, sigma};
+        MF_DISPATCH_D(d, {
+            bp.YT = w.NT; bp.tps = w.tps_u;
+            loss_bwd_dense_kernel<D, true><<<dim3((unsigned)w.BT, (unsigned)w.nsplit_u), 64, 0, s>>>(bp);
+            sum_parts_kernel<<<dim3((unsigned)((B * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_u, B, w.Bp, D, du);
+            bp.YT = w.BT; bp.tps = w.tps_v;
+            loss_bwd_dense_kernel<D, false><<<dim3((unsigned)w.NT, (unsigned)w.nsplit_v), 64, 0, s>>>(bp);
+            sum_parts_kernel<<<dim3((unsigned)((N * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_v, N, w.Np, D, dv);
+        });
+    }
+    return mf_check_launch("mf_loss_bwd");
+}

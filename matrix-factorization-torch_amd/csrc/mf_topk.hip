@@ -1,0 +1,178 @@
+// mf_topk.hip -- exact brute-force full-catalog top-k (retrieval), gfx950.
+//
+// Replaces ItemProcessor.search (xfmr_rec/data/lightning.py:237-259, LanceDB cosine
+// ANN + prefilter) by an exact scan: score tiles from the fp32 MFMA engine, streaming
+// per-query selection (mf_select.h), exclusion lists checked only for the few
+// survivors of the running threshold, then an exact ordered merge per query.
+// The same merge kernel joins the all-gathered partial top-k of a row-sharded
+// catalog (mf_topk_merge).
+#include <cmath>
+
+#include "mf_common.h"
+#include "mf_select.h"
+
+struct RetrievalPolicy {
+    struct Params {
+        const int64_t* excl_off;   // [Q + 1] or null
+        const int64_t* excl_idx;   // sorted ascending inside each query's range
+        int64_t idx_base, nY, nX;
+    };
+    struct Row {
+        int64_t lo, hi;
+    };
+    struct Tile {};
+    static __device__ __forceinline__ Row row_init(const Params& p, int64_t x, bool valid) {
+        if (!p.excl_off || !valid) return Row{0, 0};
+        return Row{p.excl_off[x], p.excl_off[x + 1]};
+    }
+    static __device__ __forceinline__ Tile tile_init(const Params&, const Row&, int64_t, int64_t) { return Tile{}; }
+    static __device__ __forceinline__ unsigned long long key(const Params& p, const Row&, const Tile&, float score,
+                                                            int, int, int64_t y) {
+        return y < p.nY ? mf_key_retrieval(score, (unsigned)y) : 0ull;
+    }
+    static __device__ __forceinline__ bool excluded(const Params& p, const Row& r, int64_t y) {
+        const int64_t want = p.idx_base + y;
+        int64_t lo = r.lo, hi = r.hi;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            const int64_t v = p.excl_idx[mid];
+            if (v == want) return true;
+            if (v < want) lo = mid + 1; else hi = mid;
+        }
+        return false;
+    }
+};
+
+struct TopkWs {
+    int64_t Qp;
+    int QT, NT, T, CAP, nchunk, tpc;
+    unsigned long long* cand;
+    int32_t* cand_cnt;
+    size_t total;
+};
+
+static TopkWs topk_ws(void* base, int64_t Q, int64_t N, int k) {
+    TopkWs w{};
+    w.Qp = mf_pad32(Q);
+    w.QT = (int)(w.Qp / 32);
+    w.NT = (int)(mf_pad32(N) / 32);
+    w.T = k <= 4 ? 2 : k <= 8 ? 4 : k <= 16 ? 8 : k <= 24 ? 12 : k <= 32 ? 16 : 32;
+    w.CAP = k <= 24 ? 64 : 128;
+    int maxchunk = (64 * 1024) / (w.CAP * 8);
+    int want = (2048 + w.QT - 1) / w.QT;
+    if (want > maxchunk) want = maxchunk;
+    if (want > w.NT) want = w.NT;
+    if (want < 1) want = 1;
+    w.tpc = (w.NT + want - 1) / want;
+    w.nchunk = (w.NT + w.tpc - 1) / w.tpc;
+    MfArena a(base);
+    w.cand = a.take<unsigned long long>((size_t)w.nchunk * w.Qp * w.CAP);
+    w.cand_cnt = a.take<int32_t>((size_t)w.nchunk * w.Qp);
+    w.total = a.used();
+    return w;
+}
+
+extern "C" size_t mf_topk_ws_bytes(int64_t Q, int64_t N, int d, int k) {
+    (void)d;
+    if (Q <= 0 || N <= 0 || k <= 0) return 0;
+    return topk_ws(nullptr, Q, N, k).total;
+}
+
+// one wave per query: candidates of all chunks -> ordered top-k
+__global__ __launch_bounds__(64) void topk_merge_cand_kernel(const unsigned long long* __restrict__ cand,
+                                                             const int32_t* __restrict__ cand_cnt, int nchunk,
+                                                             int64_t Qp, int CAP, int k, int64_t idx_base,
+                                                             float* __restrict__ out_scores,
+                                                             int64_t* __restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+    const int64_t r = blockIdx.x;
+    const int lane = mf_lane();
+    int total = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int n = cand_cnt[(int64_t)ch * Qp + r];
+        const unsigned long long* src = cand + ((int64_t)ch * Qp + r) * CAP;
+        for (int t = lane; t < n; t += 64) s_keys[total + t] = src[t];
+        total += n;
+    }
+    __syncthreads();
+    mf_wave_select(s_keys, total, k, [&](int t, unsigned long long key) {
+        if (key != 0ull) {
+            out_scores[r * k + t] = mf_key_retrieval_score(key);
+            out_idx[r * k + t] = idx_base + (int64_t)mf_key_retrieval_col(key);
+        } else {
+            out_scores[r * k + t] = -INFINITY;
+            out_idx[r * k + t] = -1;
+        }
+    });
+}
+
+// merge of G already-ordered partial results with GLOBAL indices (< 2^32)
+__global__ __launch_bounds__(64) void topk_merge_parts_kernel(const float* __restrict__ ps, const int64_t* __restrict__ pi,
+                                                              int G, int64_t Q, int k, float* __restrict__ out_scores,
+                                                              int64_t* __restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+    const int64_t r = blockIdx.x;
+    const int lane = mf_lane();
+    const int total = G * k;
+    for (int t = lane; t < total; t += 64) {
+        const int g = t / k, e = t % k;
+        const int64_t id = pi[((int64_t)g * Q + r) * k + e];
+        s_keys[t] = id >= 0 ? mf_key_retrieval(ps[((int64_t)g * Q + r) * k + e], (unsigned)id) : 0ull;
+    }
+    __syncthreads();
+    mf_wave_select(s_keys, total, k, [&](int t, unsigned long long key) {
+        if (key != 0ull) {
+            out_scores[r * k + t] = mf_key_retrieval_score(key);
+            out_idx[r * k + t] = (int64_t)mf_key_retrieval_col(key);
+        } else {
+            out_scores[r * k + t] = -INFINITY;
+            out_idx[r * k + t] = -1;
+        }
+    });
+}
+
+template <int D>
+static void launch_topk_select(const TopkWs& w, const RetrievalPolicy::Params& rp, const SelectCommon& sc, hipStream_t s) {
+    dim3 grid((unsigned)w.QT, (unsigned)w.nchunk);
+#define MF_SEL(TT, CC) select_kernel<D, TT, CC, RetrievalPolicy><<<grid, 64, 0, s>>>(rp, sc)
+    switch (w.T) {
+        case 2: MF_SEL(2, 64); break;
+        case 4: MF_SEL(4, 64); break;
+        case 8: MF_SEL(8, 64); break;
+        case 12: MF_SEL(12, 64); break;
+        case 16: MF_SEL(16, 128); break;
+        default: MF_SEL(32, 128); break;
+    }
+#undef MF_SEL
+}
+
+extern "C" int mf_topk(const float* q, int64_t Q, const float* items, int64_t N, int d, int k,
+                       const int64_t* excl_off, const int64_t* excl_idx, int64_t idx_base, void* ws,
+                       size_t ws_bytes, float* out_scores, int64_t* out_idx, mf_stream_t stream) {
+    if (!q || !items || !out_scores || !out_idx || !ws || Q <= 0 || N <= 0)
+        return mf_set_error(MF_EINVAL, "mf_topk: bad argument");
+    if (k <= 0 || k > 64) return mf_set_error(MF_ENOTSUP, "mf_topk: k = %d outside 1..64", k);
+    if (!mf_width_ok(d)) return mf_set_error(MF_EINVAL, "mf_topk: embedding width %d not in {32,64,128,256}", d);
+    if (N >= (1ll << 32) || idx_base < 0 || idx_base + N > (1ll << 32))
+        return mf_set_error(MF_ENOTSUP, "mf_topk: item indices must fit 32 bits");
+    if ((excl_off == nullptr) != (excl_idx == nullptr)) return mf_set_error(MF_EINVAL, "mf_topk: excl_off/excl_idx mismatch");
+    if (ws_bytes < mf_topk_ws_bytes(Q, N, d, k)) return mf_set_error(MF_ENOSPC, "mf_topk: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TopkWs w = topk_ws(ws, Q, N, k);
+    RetrievalPolicy::Params rp{excl_off, excl_idx, idx_base, N, Q};
+    SelectCommon sc{q, Q, items, N, w.NT, w.tpc, w.Qp, k, w.cand, w.cand_cnt};
+    MF_DISPATCH_D(d, { launch_topk_select<D>(w, rp, sc, s); });
+    topk_merge_cand_kernel<<<dim3((unsigned)Q), 64, (size_t)w.nchunk * w.CAP * 8, s>>>(w.cand, w.cand_cnt, w.nchunk, w.Qp, w.CAP, k,
+                                                                                      idx_base, out_scores, out_idx);
+    return mf_check_launch("mf_topk");
+}
+
+extern "C" int mf_topk_merge(const float* part_scores, const int64_t* part_idx, int G, int64_t Q, int k,
+                             float* out_scores, int64_t* out_idx, mf_stream_t stream) {
+    if (!part_scores || !part_idx || !out_scores || !out_idx || G <= 0 || Q <= 0 || k <= 0)
+        return mf_set_error(MF_EINVAL, "mf_topk_merge: bad argument");
+    if ((size_t)G * k * 8 > 64 * 1024) return mf_set_error(MF_ENOTSUP, "mf_topk_merge: G * k too large");
+    topk_merge_parts_kernel<<<dim3((unsigned)Q), 64, (size_t)G * k * 8, static_cast<hipStream_t>(stream)>>>(
+        part_scores, part_idx, G, Q, k, out_scores, out_idx);
+    return mf_check_launch("mf_topk_merge");
+}

@@ -1,0 +1,221 @@
+"""The seven in-batch embedding losses of ``xfmr_rec/losses.py`` on gfx950.
+
+Same class names, constructor keywords (``num_negatives``, ``sigma``, ``margin``;
+losses.py:27-37), call signature (``loss_fn(user_embed, item_embed, target, *,
+item_idx, pos_idx)``; losses.py:39-52) and ``ValueError`` behaviour
+(``check_inputs``, losses.py:54-79) as the reference, so ``get_loss_fns``
+(xfmr_rec/lightning.py:267-287) can instantiate them unchanged.  The arithmetic runs
+in ``libmf_hip.so`` (``mf_loss_fwd`` / ``mf_loss_bwd``); there is no torch fallback.
+
+Extensions (absent upstream, default off): ``logq=`` (logQ correction
+``L_ij -= logq[j]``) and :func:`fused_losses` (all seven values from ONE pass over
+the score tiles, as ``compute_losses`` evaluates all seven every step,
+xfmr_rec/lightning.py:137-146).
+"""
+from __future__ import annotations
+
+import abc
+
+import torch
+
+from . import _lib
+
+KINDS = (
+    "AlignmentLoss",
+    "ContrastiveLoss",
+    "AlignmentContrastiveLoss",
+    "InfomationNoiseContrastiveEstimationLoss",
+    "MutualInformationNeuralEstimationLoss",
+    "PairwiseHingeLoss",
+    "PairwiseLogisticLoss",
+)
+MAX_MINED_NEGATIVES = 64
+
+
+def _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq):
+    u = _lib.dev_f32(user_embed, "user_embed")
+    v = _lib.dev_f32(item_embed, "item_embed")
+    d = u.shape[1]
+    dp = _lib.padded_width(d)
+    if dp != d:  # zero columns change no score (mf_numerics.h)
+        u = torch.nn.functional.pad(u, (0, dp - d))
+        v = torch.nn.functional.pad(v, (0, dp - d))
+    t = _lib.dev_f32(target, "target")
+    ii = _lib.dev_i64(item_idx, "item_idx")
+    if ii.numel() != v.shape[0]:
+        msg = f"item_idx should have one id per item row: {ii.numel() = }, {v.shape[0] = }"
+        raise ValueError(msg)
+    pi = None
+    p = 0
+    if pos_idx is not None:
+        pi = _lib.dev_i64(pos_idx, "pos_idx")
+        if pi.dim() != 2 or pi.shape[0] != u.shape[0]:
+            msg = f"pos_idx should be (batch_size, num_positives): {tuple(pi.shape) = }"
+            raise ValueError(msg)
+        p = pi.shape[1]
+        if p == 0:
+            pi = None
+    lq = None
+    if logq is not None:
+        lq = _lib.dev_f32(logq, "logq")
+        if lq.numel() != v.shape[0]:
+            msg = f"logq should have one value per item row: {lq.numel() = }, {v.shape[0] = }"
+            raise ValueError(msg)
+    return u, v, t, ii, pi, p, lq, d, dp
+
+
+class _LossFunction(torch.autograd.Function):
+    """One pass evaluates every loss in ``kind_mask``; backward differentiates ``bwd_kind``."""
+
+    @staticmethod
+    def forward(ctx, user_embed, item_embed, target, item_idx, pos_idx, logq, kind_mask, bwd_kind,
+                num_negatives, sigma, margin):
+        u, v, t, ii, pi, p, lq, d, dp = _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq)
+        b, n = u.shape[0], v.shape[0]
+        lib = _lib.lib()
+        nbytes = lib.mf_loss_ws_bytes(b, n, dp, p, num_negatives)
+        ws = _lib.workspace(nbytes, u.device)
+        out = torch.zeros(len(KINDS), dtype=torch.float32, device=u.device)
+        _lib.check(lib.mf_loss_fwd(b, n, dp, p, num_negatives, sigma, margin, kind_mask, _lib.ptr(u), _lib.ptr(v),
+                                   _lib.ptr(t), _lib.ptr(ii), _lib.ptr(pi), _lib.ptr(lq), _lib.ptr(ws), ws.numel(),
+                                   _lib.ptr(out), None, _lib.stream_ptr()))
+        ctx.save_for_backward(u, v, t, lq, ws)
+        ctx.meta = (b, n, d, dp, p, num_negatives, sigma, margin, bwd_kind, user_embed.dtype, item_embed.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        u, v, t, lq, ws = ctx.saved_tensors
+        b, n, d, dp, p, k, sigma, margin, bwd_kind, u_dtype, v_dtype = ctx.meta
+        # only the train loss is back-propagated (xfmr_rec/lightning.py:192)
+        nz = torch.nonzero(grad_out).flatten().tolist() if bwd_kind is None else [bwd_kind]
+        du = dv = None
+        lib = _lib.lib()
+        for kind in nz:
+            g = grad_out[kind : kind + 1].to(torch.float32).contiguous()
+            du_k = torch.empty_like(u)
+            dv_k = torch.empty_like(v)
+            _lib.check(lib.mf_loss_bwd(b, n, dp, p, k, sigma, margin, kind, _lib.ptr(u), _lib.ptr(v), _lib.ptr(t),
+                                       _lib.ptr(lq), _lib.ptr(ws), ws.numel(), _lib.ptr(g), _lib.ptr(du_k),
+                                       _lib.ptr(dv_k), _lib.stream_ptr()))
+            du = du_k if du is None else du + du_k
+            dv = dv_k if dv is None else dv + dv_k
+        if du is None:
+            du, dv = torch.zeros_like(u), torch.zeros_like(v)
+        if dp != d:
+            du, dv = du[:, :d], dv[:, :d]
+        return (du.to(u_dtype), dv.to(v_dtype)) + (None,) * 9
+
+
+def check_inputs(user_embed: torch.Tensor, item_embed: torch.Tensor, target: torch.Tensor) -> None:
+    """Same conditions and exception type as losses.py:54-79."""
+    if user_embed.dim() != 2 or item_embed.dim() != 2:  # noqa: PLR2004
+        msg = f"inputs should have 2 dimensions: {user_embed.dim() = }, {item_embed.dim() = }"
+        raise ValueError(msg)
+    if user_embed.size(1) != item_embed.size(1):
+        msg = f"embeddings dimension 1 should match: {user_embed.size(1) = }, {item_embed.size(1) = }"
+        raise ValueError(msg)
+    if not (user_embed.size(0) == target.size(0) and item_embed.size(0) >= target.size(0)):
+        msg = (
+            "embeddings dimension 0 should match: "
+            f"{target.size(0) = }, {user_embed.size(0) = }, {item_embed.size(0) = }"
+        )
+        raise ValueError(msg)
+
+
+def fused_losses(user_embed, item_embed, target, *, item_idx, pos_idx, num_negatives=0, sigma=1.0, margin=1.0,
+                 logq=None, kinds=KINDS) -> dict[str, torch.Tensor]:
+    """All requested losses from one sweep over the score tiles.  Every returned value is
+    differentiable; backward runs one HIP backward per loss that receives gradient."""
+    check_inputs(user_embed, item_embed, target)
+    mask = 0
+    for name in kinds:
+        mask |= 1 << KINDS.index(name)
+    out = _LossFunction.apply(user_embed, item_embed, target, item_idx, pos_idx, logq, mask, None,
+                              int(num_negatives), float(sigma), float(margin))
+    return {name: out[KINDS.index(name)] for name in kinds}
+
+
+class EmbeddingLoss(torch.nn.Module, abc.ABC):
+    """Base class, mirrors ``EmbeddingLoss`` (losses.py:26-79)."""
+
+    def __init__(self, *, num_negatives: int = 0, sigma: float = 1.0, margin: float = 1.0) -> None:
+        super().__init__()
+        self.num_negatives = num_negatives
+        self.sigma = sigma
+        self.margin = margin
+
+    @property
+    def kind(self) -> int:
+        return KINDS.index(type(self).__name__)
+
+    def check_inputs(self, user_embed: torch.Tensor, item_embed: torch.Tensor, target: torch.Tensor) -> None:
+        check_inputs(user_embed, item_embed, target)
+
+    def forward(self, user_embed: torch.Tensor, item_embed: torch.Tensor, target: torch.Tensor, *,
+                item_idx: torch.Tensor, pos_idx: torch.Tensor | None, logq: torch.Tensor | None = None,
+                ) -> torch.Tensor:
+        self.check_inputs(user_embed, item_embed, target)
+        return self.loss(user_embed, item_embed, target, item_idx=item_idx, pos_idx=pos_idx, logq=logq)
+
+    def loss(self, user_embed, item_embed, target, *, item_idx, pos_idx, logq=None) -> torch.Tensor:
+        k = int(self.num_negatives)
+        if 0 < k < item_embed.size(0) and k > MAX_MINED_NEGATIVES and self.kind != 0:
+            msg = f"semi-hard mining supports num_negatives <= {MAX_MINED_NEGATIVES} (or >= num_items): {k = }"
+            raise NotImplementedError(msg)
+        out = _LossFunction.apply(user_embed, item_embed, target, item_idx, pos_idx, logq, 1 << self.kind, self.kind,
+                                  k, float(self.sigma), float(self.margin))
+        return out[self.kind]
+
+
+class AlignmentLoss(EmbeddingLoss):  # losses.py:249-259
+    pass
+
+
+class ContrastiveLoss(EmbeddingLoss):  # losses.py:262-274
+    pass
+
+
+class AlignmentContrastiveLoss(EmbeddingLoss):  # losses.py:277-291
+    pass
+
+
+class InfomationNoiseContrastiveEstimationLoss(EmbeddingLoss):  # losses.py:294-306 (spelling kept)
+    pass
+
+
+class MutualInformationNeuralEstimationLoss(EmbeddingLoss):  # losses.py:309-321
+    pass
+
+
+class PairwiseEmbeddingLoss(EmbeddingLoss, abc.ABC):  # losses.py:324-349
+    pass
+
+
+class PairwiseLogisticLoss(PairwiseEmbeddingLoss):  # losses.py:352-354 (BPR when margin = 0)
+    pass
+
+
+class PairwiseHingeLoss(PairwiseEmbeddingLoss):  # losses.py:357-359 (default train_loss)
+    pass
+
+
+@torch.no_grad()
+def negative_mask(user_embed, item_embed, target, *, item_idx, pos_idx, num_negatives=0, sigma=1.0,
+                  logq=None) -> torch.Tensor:
+    """Boolean ``[B, N]`` mask of the negatives that enter the loss: ``negative_masks``
+    followed by ``semi_hard_mining`` (losses.py:92-162), computed by the HIP path
+    (``out_mask_bits`` of ``mf_loss_fwd``).  Diagnostic / test helper."""
+    check_inputs(user_embed, item_embed, target)
+    u, v, t, ii, pi, p, lq, d, dp = _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq)
+    b, n = u.shape[0], v.shape[0]
+    nw = (n + 31) // 32
+    lib = _lib.lib()
+    ws = _lib.workspace(lib.mf_loss_ws_bytes(b, n, dp, p, int(num_negatives)), u.device)
+    out = torch.zeros(len(KINDS), dtype=torch.float32, device=u.device)
+    bits = torch.zeros(b, nw, dtype=torch.int32, device=u.device)
+    _lib.check(lib.mf_loss_fwd(b, n, dp, p, int(num_negatives), float(sigma), 1.0, 1 << 1, _lib.ptr(u), _lib.ptr(v),
+                               _lib.ptr(t), _lib.ptr(ii), _lib.ptr(pi), _lib.ptr(lq), _lib.ptr(ws), ws.numel(),
+                               _lib.ptr(out), _lib.ptr(bits), _lib.stream_ptr()))
+    shifts = torch.arange(32, device=u.device, dtype=torch.int32)
+    return ((bits[:, :, None] >> shifts) & 1).bool().reshape(b, nw * 32)[:, :n]

@@ -1,0 +1,114 @@
+"""Sparse row optimisers for :class:`models.EmbeddingTower` tables.
+
+``configure_optimizers`` of the reference returns dense ``torch.optim.AdamW``
+(xfmr_rec/lightning.py:238-239).  With embedding tables only the gathered rows
+receive gradient, so the update is a scatter over the touched rows
+(``mf_update_sgd`` / ``mf_update_adam``): duplicate ids are summed first, every
+touched row is read and written once.  Spec: ``oracle/embed.py`` (no reference
+implementation).  Both classes are ``torch.optim.Optimizer``
+subclasses, so Lightning's automatic optimisation can drive them.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _pending(p: torch.Tensor):
+    items = getattr(p, "_mf_pending", None)
+    if not items:
+        return None
+    if len(items) == 1:
+        ids, g, norm = items[0]
+    else:
+        if len({n for _, _, n in items}) != 1:
+            raise _lib.MfHipError("a table was gathered both with and without normalisation in one step")
+        ids = torch.cat([i for i, _, _ in items])
+        g = torch.cat([x for _, x, _ in items])
+        norm = items[0][2]
+    return ids, g, norm
+
+
+class _SparseRowOptimizer(torch.optim.Optimizer):
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        super().zero_grad(set_to_none=set_to_none)
+        for group in self.param_groups:
+            for p in group["params"]:
+                if getattr(p, "_mf_pending", None):
+                    p._mf_pending.clear()
+
+    @staticmethod
+    def _check(p: torch.Tensor) -> None:
+        if p.grad is not None:
+            raise _lib.MfHipError("dense gradient on an embedding table: gather rows through EmbeddingTower")
+        if p.dim() != 2 or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+            raise _lib.MfHipError("embedding table must be a contiguous 2-D fp32 tensor on the GPU")
+
+
+class SparseSGD(_SparseRowOptimizer):
+    """row -= lr * (sum of the row's gradients + weight_decay * row), touched rows only."""
+
+    def __init__(self, params, lr: float = 1e-2, weight_decay: float = 0.0) -> None:
+        super().__init__(params, {"lr": lr, "weight_decay": weight_decay})
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.lib()
+        for group in self.param_groups:
+            for p in group["params"]:
+                self._check(p)
+                pend = _pending(p)
+                if pend is None:
+                    continue
+                ids, g, norm = pend
+                n, d = ids.numel(), p.shape[1]
+                ws = _lib.workspace(lib.mf_update_ws_bytes(n, d), p.device)
+                _lib.check(lib.mf_update_sgd(p.data_ptr(), p.shape[0], d, ids.data_ptr(), n, g.data_ptr(), int(norm),
+                                             group["lr"], group["weight_decay"], ws.data_ptr(), ws.numel(),
+                                             _lib.stream_ptr()))
+                p._mf_pending.clear()
+        return loss
+
+
+class RowAdam(_SparseRowOptimizer):
+    """Lazy row-wise AdamW: moments of touched rows only, global step for the bias
+    correction, decoupled weight decay (torch.optim.AdamW's defaults otherwise)."""
+
+    def __init__(self, params, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.01) -> None:
+        super().__init__(params, {"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay})
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.lib()
+        for group in self.param_groups:
+            for p in group["params"]:
+                self._check(p)
+                pend = _pending(p)
+                if pend is None:
+                    continue
+                state = self.state[p]
+                if not state:
+                    state["step"] = 0
+                    state["exp_avg"] = torch.zeros_like(p)
+                    state["exp_avg_sq"] = torch.zeros_like(p)
+                state["step"] += 1
+                ids, g, norm = pend
+                n, d = ids.numel(), p.shape[1]
+                ws = _lib.workspace(lib.mf_update_ws_bytes(n, d), p.device)
+                b1, b2 = group["betas"]
+                _lib.check(lib.mf_update_adam(p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                                              p.shape[0], d, ids.data_ptr(), n, g.data_ptr(), int(norm), state["step"],
+                                              group["lr"], b1, b2, group["eps"], group["weight_decay"], ws.data_ptr(),
+                                              ws.numel(), _lib.stream_ptr()))
+                p._mf_pending.clear()
+        return loss

@@ -1,0 +1,130 @@
+"""Exact brute-force retrieval over the item table (replaces the LanceDB ANN index).
+
+Reference: ``ItemProcessor.get_index`` embeds every item and builds an
+``IVF_HNSW_PQ`` cosine index (xfmr_rec/data/lightning.py:182-235);
+``ItemProcessor.search`` runs one query with a ``movie_id NOT IN (...)`` prefilter
+and returns the ``top_k`` rows with ``score = 1 - cosine distance``, best first
+(:237-259).  Here the "index" is the unit-norm item matrix itself, resident in HBM,
+and ``search`` is an exact scan (``mf_topk``): same scores for unit-norm rows, exact
+instead of approximate, batched over queries, ties broken by lowest item row.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .params import ITEM_ID_COL, ITEM_IDX_COL, TOP_K
+
+
+def _csr(exclude: Sequence[Sequence[int]] | None, q: int, device):
+    """Per-query exclusion lists -> (offsets[Q+1], sorted row indices) on the GPU."""
+    if exclude is None:
+        return None, None
+    if len(exclude) != q:
+        msg = f"one exclusion list per query expected: {len(exclude) = }, {q = }"
+        raise ValueError(msg)
+    lens = np.fromiter((len(e) for e in exclude), dtype=np.int64, count=q)
+    off = np.zeros(q + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    flat = np.concatenate([np.sort(np.asarray(e, dtype=np.int64)) for e in exclude]) if off[-1] else np.zeros(1, np.int64)
+    return torch.from_numpy(off).to(device), torch.from_numpy(flat).to(device)
+
+
+class ItemIndex:
+    """Item embeddings ``[N, d]`` (row r = global item row ``idx_base + r``) on one GPU."""
+
+    def __init__(self, embeddings: torch.Tensor, *, idx_base: int = 0) -> None:
+        emb = _lib.dev_f32(embeddings.detach(), "embeddings")
+        self.dim = emb.shape[1]
+        dp = _lib.padded_width(self.dim)
+        if dp != self.dim:
+            emb = torch.nn.functional.pad(emb, (0, dp - self.dim))
+        self.embeddings = emb.contiguous()
+        self.idx_base = int(idx_base)
+
+    @property
+    def num_items(self) -> int:
+        return self.embeddings.shape[0]
+
+    def search(self, queries: torch.Tensor, top_k: int = TOP_K, *, exclude: Sequence[Sequence[int]] | None = None,
+               exclude_csr: tuple[torch.Tensor, torch.Tensor] | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+        """``(scores [Q, k] fp32, rows [Q, k] int64)``, best first; ``exclude`` holds GLOBAL
+        item rows per query (or pass a prebuilt device CSR with sorted ids)."""
+        q = _lib.dev_f32(queries, "queries")
+        if q.dim() != 2 or q.shape[1] != self.dim:
+            msg = f"queries should be (num_queries, {self.dim}): {tuple(q.shape) = }"
+            raise ValueError(msg)
+        if self.embeddings.shape[1] != self.dim:
+            q = torch.nn.functional.pad(q, (0, self.embeddings.shape[1] - self.dim))
+        nq, n, d = q.shape[0], self.num_items, self.embeddings.shape[1]
+        off, ids = exclude_csr if exclude_csr is not None else _csr(exclude, nq, q.device)
+        lib = _lib.lib()
+        ws = _lib.workspace(lib.mf_topk_ws_bytes(nq, n, d, top_k), q.device)
+        scores = torch.empty(nq, top_k, dtype=torch.float32, device=q.device)
+        rows = torch.empty(nq, top_k, dtype=torch.int64, device=q.device)
+        _lib.check(lib.mf_topk(q.data_ptr(), nq, self.embeddings.data_ptr(), n, d, top_k, _lib.ptr(off), _lib.ptr(ids),
+                               self.idx_base, ws.data_ptr(), ws.numel(), scores.data_ptr(), rows.data_ptr(),
+                               _lib.stream_ptr()))
+        return scores, rows
+
+
+def merge_topk(part_scores: torch.Tensor, part_rows: torch.Tensor, top_k: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """Merge per-shard results ``[G, Q, k]`` (global rows) into the global top-k (``mf_topk_merge``)."""
+    ps = _lib.dev_f32(part_scores, "part_scores")
+    pr = _lib.dev_i64(part_rows, "part_rows")
+    g, nq, k = ps.shape
+    if k != top_k:
+        msg = f"partial results must hold top_k entries: {k = }, {top_k = }"
+        raise ValueError(msg)
+    scores = torch.empty(nq, k, dtype=torch.float32, device=ps.device)
+    rows = torch.empty(nq, k, dtype=torch.int64, device=ps.device)
+    _lib.check(_lib.lib().mf_topk_merge(ps.data_ptr(), pr.data_ptr(), g, nq, k, scores.data_ptr(), rows.data_ptr(),
+                                        _lib.stream_ptr()))
+    return scores, rows
+
+
+class ItemProcessor:
+    """The retrieval half of ``xfmr_rec.data.lightning.ItemProcessor`` (:154-259): ``get_index``
+    embeds the catalog with the item tower, ``search`` answers one query like the reference
+    (numpy ``[1, d]`` in, ``pandas.DataFrame`` out with ``movie_rn``, ``movie_id``, ``score``)."""
+
+    idx_col: str = ITEM_IDX_COL
+    id_col: str = ITEM_ID_COL
+
+    def __init__(self, item_ids: Sequence[int] | torch.Tensor | None = None) -> None:
+        self.item_ids = None if item_ids is None else torch.as_tensor(item_ids, dtype=torch.int64).cpu()
+        self.index: ItemIndex | None = None
+        self._row_of_id: dict[int, int] | None = None
+
+    @torch.inference_mode()
+    def get_index(self, model: torch.nn.Module, subset: str = "predict") -> ItemIndex:  # noqa: ARG002
+        tower = model.towers["item"] if hasattr(model, "towers") else model
+        rows = torch.arange(tower.num_embeddings, device=tower.weight.device)
+        self.index = ItemIndex(tower(rows))
+        if self.item_ids is None:
+            self.item_ids = torch.arange(tower.num_embeddings)
+        self._row_of_id = {int(i): r for r, i in enumerate(self.item_ids.tolist())}
+        return self.index
+
+    def search(self, embedding, exclude_item_ids: list[int] | None = None, top_k: int = TOP_K):
+        import pandas as pd
+
+        if self.index is None:
+            msg = "`index` must be intialised first"  # message kept from data/lightning.py:244
+            raise ValueError(msg)
+        q = torch.as_tensor(np.asarray(embedding), dtype=torch.float32).reshape(1, -1).to(self.index.embeddings.device)
+        rows = [self._row_of_id[i] for i in (exclude_item_ids or []) if i in self._row_of_id]
+        scores, idx = self.index.search(q, top_k, exclude=[rows])
+        idx = idx[0].cpu()
+        keep = idx >= 0
+        idx = idx[keep]
+        return pd.DataFrame(
+            {
+                self.idx_col: idx.numpy(),
+                self.id_col: self.item_ids[idx].numpy(),
+                "score": scores[0].cpu()[keep].numpy(),
+            }
+        )

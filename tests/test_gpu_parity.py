@@ -1,0 +1,274 @@
+"""GPU parity tests: the HIP path (through the Python surface -> ctypes -> C ABI of
+libmf_hip.so) against the CPU oracle on identical seeded inputs and against the golden
+vectors derived from the reference.  Bars: scores / masks / top-k bit-exact; loss and
+gradients within 1e-4 (fp32, sigma = 1; scaled by sigma otherwise)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import chain, embed as oembed, losses as ol, retrieval as oretr
+from tests.conftest import golden_files
+
+pytestmark = pytest.mark.gpu
+SIGMA_MARGIN = ((1.0, 1.0), (2.0, 0.5), (1.0, 0.0))
+DEV = "cuda:0"
+
+
+def _unit(n, d, gen):
+    return torch.nn.functional.normalize(torch.randn(n, d, generator=gen), dim=-1)
+
+
+# ----------------------------------------------------------------- score engine ---
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+def test_mfma_scores_equal_fmaf_chain_bitwise(mf, d):
+    g = torch.Generator().manual_seed(d)
+    u, v = torch.randn(70, d, generator=g), torch.randn(133, d, generator=g)
+    out = torch.empty(70, 133, device=DEV)
+    ud, vd = u.to(DEV), v.to(DEV)
+    mf._lib.check(mf._lib.lib().mf_scores(ud.data_ptr(), 70, vd.data_ptr(), 133, d, out.data_ptr(), None))
+    want = chain.scores(u.numpy(), v.numpy())
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_sqnorm_bitwise(mf):
+    x = torch.randn(300, 128)
+    out = torch.empty(300, device=DEV)
+    xd = x.to(DEV)
+    mf._lib.check(mf._lib.lib().mf_row_sqnorm(xd.data_ptr(), 300, 128, out.data_ptr(), None))
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), chain.sqnorm(x.numpy()).view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 5, 2048, 5000])
+def test_sort_keys_is_stable_sort(mf, n):
+    g = torch.Generator().manual_seed(n)
+    keys = torch.randint(0, max(2, n // 3), (n,), generator=g)
+    kd = keys.to(DEV)
+    lib = mf._lib.lib()
+    perm = torch.empty(n, dtype=torch.int32, device=DEV)
+    sk = torch.empty(n, dtype=torch.int64, device=DEV)
+    ws = mf._lib.workspace(lib.mf_sort_ws_bytes(n), DEV)
+    mf._lib.check(lib.mf_sort_keys(kd.data_ptr(), n, perm.data_ptr(), sk.data_ptr(), ws.data_ptr(), ws.numel(), None))
+    want = torch.argsort(keys, stable=True)
+    assert torch.equal(perm.cpu().long(), want)
+    assert torch.equal(sk.cpu(), keys[want])
+
+
+# ------------------------------------------------------------------------ losses ---
+def _run_gpu(mf, kind, t, k, sigma, margin, logq=None):
+    u = t["u"].to(DEV).requires_grad_()
+    v = t["v"].to(DEV).requires_grad_()
+    fn = getattr(mf.losses, kind)(num_negatives=k, sigma=sigma, margin=margin)
+    val = fn(u, v, t["target"].to(DEV), item_idx=t["item_idx"].to(DEV), pos_idx=t["pos_idx"].to(DEV),
+             logq=None if logq is None else logq.to(DEV))
+    val.backward()
+    return float(val.detach().cpu()), u.grad.cpu().numpy(), v.grad.cpu().numpy()
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.stem)
+def test_losses_match_reference_golden(mf, path):
+    """Values produced by the reference's own xfmr_rec/losses.py (tests/golden)."""
+    z = np.load(path)
+    t = {k: torch.from_numpy(z[k]) for k in ("u", "v", "target", "item_idx", "pos_idx")}
+    n = t["v"].shape[0]
+    gs = int(z["gstride"])
+    for ki, kind in enumerate(ol.KINDS):
+        for k in (0, 4, n):
+            for smi, (sigma, margin) in enumerate(SIGMA_MARGIN):
+                tag = f"{ki}_{k}_{smi}"
+                want = float(z[f"loss_{tag}"])
+                got, du, dv = _run_gpu(mf, kind, t, k, sigma, margin)
+                if not np.isfinite(want):
+                    assert got == want, (path.stem, tag, got, want)   # MINE, no valid negative: -inf
+                    continue
+                assert abs(got - want) <= 1e-4 * sigma * max(1.0, abs(want)), (path.stem, tag, got, want)
+                np.testing.assert_allclose(du[::gs], z[f"du_{tag}"], rtol=2e-4, atol=2e-5 * sigma, err_msg=tag)
+                np.testing.assert_allclose(dv[::gs], z[f"dv_{tag}"], rtol=2e-4, atol=2e-5 * sigma, err_msg=tag)
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.stem)
+def test_masks_bit_exact_vs_oracle(mf, path):
+    z = np.load(path)
+    t = {k: torch.from_numpy(z[k]) for k in ("u", "v", "target", "item_idx", "pos_idx")}
+    b, n = t["u"].shape[0], t["v"].shape[0]
+    for sigma in (1.0, 2.0):
+        lg = torch.from_numpy(chain.logits(t["u"].numpy(), t["v"].numpy(), t["target"].numpy(), sigma))
+        base = ol.negative_masks(t["item_idx"], t["pos_idx"], b)
+        for k in (0, 4, n):
+            want = ol.semi_hard_mining(lg, base.clone(), k)
+            got = mf.losses.negative_mask(t["u"].to(DEV), t["v"].to(DEV), t["target"].to(DEV),
+                                          item_idx=t["item_idx"].to(DEV), pos_idx=t["pos_idx"].to(DEV),
+                                          num_negatives=k, sigma=sigma).cpu()
+            assert torch.equal(got, want), (path.stem, sigma, k, (got != want).sum().item())
+
+
+def _random_case(b, n, d, p, seed, n_items=None):
+    g = torch.Generator().manual_seed(seed)
+    n_items = n_items or max(n // 2, 4)
+    t = {
+        "u": _unit(b, d, g), "v": _unit(n, d, g),
+        "target": torch.randint(-2, 6, (b,), generator=g),
+        "item_idx": torch.randint(1, n_items + 1, (n,), generator=g),
+        "pos_idx": torch.randint(0, n_items + 1, (b, p), generator=g),
+    }
+    t["pos_idx"][:, 0] = t["item_idx"][:b]
+    return t
+
+
+@pytest.mark.parametrize("shape", [(200, 400, 64, 20), (33, 95, 32, 5), (64, 64, 128, 1), (100, 260, 256, 40)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("k", [0, 4, 24, 40])
+def test_losses_match_oracle_ragged_shapes(mf, shape, k):
+    """Tile-ragged shapes, every loss class, dense and mined, with and without logQ."""
+    b, n, d, p = shape
+    t = _random_case(b, n, d, p, seed=sum(shape) + k)
+    g = torch.Generator().manual_seed(7)
+    for logq in (None, torch.log(torch.rand(n, generator=g) * 0.9 + 0.05)):
+        for sigma, margin in ((1.0, 1.0), (3.0, 0.25)):
+            lg = chain.logits(t["u"].numpy(), t["v"].numpy(), t["target"].numpy(), sigma,
+                              None if logq is None else logq.numpy())
+            for kind in ol.KINDS:
+                u = t["u"].clone().requires_grad_()
+                v = t["v"].clone().requires_grad_()
+                want = ol.loss(kind, u, v, t["target"], item_idx=t["item_idx"], pos_idx=t["pos_idx"], num_negatives=k,
+                               sigma=sigma, margin=margin, logq=logq, mining_logits=lg)
+                want.backward()
+                got, du, dv = _run_gpu(mf, kind, t, k, sigma, margin, logq)
+                w = float(want.detach())
+                if not np.isfinite(w):
+                    assert got == w or (np.isnan(got) and np.isnan(w)), (kind, got, w)
+                    continue
+                assert abs(got - w) <= 1e-4 * sigma * max(1.0, abs(w)), (kind, k, sigma, got, w)
+                np.testing.assert_allclose(du, u.grad.numpy(), rtol=2e-4, atol=2e-5 * sigma, err_msg=kind)
+                np.testing.assert_allclose(dv, v.grad.numpy(), rtol=2e-4, atol=2e-5 * sigma, err_msg=kind)
+
+
+def test_fused_losses_equal_individual(mf):
+    t = _random_case(96, 192, 64, 8, seed=5)
+    dev = {k: x.to(DEV) for k, x in t.items()}
+    fused = mf.losses.fused_losses(dev["u"], dev["v"], dev["target"], item_idx=dev["item_idx"], pos_idx=dev["pos_idx"],
+                                   num_negatives=4, sigma=1.0, margin=1.0)
+    for kind in ol.KINDS:
+        single = getattr(mf.losses, kind)(num_negatives=4)(dev["u"], dev["v"], dev["target"], item_idx=dev["item_idx"],
+                                                            pos_idx=dev["pos_idx"])
+        assert float(fused[kind]) == float(single), kind
+
+
+def test_check_inputs_errors(mf):
+    fn = mf.losses.PairwiseHingeLoss()
+    u, v = torch.randn(4, 32, device=DEV), torch.randn(8, 32, device=DEV)
+    idx = torch.arange(8, device=DEV)
+    with pytest.raises(ValueError, match="2 dimensions"):
+        fn(u[0], v, torch.ones(4, device=DEV), item_idx=idx, pos_idx=None)
+    with pytest.raises(ValueError, match="dimension 1"):
+        fn(u, v[:, :16], torch.ones(4, device=DEV), item_idx=idx, pos_idx=None)
+    with pytest.raises(ValueError, match="dimension 0"):
+        fn(u, v, torch.ones(5, device=DEV), item_idx=idx, pos_idx=None)
+    with pytest.raises(ValueError, match="dimension 0"):
+        fn(v, u, torch.ones(8, device=DEV), item_idx=idx[:4], pos_idx=None)
+
+
+# ------------------------------------------------------------ towers and updates ---
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_gather_rows(mf, d, normalize):
+    g = torch.Generator().manual_seed(d)
+    table = torch.randn(500, d, generator=g)
+    idx = torch.randint(0, 500, (3, 77), generator=g)
+    tower = mf.models.EmbeddingTower(500, d, normalize=normalize, device=DEV)
+    with torch.no_grad():
+        tower.weight.copy_(table.to(DEV))
+    got = tower(idx.to(DEV)).detach().cpu()
+    want = oembed.gather(table, idx, normalize)
+    if normalize:
+        torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    else:
+        assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("d", [32, 128])
+@pytest.mark.parametrize("normalize", [False, True])
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_sparse_update_matches_oracle(mf, d, normalize, opt):
+    g = torch.Generator().manual_seed(d + normalize)
+    rows, n = 300, 700
+    table0 = torch.randn(rows, d, generator=g)
+    idx = torch.randint(0, 40, (n,), generator=g)          # heavy duplicates
+    idx[:50] = torch.randint(0, rows, (50,), generator=g)
+    tower = mf.models.EmbeddingTower(rows, d, normalize=normalize, device=DEV)
+    with torch.no_grad():
+        tower.weight.copy_(table0.to(DEV))
+    optim = (mf.optim.SparseSGD(tower.parameters(), lr=0.1, weight_decay=0.01) if opt == "sgd"
+             else mf.optim.RowAdam(tower.parameters(), lr=0.05, weight_decay=0.01))
+    ref = table0.clone()
+    m, v = torch.zeros_like(ref), torch.zeros_like(ref)
+    for step in (1, 2, 3):
+        gout = torch.randn(n, d, generator=g)
+        out = tower(idx.to(DEV))
+        out.backward(gout.to(DEV))
+        optim.step()
+        optim.zero_grad()
+        graw = oembed.normalize_backward(ref[idx], gout) if normalize else gout
+        if opt == "sgd":
+            oembed.sgd_update(ref, idx, graw, 0.1, 0.01)
+        else:
+            oembed.adam_update(ref, m, v, idx, graw, step=step, lr=0.05, weight_decay=0.01)
+        torch.testing.assert_close(tower.weight.detach().cpu(), ref, rtol=2e-5, atol=2e-6)
+
+
+# --------------------------------------------------------------------- retrieval ---
+@pytest.mark.parametrize("cfg", [(50, 5000, 64, 20), (1, 3883, 64, 20), (33, 1000, 128, 5), (7, 300, 32, 64), (40, 2500, 256, 33)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_topk_bit_exact(mf, cfg):
+    nq, n, d, k = cfg
+    g = torch.Generator().manual_seed(n)
+    q, items = _unit(nq, d, g), _unit(n, d, g)
+    items[10] = items[3]                                   # exact score ties -> lowest row first
+    excl = [sorted(set(torch.randint(0, n, (int(torch.randint(0, 60, (1,), generator=g)),), generator=g).tolist()))
+            for _ in range(nq)]
+    index = mf.retrieval.ItemIndex(items.to(DEV))
+    s, i = index.search(q.to(DEV), k, exclude=excl)
+    ws, wi = chain.topk(q.numpy(), items.numpy(), k, excl)
+    assert np.array_equal(i.cpu().numpy(), wi)
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+
+
+def test_topk_degenerate_inputs(mf):
+    """All scores equal (zero queries): lowest rows win; fewer than k candidates: -1 padding."""
+    items = torch.randn(400, 32)
+    index = mf.retrieval.ItemIndex(items.to(DEV))
+    s, i = index.search(torch.zeros(3, 32, device=DEV), 20)
+    assert torch.equal(i.cpu(), torch.arange(20).repeat(3, 1))
+    small = mf.retrieval.ItemIndex(items[:6].to(DEV))
+    s, i = small.search(torch.randn(2, 32).to(DEV), 8, exclude=[[0, 1], []])
+    assert (i[0, 4:] == -1).all() and (i[1, 6:] == -1).all() and torch.isinf(s[0, 4:]).all()
+
+
+def test_sharded_topk_merge_equals_full(mf):
+    g = torch.Generator().manual_seed(11)
+    q, items = _unit(64, 64, g), _unit(4001, 64, g)
+    full_s, full_i = mf.retrieval.ItemIndex(items.to(DEV)).search(q.to(DEV), 20)
+    bounds = np.linspace(0, 4001, 9).astype(int)
+    ps, pi = [], []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        s, i = mf.retrieval.ItemIndex(items[lo:hi].to(DEV), idx_base=int(lo)).search(q.to(DEV), 20)
+        ps.append(s)
+        pi.append(i)
+    ms, mi = mf.retrieval.merge_topk(torch.stack(ps), torch.stack(pi), 20)
+    assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
+    os_, oi = oretr.merge_topk(torch.stack(ps).cpu().numpy(), torch.stack(pi).cpu().numpy(), 20)
+    assert np.array_equal(oi, mi.cpu().numpy())
+
+
+def test_item_processor_search_surface(mf):
+    cfg = mf.models.ModelConfig(num_users=50, num_items=200, hidden_size=32)
+    towers = mf.models.init_towers(cfg, device=DEV)
+    proc = mf.retrieval.ItemProcessor(item_ids=list(range(1000, 1200)))
+    proc.get_index(towers["item"])
+    emb = towers["user"](torch.tensor([3], device=DEV)).detach().cpu().numpy()
+    df = proc.search(emb, exclude_item_ids=[1000, 1001], top_k=10)
+    assert list(df.columns) == ["movie_rn", "movie_id", "score"] and len(df) == 10
+    assert df["score"].is_monotonic_decreasing and not set(df["movie_id"]) & {1000, 1001}
+    with pytest.raises(ValueError, match="must be intialised first"):
+        mf.retrieval.ItemProcessor().search(emb)
