@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X: train pairs/s + full-catalog top-k queries/s.
+
+Workload (BASELINE.json configs[2], "C3"): MovieLens-25M *shape* -- 162,541 users x
+62,423 items, d = 128, InfoNCE + logQ correction, synthetic ids (Zipf item popularity,
+log-normal user activity, seed 0; no MovieLens files exist offline), random-init
+unit-norm tables.
+
+One training "step" = one batch of B (user, positive item, sampled negative item)
+triples through: tower gathers -> fused score/loss forward -> backward -> sparse
+row update of both tables.  One retrieval "step" = Q queries against the whole
+catalog with per-query exclusion lists, k = 20.  Inputs are resident in HBM when the
+timed region starts.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `value` is train pairs/s over all ranks; the top-k
+leg is reported beside it (`topk`), each with the roofline of its dominant kernel,
+and the CPU baseline (the oracle's restatement of the same step, torch CPU, all host
+cores, bounded sample) on rank 0 at N = 1.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import pathlib
+import sys
+import time
+
+import torch
+
+ROOT = pathlib.Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+NUM_USERS, NUM_ITEMS, DIM = 162_541, 62_423, 128       # ML-25M shape
+PEAK_F32_MFMA_TFLOPS = 157.3                            # MI355X_MICROARCH.md, fp32 matrix
+PEAK_HBM_GBS = 8000.0
+TOP_K, POS_PAD = 20, 64
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8192, help="pairs per GPU per step")
+    ap.add_argument("--queries", type=int, default=1024, help="queries per GPU per retrieval step")
+    ap.add_argument("--optimizer", choices=("adam", "sgd"), default="adam")
+    ap.add_argument("--num-negatives", type=int, default=0, help="0 = all in-batch negatives (sampled softmax)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def zipf_weights(n: int, s: float = 1.0) -> torch.Tensor:
+    return 1.0 / torch.arange(1, n + 1, dtype=torch.float64) ** s
+
+
+def make_batches(n_batches: int, batch: int, seed: int, device):
+    """MovieLens-shaped id batches: Zipf(1) item popularity, log-normal user activity."""
+    g = torch.Generator().manual_seed(seed)
+    item_w = zipf_weights(NUM_ITEMS - 1)
+    user_w = torch.exp(torch.randn(NUM_USERS - 1, generator=g, dtype=torch.float64))
+    out = []
+    for _ in range(n_batches):
+        user = torch.multinomial(user_w, batch, replacement=True, generator=g) + 1
+        item = torch.multinomial(item_w, batch, replacement=True, generator=g) + 1
+        neg = torch.randint(1, NUM_ITEMS, (batch,), generator=g)
+        target = torch.randint(1, 6, (batch,), generator=g)
+        n_pos = torch.randint(8, POS_PAD + 1, (batch,), generator=g)
+        pos = torch.multinomial(item_w, batch * POS_PAD, replacement=True, generator=g).reshape(batch, POS_PAD) + 1
+        pos[:, 0] = item
+        pos[torch.arange(POS_PAD)[None, :] >= n_pos[:, None]] = 0
+        out.append({k: v.to(device) for k, v in
+                    dict(user=user, item=torch.cat([item, neg]), target=target, pos=pos).items()})
+    counts = torch.bincount(torch.cat([b["item"].cpu() for b in out]), minlength=NUM_ITEMS)
+    return out, counts
+
+
+def logq_table(device) -> torch.Tensor:
+    """log of the sampling probability of each item row: positives ~ Zipf, negatives ~ uniform."""
+    w = zipf_weights(NUM_ITEMS - 1)
+    p = 0.5 * w / w.sum() + 0.5 / (NUM_ITEMS - 1)
+    return torch.cat([torch.zeros(1, dtype=torch.float64), p.log()]).to(torch.float32).to(device)
+
+
+class Trainer:
+    """The reference's training_step shape (xfmr_rec/lightning.py:97-147,189-192) on the HIP path."""
+
+    def __init__(self, mf, device, optimizer: str, num_negatives: int):
+        cfg = mf.models.ModelConfig(num_users=NUM_USERS, num_items=NUM_ITEMS, hidden_size=DIM)
+        torch.manual_seed(0)
+        self.towers = mf.models.init_towers(cfg, device=device)
+        self.loss_fn = mf.losses.InfomationNoiseContrastiveEstimationLoss(num_negatives=num_negatives, sigma=1.0)
+        params = list(self.towers.parameters())
+        self.opt = mf.optim.RowAdam(params, lr=1e-4) if optimizer == "adam" else mf.optim.SparseSGD(params, lr=1e-2)
+        self.logq = logq_table(device)
+
+    def item_matrix(self) -> torch.Tensor:
+        return self.towers["item"](torch.arange(NUM_ITEMS, device=self.logq.device)).detach()
+
+    def user_vectors(self, rows: torch.Tensor) -> torch.Tensor:
+        return self.towers["user"](rows).detach()
+
+    def step(self, b) -> torch.Tensor:
+        u = self.towers["user"](b["user"])
+        v = self.towers["item"](b["item"])
+        loss = self.loss_fn(u, v, b["target"], item_idx=b["item"], pos_idx=b["pos"], logq=self.logq[b["item"]])
+        loss.backward()
+        self.opt.step()
+        return loss
+
+
+def timed(fn, n_steps: int, dist_on: bool) -> float:
+    if dist_on:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        fn(i)
+    torch.cuda.synchronize()
+    if dist_on:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    return dt
+
+
+def kernel_span(lib, name: str):
+    tot = ctypes.c_double(0.0)
+    n = lib.mf_timing_get(name.encode(), ctypes.byref(tot))
+    return (tot.value / n if n else None), n
+
+
+def cpu_train_baseline(batches, logq, optimizer: str, n_steps: int, num_negatives: int):
+    """The oracle's restatement of the same step (torch CPU, all host cores)."""
+    from oracle import embed as oembed, losses as ol
+
+    torch.manual_seed(0)
+    ut = torch.randn(NUM_USERS, DIM) / DIM**0.5
+    it = torch.randn(NUM_ITEMS, DIM) / DIM**0.5
+    state = [torch.zeros_like(ut), torch.zeros_like(ut), torch.zeros_like(it), torch.zeros_like(it)]
+    t0 = time.perf_counter()
+    for s in range(n_steps):
+        b = batches[s % len(batches)]
+        ur = ut[b["user"]].requires_grad_()
+        ir = it[b["item"]].requires_grad_()
+        un = ur / ur.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        vn = ir / ir.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        loss = ol.loss("InfomationNoiseContrastiveEstimationLoss", un, vn, b["target"], item_idx=b["item"],
+                       pos_idx=b["pos"], num_negatives=num_negatives, logq=logq[b["item"]])
+        loss.backward()
+        if optimizer == "adam":
+            oembed.adam_update(ut, state[0], state[1], b["user"], ur.grad, step=s + 1, lr=1e-4, weight_decay=0.01)
+            oembed.adam_update(it, state[2], state[3], b["item"], ir.grad, step=s + 1, lr=1e-4, weight_decay=0.01)
+        else:
+            oembed.sgd_update(ut, b["user"], ur.grad, 1e-2)
+            oembed.sgd_update(it, b["item"], ir.grad, 1e-2)
+    return time.perf_counter() - t0
+
+
+def main() -> None:
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
+    mf = importlib.import_module("matrix-factorization-torch_amd")
+    lib = mf._lib.lib()
+    B, Q, K, W = args.batch, args.queries, args.steps, args.warmup
+
+    # ------------------------------------------------------------------ training leg --
+    n_batches = min(K + W, 8)
+    batches, _ = make_batches(n_batches, B, seed=1000 + rank, device=device)
+    if dist_on:
+        trainer = mf.distributed.ShardedTrainer(mf, device, args.optimizer, args.num_negatives,
+                                                num_users=NUM_USERS, num_items=NUM_ITEMS, dim=DIM, logq=logq_table(device))
+    else:
+        trainer = Trainer(mf, device, args.optimizer, args.num_negatives)
+    for i in range(W):
+        trainer.step(batches[i % n_batches])
+    lib.mf_timing_reset()
+    lib.mf_timing_enable(1)
+    dt_train = timed(lambda i: trainer.step(batches[(W + i) % n_batches]), K, dist_on)
+    lib.mf_timing_enable(0)
+    pairs_per_s = world * B * K / dt_train
+    N = 2 * B
+    spans = {n: kernel_span(lib, n)[0] for n in ("loss_fwd_dense", "loss_bwd_du", "loss_bwd_dv", "mining_select",
+                                                 "gather_rows", "update_rows")}
+    dense = {n: spans[n] for n in ("loss_fwd_dense", "loss_bwd_du", "loss_bwd_dv") if spans[n]}
+    train_roof = None
+    if dense:
+        dom = max(dense, key=dense.get)
+        flops = 2.0 * B * N * DIM                      # one B x N x d contraction per launch
+        ach = flops / (dense[dom] * 1e-3) / 1e12
+        train_roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                      "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                      "avg_ms": round(dense[dom], 4),
+                      "all_kernels_avg_ms": {k: round(v, 4) for k, v in spans.items() if v}}
+
+    # ----------------------------------------------------------------- retrieval leg --
+    with torch.no_grad():
+        items = trainer.item_matrix()
+        qrows = torch.arange(1 + rank * Q, 1 + (rank + 1) * Q, device=device) % NUM_USERS
+        queries = trainer.user_vectors(qrows)
+    g = torch.Generator().manual_seed(7 + rank)
+    item_w = zipf_weights(NUM_ITEMS - 1)
+    pieces, offs = [], [0]                         # per-query history (sorted unique item rows)
+    for n in torch.randint(20, 300, (Q,), generator=g).tolist():
+        pieces.append(torch.unique(torch.multinomial(item_w, n, replacement=True, generator=g) + 1))
+        offs.append(offs[-1] + pieces[-1].numel())
+    csr = (torch.tensor(offs, dtype=torch.int64, device=device), torch.cat(pieces).to(device))
+    if dist_on:
+        searcher = mf.distributed.ShardedIndex(trainer.item_shard(), trainer.item_shard_base(), NUM_ITEMS)
+        run_topk = lambda i: searcher.search(queries, TOP_K, exclude_csr=csr)   # noqa: E731
+    else:
+        index = mf.retrieval.ItemIndex(items)
+        run_topk = lambda i: index.search(queries, TOP_K, exclude_csr=csr)      # noqa: E731
+    for i in range(W):
+        run_topk(i)
+    lib.mf_timing_reset()
+    lib.mf_timing_enable(1)
+    dt_topk = timed(run_topk, K, dist_on)
+    lib.mf_timing_enable(0)
+    qps = world * Q * K / dt_topk
+    span, _n = kernel_span(lib, "topk_select")
+    topk_roof = None
+    if span:
+        # per launch every rank scores (world * Q) queries against its N / world rows
+        n_local = items.shape[0] if not dist_on else trainer.item_shard().shape[0]
+        flops = 2.0 * (world * Q) * n_local * DIM
+        ach = flops / (span * 1e-3) / 1e12
+        topk_roof = {"kernel": "select_kernel<RetrievalPolicy>", "bound": "mfma", "achieved": round(ach, 2),
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                     "traffic": None, "avg_ms": round(span, 4)}
+
+    # --------------------------------------------------------------------- CPU leg ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import retrieval as oretr
+
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        cb = [{k: v.cpu() for k, v in b.items()} for b in batches[: args.cpu_steps]]
+        dt_cpu = cpu_train_baseline(cb, logq_table("cpu"), args.optimizer, args.cpu_steps, args.num_negatives)
+        qc, ic = queries.cpu(), items.cpu()
+        excl = [p.tolist() for p in pieces]
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            oretr.topk_fast(qc, ic, TOP_K, excl)
+        dt_cpu_topk = (time.perf_counter() - t0) / reps
+        cpu = {"value": round(B * args.cpu_steps / dt_cpu, 1), "unit": "pairs/s", "cores": torch.get_num_threads(),
+               "kind": "port",
+               "sample": f"{args.cpu_steps} steps of the same workload (B={B}, N={N}, d={DIM}, InfoNCE+logQ, "
+                         f"{args.optimizer}) by oracle/ on torch CPU; top-k: {reps} batches of Q={Q}",
+               "topk_value": round(Q / dt_cpu_topk, 1), "topk_unit": "queries/s"}
+
+    if rank == 0:
+        line = {
+            "metric": "train pairs/sec + full-catalog top-k queries/sec, ML-25M d=128",
+            "value": round(pairs_per_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt_train / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: MovieLens-25M shape (162,541 users x 62,423 items), d=128, InfoNCE + logQ, "
+                                   f"num_negatives={args.num_negatives}, row-{args.optimizer} update",
+                       "batch_per_gpu": B, "items_per_step": N, "pos_pad": POS_PAD,
+                       "parallelism": f"dp{world}" + (" + item rows sharded" if dist_on else "")},
+            "roofline": train_roof,
+            "topk": {"value": round(qps, 1), "unit": "queries/s", "ms_per_step": round(dt_topk / K * 1e3, 4),
+                     "queries_per_gpu": Q, "k": TOP_K, "catalog_rows": NUM_ITEMS, "roofline": topk_roof},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

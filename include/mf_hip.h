@@ -55,6 +55,14 @@ enum mf_loss_kind {
 const char* mf_last_error(void);
 int mf_version(void);
 
+/* Optional HIP-event timing of the dominant kernels ("loss_fwd_dense",
+ * "loss_bwd_du", "loss_bwd_dv", "mining_select", "topk_select", "gather_rows",
+ * "update_rows"), recorded on the launch stream.  mf_timing_get blocks until the
+ * recorded spans finished and returns their count (total_ms = summed duration). */
+void mf_timing_enable(int on);
+void mf_timing_reset(void);
+int64_t mf_timing_get(const char* name, double* total_ms);
+
 /* ------------------------------------------------------------------ towers ---
  * Replaces the tower forward `MatrixFactorizationLitModule.forward`
  * (xfmr_rec/lightning.py:60-74: text -> BERT -> mean-pool -> L2-normalise) by an

@@ -20,6 +20,9 @@ c_i64, c_int, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, 
 SIGNATURES = {
     "mf_last_error": (ctypes.c_char_p, []),
     "mf_version": (c_int, []),
+    "mf_timing_enable": (None, [c_int]),
+    "mf_timing_reset": (None, []),
+    "mf_timing_get": (c_i64, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]),
     "mf_gather_rows": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "mf_row_sqnorm": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "mf_scores": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp]),

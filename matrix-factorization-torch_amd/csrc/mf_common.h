@@ -24,6 +24,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---- host-side error plumbing (definitions in mf_api.hip) -------------------
 int mf_set_error(int code, const char* fmt, ...);
 int mf_check_launch(const char* what);
+// optional HIP-event spans around the dominant kernels (mf_api.hip)
+bool mf_timing_on();
+void mf_timing_begin(const char* name, hipStream_t s);
+void mf_timing_end(const char* name, hipStream_t s);
+#define MF_TIMED(name, stream, ...)                        \
+    do {                                                   \
+        const bool mf_t_ = mf_timing_on();                 \
+        if (mf_t_) mf_timing_begin(name, stream);          \
+        __VA_ARGS__;                                       \
+        if (mf_t_) mf_timing_end(name, stream);            \
+    } while (0)
 static inline bool mf_width_ok(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
 static inline size_t mf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int64_t mf_pad32(int64_t x) { return (x + 31) / 32 * 32; }

@@ -49,7 +49,7 @@ extern "C" int mf_gather_rows(const float* table, int64_t n_rows, int d, const i
     MF_DISPATCH_D(d, {
         constexpr int RPB = (64 / (D / 4)) * 4;  // rows per 256-thread block
         dim3 grid((unsigned)((n + RPB - 1) / RPB));
-        gather_rows_kernel<D><<<grid, 256, 0, s>>>(table, n_rows, idx, n, normalize, out, out_inv_norm);
+        MF_TIMED("gather_rows", s, gather_rows_kernel<D><<<grid, 256, 0, s>>>(table, n_rows, idx, n, normalize, out, out_inv_norm));
     });
     return mf_check_launch("mf_gather_rows");
 }
@@ -261,7 +261,7 @@ static int update_common(float* table, float* m, float* v, int64_t n_rows, int d
     MF_DISPATCH_D(d, {
         constexpr int RPB = (64 / (D / 4)) * 4;
         dim3 grid((unsigned)((n + RPB - 1) / RPB));
-        update_rows_kernel<D, ADAM><<<grid, 256, 0, s>>>(table, m, v, n_rows, w.perm, w.skeys, n, grad, normalized, hp);
+        MF_TIMED("update_rows", s, (update_rows_kernel<D, ADAM><<<grid, 256, 0, s>>>(table, m, v, n_rows, w.perm, w.skeys, n, grad, normalized, hp)));
     });
     return mf_check_launch(what);
 }

@@ -758,7 +758,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
         FwdParams fp{u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.part, B, N, w.Bp, w.NT, w.tps_f, need, sigma, margin};
         MF_DISPATCH_D(d, {
             dim3 grid((unsigned)w.BT, (unsigned)w.nsplit_f);
-            loss_fwd_dense_kernel<D><<<grid, 64, 0, s>>>(fp);
+            MF_TIMED("loss_fwd_dense", s, loss_fwd_dense_kernel<D><<<grid, 64, 0, s>>>(fp));
         });
         stats_merge_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(w.part, w.nsplit_f, w.Bp, w.stats);
         if (out_mask_bits)
@@ -766,7 +766,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     } else if (scores_needed) {
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
         SelectCommon sc{u, B, v, N, w.NT, w.tpc, w.Bp, num_negatives, w.cand, w.cand_cnt};
-        MF_DISPATCH_D(d, { launch_mining_select<D>(w, mp, sc, s); });
+        MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, launch_mining_select<D>(w, mp, sc, s)); });
         mined_merge_kernel<<<dim3((unsigned)B), 64, (size_t)w.nchunk * w.CAP * 8, s>>>(w.cand, w.cand_cnt, w.nchunk, w.Bp, w.CAP,
                                                                                       num_negatives, w.sel, w.sel_cnt);
         mined_stats_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.sel,
@@ -813,10 +813,10 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
         BwdParams bp{u, v, w.nu, w.nv, w.sgn, logq ? w.logq : nullptr, w.rowc, w.maskW, w.maskTW, w.dpart, B, N, w.Bp, w.Np, 0, 0, gmode, sigma};
         MF_DISPATCH_D(d, {
             bp.YT = w.NT; bp.tps = w.tps_u;
-            loss_bwd_dense_kernel<D, true><<<dim3((unsigned)w.BT, (unsigned)w.nsplit_u), 64, 0, s>>>(bp);
+            MF_TIMED("loss_bwd_du", s, (loss_bwd_dense_kernel<D, true><<<dim3((unsigned)w.BT, (unsigned)w.nsplit_u), 64, 0, s>>>(bp)));
             sum_parts_kernel<<<dim3((unsigned)((B * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_u, B, w.Bp, D, du);
             bp.YT = w.BT; bp.tps = w.tps_v;
-            loss_bwd_dense_kernel<D, false><<<dim3((unsigned)w.NT, (unsigned)w.nsplit_v), 64, 0, s>>>(bp);
+            MF_TIMED("loss_bwd_dv", s, (loss_bwd_dense_kernel<D, false><<<dim3((unsigned)w.NT, (unsigned)w.nsplit_v), 64, 0, s>>>(bp)));
             sum_parts_kernel<<<dim3((unsigned)((N * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_v, N, w.Np, D, dv);
         });
     }

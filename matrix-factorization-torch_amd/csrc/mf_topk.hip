@@ -161,7 +161,7 @@ extern "C" int mf_topk(const float* q, int64_t Q, const float* items, int64_t N,
     TopkWs w = topk_ws(ws, Q, N, k);
     RetrievalPolicy::Params rp{excl_off, excl_idx, idx_base, N, Q};
     SelectCommon sc{q, Q, items, N, w.NT, w.tpc, w.Qp, k, w.cand, w.cand_cnt};
-    MF_DISPATCH_D(d, { launch_topk_select<D>(w, rp, sc, s); });
+    MF_DISPATCH_D(d, { MF_TIMED("topk_select", s, launch_topk_select<D>(w, rp, sc, s)); });
     topk_merge_cand_kernel<<<dim3((unsigned)Q), 64, (size_t)w.nchunk * w.CAP * 8, s>>>(w.cand, w.cand_cnt, w.nchunk, w.Qp, w.CAP, k,
                                                                                       idx_base, out_scores, out_idx);
     return mf_check_launch("mf_topk");
