@@ -143,8 +143,8 @@ int mf_update_adam(float* table, float* exp_avg, float* exp_avg_sq, int64_t n_ro
  * Replaces `ItemProcessor.search` (xfmr_rec/data/lightning.py:237-259; LanceDB
  * cosine ANN with prefilter) by EXACT brute-force top-k over the indexed item
  * matrix: score = chain dot(q, item) (= 1 - cosine distance for unit-norm rows),
- * exclusion prefilter by per-query sorted id lists (CSR: excl_off[Q+1],
- * excl_idx[], GLOBAL item row indices; both nullable), best first, ties by lowest
+ * exclusion prefilter by per-query id lists (CSR: excl_off[Q+1], excl_idx[],
+ * GLOBAL item row indices in any order; both nullable), best first, ties by lowest
  * item index.  `idx_base` is the global index of items[0] (row-sharded catalogs).
  * out_scores[Q,k] fp32, out_idx[Q,k] int64 global indices (-1 / -inf padding when
  * fewer than k candidates).  k <= 64. */

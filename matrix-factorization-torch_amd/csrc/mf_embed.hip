@@ -167,35 +167,18 @@ struct AdamHyper {
     float lr, beta1, beta2, eps, wd, bc1, bc2;
 };
 
-// One d/4-lane group per sorted position; the head of each run of equal ids sums
-// the run's gradient rows in batch order (deterministic) and updates the row once.
+// One d/4-lane group per sorted position.  Runs of equal ids are summed in two
+// deterministic levels so that a very popular row (Zipf: hundreds of duplicates in
+// one batch) does not serialise on one group: every 32nd position of a run sums up
+// to 32 gradient rows (batch order); a run longer than 32 parks these partial sums
+// and its first position adds them up in order in a second launch.
 template <int D, bool ADAM>
-__global__ __launch_bounds__(256) void update_rows_kernel(float* __restrict__ table,
-                                                          float* __restrict__ exp_avg,
-                                                          float* __restrict__ exp_avg_sq,
-                                                          int64_t n_rows,
-                                                          const int32_t* __restrict__ perm,
-                                                          const int64_t* __restrict__ skeys, int64_t n,
-                                                          const float* __restrict__ grad,
-                                                          int normalized, AdamHyper hp) {
+__device__ __forceinline__ void apply_row_update(bool active, int64_t row, int c, f32x4 acc,
+                                                 float* __restrict__ table, float* __restrict__ exp_avg,
+                                                 float* __restrict__ exp_avg_sq, int normalized,
+                                                 const AdamHyper& hp) {
     constexpr int LPR = D / 4;
-    constexpr int RPW = 64 / LPR;
-    const int lane = mf_lane();
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t p = wave * RPW + lane / LPR;
-    const int c = lane % LPR;
-    int64_t row = 0;
-    bool head = false;
-    if (p < n) {
-        row = skeys[p];
-        head = (p == 0 || skeys[p - 1] != row) && row >= 0 && row < n_rows;
-    }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (head) {
-        for (int64_t q = p; q < n && skeys[q] == row; ++q)
-            acc += reinterpret_cast<const f32x4*>(grad + (int64_t)perm[q] * D)[c];
-    }
-    const int64_t rr = head ? row : 0;
+    const int64_t rr = active ? row : 0;
     f32x4 w = reinterpret_cast<const f32x4*>(table + rr * D)[c];
     f32x4 g = acc;
     if (normalized) {   // grad is w.r.t. w / max(||w||, 1e-12): apply the Jacobian
@@ -205,7 +188,7 @@ __global__ __launch_bounds__(256) void update_rows_kernel(float* __restrict__ ta
         float pr = mf_group_sum(acc[0] * uh[0] + acc[1] * uh[1] + acc[2] * uh[2] + acc[3] * uh[3], LPR);
         g = (acc - uh * pr) * inv;
     }
-    if (!head) return;
+    if (!active) return;
     if (!ADAM) {
         w = w - hp.lr * (g + hp.wd * w);
     } else {
@@ -224,26 +207,77 @@ __global__ __launch_bounds__(256) void update_rows_kernel(float* __restrict__ ta
     reinterpret_cast<f32x4*>(table + rr * D)[c] = w;
 }
 
+static constexpr int RUN_CHUNK = 32;
+
+template <int D, bool ADAM, int PHASE>
+__global__ __launch_bounds__(256) void update_rows_kernel(float* __restrict__ table,
+                                                          float* __restrict__ exp_avg,
+                                                          float* __restrict__ exp_avg_sq,
+                                                          int64_t n_rows,
+                                                          const int32_t* __restrict__ perm,
+                                                          const int64_t* __restrict__ skeys, int64_t n,
+                                                          const float* __restrict__ grad,
+                                                          float* __restrict__ partial,
+                                                          int normalized, AdamHyper hp) {
+    constexpr int LPR = D / 4;
+    constexpr int RPW = 64 / LPR;
+    const int lane = mf_lane();
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t p = wave * RPW + lane / LPR;
+    const int c = lane % LPR;
+    int64_t row = 0, start = 0;
+    bool in_range = false;
+    if (p < n) {
+        row = skeys[p];
+        in_range = row >= 0 && row < n_rows;
+        int64_t lo = 0, hi = p;                       // first position of this id
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (skeys[mid] < row) lo = mid + 1; else hi = mid;
+        }
+        start = lo;
+    }
+    const bool is_start = p < n && p == start;
+    const bool long_run = p < n && start + RUN_CHUNK < n && skeys[start + RUN_CHUNK] == row;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    bool apply = false;
+    if (PHASE == 1) {
+        const bool subhead = p < n && in_range && ((p - start) % RUN_CHUNK) == 0;
+        if (subhead) {
+            for (int64_t q = p; q < n && q < p + RUN_CHUNK && skeys[q] == row; ++q)
+                acc += reinterpret_cast<const f32x4*>(grad + (int64_t)perm[q] * D)[c];
+            if (long_run) reinterpret_cast<f32x4*>(partial + p * D)[c] = acc;
+            else apply = true;                        // short run: p is its start, acc is complete
+        }
+    } else {
+        if (is_start && in_range && long_run) {
+            for (int64_t q = p; q < n && skeys[q] == row; q += RUN_CHUNK)
+                acc += reinterpret_cast<const f32x4*>(partial + q * D)[c];
+            apply = true;
+        }
+    }
+    apply_row_update<D, ADAM>(apply, row, c, acc, table, exp_avg, exp_avg_sq, normalized, hp);
+}
+
 struct UpdateWs {
     int32_t* perm;
     int64_t* skeys;
     void* sort_ws;
+    float* partial;
     size_t total;
 };
-static UpdateWs update_ws(void* ws, int64_t n) {
+static UpdateWs update_ws(void* ws, int64_t n, int d) {
     MfArena a(ws);
     UpdateWs w;
     w.perm = a.take<int32_t>((size_t)n);
     w.skeys = a.take<int64_t>((size_t)n);
     w.sort_ws = a.take<char>(mf_sort_ws_bytes(n));
+    w.partial = a.take<float>((size_t)n * d);
     w.total = a.used();
     return w;
 }
 
-extern "C" size_t mf_update_ws_bytes(int64_t n, int d) {
-    (void)d;
-    return update_ws(nullptr, n > 0 ? n : 1).total;
-}
+extern "C" size_t mf_update_ws_bytes(int64_t n, int d) { return update_ws(nullptr, n > 0 ? n : 1, d).total; }
 
 template <bool ADAM>
 static int update_common(float* table, float* m, float* v, int64_t n_rows, int d, const int64_t* idx,
@@ -252,16 +286,20 @@ static int update_common(float* table, float* m, float* v, int64_t n_rows, int d
     if (!table || !idx || !grad || !ws || n < 0 || n_rows <= 0 || (ADAM && (!m || !v)))
         return mf_set_error(MF_EINVAL, "%s: bad argument", what);
     if (n_rows >= (1ll << 39)) return mf_set_error(MF_ENOTSUP, "%s: table too large", what);
+    if (!mf_width_ok(d)) return mf_set_error(MF_EINVAL, "%s: embedding width %d not in {32,64,128,256}", what, d);
     if (ws_bytes < mf_update_ws_bytes(n, d)) return mf_set_error(MF_ENOSPC, "%s: workspace too small", what);
     if (n == 0) return MF_OK;
-    UpdateWs w = update_ws(ws, n);
+    UpdateWs w = update_ws(ws, n, d);
     int rc = mf_sort_keys(idx, n, w.perm, w.skeys, w.sort_ws, mf_sort_ws_bytes(n), stream);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     MF_DISPATCH_D(d, {
         constexpr int RPB = (64 / (D / 4)) * 4;
         dim3 grid((unsigned)((n + RPB - 1) / RPB));
-        MF_TIMED("update_rows", s, (update_rows_kernel<D, ADAM><<<grid, 256, 0, s>>>(table, m, v, n_rows, w.perm, w.skeys, n, grad, normalized, hp)));
+        MF_TIMED("update_rows", s, {
+            (update_rows_kernel<D, ADAM, 1><<<grid, 256, 0, s>>>(table, m, v, n_rows, w.perm, w.skeys, n, grad, w.partial, normalized, hp));
+            (update_rows_kernel<D, ADAM, 2><<<grid, 256, 0, s>>>(table, m, v, n_rows, w.perm, w.skeys, n, grad, w.partial, normalized, hp));
+        });
     });
     return mf_check_launch(what);
 }

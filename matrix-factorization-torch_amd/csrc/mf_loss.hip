@@ -44,9 +44,8 @@ struct LossWs {
     int nsplit_v, tps_v;          // dV pass: user-range splits
     int T, CAP, nchunk, tpc;      // mining select geometry
     float *nu, *nv, *lii, *dii, *sgn, *logq;
-    int32_t* perm;
-    int64_t* skeys;
-    void* sort_ws;
+    long long* htab;
+    int slots;
     uint32_t *maskW, *maskTW;
     float *part, *stats, *rowloss, *rowc, *dpart;
     unsigned long long* cand;
@@ -66,7 +65,6 @@ static void split_geometry(int x_tiles, int y_tiles, int* nsplit, int* tps) {
 static bool mining_on(int num_negatives, int64_t N) { return num_negatives > 0 && num_negatives < N; }
 
 static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_negatives) {
-    (void)P;
     LossWs w{};
     w.B = B; w.N = N; w.d = d;
     w.Bp = mf_pad32(B); w.Np = mf_pad32(N);
@@ -91,8 +89,9 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.nu = a.take<float>(w.Bp); w.nv = a.take<float>(w.Np);
     w.lii = a.take<float>(w.Bp); w.dii = a.take<float>(w.Bp); w.sgn = a.take<float>(w.Bp);
     w.logq = a.take<float>(w.Np);
-    w.perm = a.take<int32_t>(N); w.skeys = a.take<int64_t>(N);
-    w.sort_ws = a.take<char>(mf_sort_ws_bytes(N));
+    w.slots = 8;
+    while (w.slots < 2 * (P + 1)) w.slots *= 2;
+    w.htab = a.take<long long>((size_t)w.Bp * w.slots);
     w.maskW = a.take<uint32_t>((size_t)w.NT * w.Bp);
     w.maskTW = a.take<uint32_t>((size_t)w.BT * w.Np);
     w.part = a.take<float>((size_t)w.nsplit_f * NSTAT * w.Bp);
@@ -145,35 +144,79 @@ __global__ __launch_bounds__(256) void diag_kernel(const float* __restrict__ u, 
 // ------------------------------------------------------------------ hit masks --
 // maskW [tj][i]  bit c : item column 32 tj + c is NOT a valid negative of user i
 // maskTW[ti][j]  bit r : user 32 ti + r  x  item j   (same bit, transposed words)
-__global__ __launch_bounds__(256) void mask_pad_kernel(uint32_t* __restrict__ maskW, uint32_t* __restrict__ maskTW,
-                                                       int64_t B, int64_t N, int64_t Bp, int64_t Np, int BT, int NT) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int nc = (int)(N - (int64_t)(NT - 1) * 32);   // valid columns in the last item tile (1..32)
-    const int nr = (int)(B - (int64_t)(BT - 1) * 32);
-    if (t < Bp && nc < 32) maskW[(int64_t)(NT - 1) * Bp + t] = ~0u << nc;
-    if (t < Np && nr < 32) maskTW[(int64_t)(BT - 1) * Np + t] = ~0u << nr;
+//
+// The reference compares every (user, column, positive) triple (B x N x P bools,
+// losses.py:108).  Here each user's positives (plus its own item, the accidental-hit
+// term of losses.py:103) go into a small open-addressing hash set, and the B x N
+// membership tests are one dense, atomic-free sweep: a half-wave holds 32 users on
+// its lanes and walks column tiles; each lane ORs its own word of maskW, and the
+// ballot of a column over the 32 lanes IS that column's maskTW word.
+static constexpr long long HT_EMPTY = (long long)0x8080808080808080ull;   // memset(0x80)
+
+__device__ __forceinline__ unsigned ht_hash(long long id, unsigned slots_mask) {
+    return (((unsigned)id * 2654435761u) ^ (unsigned)((unsigned long long)id >> 32) * 40503u) >> 7 & slots_mask;
 }
 
-__global__ __launch_bounds__(256) void mask_build_kernel(const int64_t* __restrict__ item_idx,
-                                                         const int64_t* __restrict__ pos_idx,
-                                                         const int32_t* __restrict__ perm,
-                                                         const int64_t* __restrict__ skeys, int64_t B, int64_t N,
-                                                         int P, int64_t Bp, int64_t Np,
-                                                         uint32_t* __restrict__ maskW, uint32_t* __restrict__ maskTW) {
+__global__ __launch_bounds__(256) void ht_insert_kernel(const int64_t* __restrict__ item_idx,
+                                                        const int64_t* __restrict__ pos_idx, int64_t B, int P,
+                                                        int slots, long long* __restrict__ htab) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / (P + 1);
     const int p = (int)(t % (P + 1));
     if (i >= B) return;
-    const int64_t key = (p == P) ? item_idx[i] : pos_idx[i * P + p];
-    int64_t lo = 0, hi = N;   // lower_bound
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (skeys[mid] < key) lo = mid + 1; else hi = mid;
+    const long long key = (p == P) ? item_idx[i] : pos_idx[i * P + p];
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(htab + i * slots);
+    unsigned hpos = ht_hash(key, slots - 1);
+    for (int probe = 0; probe < slots; ++probe) {
+        const unsigned long long old = atomicCAS(&tab[hpos], (unsigned long long)HT_EMPTY, (unsigned long long)key);
+        if (old == (unsigned long long)HT_EMPTY || old == (unsigned long long)key) return;
+        hpos = (hpos + 1) & (slots - 1);
     }
-    for (int64_t q = lo; q < N && skeys[q] == key; ++q) {
-        const int64_t j = perm[q];
-        atomicOr(&maskW[(j >> 5) * Bp + i], 1u << (j & 31));
-        atomicOr(&maskTW[(i >> 5) * Np + j], 1u << (i & 31));
+}
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(256) void mask_sweep_kernel(const int64_t* __restrict__ item_idx,
+                                                         const long long* __restrict__ htab, int slots, int64_t B,
+                                                         int64_t N, int64_t Bp, int64_t Np, int NT,
+                                                         uint32_t* __restrict__ maskW, uint32_t* __restrict__ maskTW) {
+    extern __shared__ __attribute__((aligned(16))) long long s_tab[];   // [32][slots] when IN_LDS
+    const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
+    const int ti = blockIdx.x;
+    const int64_t i = (int64_t)ti * 32 + c;
+    const long long* tab = htab + i * slots;
+    if (IN_LDS) {
+        for (int t = threadIdx.x; t < 32 * slots; t += 256) s_tab[t] = htab[(int64_t)ti * 32 * slots + t];
+        __syncthreads();
+        tab = s_tab + c * slots;
+    }
+    const unsigned smask = slots - 1;
+    const bool user_ok = i < B;
+    const int hw = (threadIdx.x >> 6) * 2 + h;            // half-wave id inside the block: 0..7
+    for (int tj = blockIdx.y * 8 + hw; tj < NT; tj += 8 * gridDim.y) {
+        const int64_t j0 = (int64_t)tj * 32;
+        uint32_t word = 0u, tword = 0u;
+#pragma unroll 4
+        for (int c2 = 0; c2 < 32; ++c2) {
+            const int64_t j = j0 + c2;
+            bool hit = true;                                // padding column / padding user: never a negative
+            if (j < N && user_ok) {
+                const long long id = item_idx[j];
+                unsigned hpos = ht_hash(id, smask);
+                hit = false;
+                for (int probe = 0; probe < slots; ++probe) {
+                    const long long sv = tab[hpos];
+                    if (sv == id) { hit = true; break; }
+                    if (sv == HT_EMPTY) break;
+                    hpos = (hpos + 1) & smask;
+                }
+            }
+            word |= (hit ? 1u : 0u) << c2;
+            const unsigned long long bal = __ballot(hit);
+            const uint32_t mine = h ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+            if (c == c2) tword = mine;
+        }
+        maskW[(int64_t)tj * Bp + i] = word;
+        maskTW[(int64_t)ti * Np + j0 + c] = tword;
     }
 }
 
@@ -738,14 +781,19 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     diag_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(u, v, target, logq, w.nu, w.nv, B, w.Bp, d, sigma,
                                                                      w.lii, w.dii, w.sgn);
     if (scores_needed) {
-        if ((rc = mf_sort_keys(item_idx, N, w.perm, w.skeys, w.sort_ws, mf_sort_ws_bytes(N), stream))) return rc;
-        (void)hipMemsetAsync(w.maskW, 0, (size_t)w.NT * w.Bp * 4, s);
-        (void)hipMemsetAsync(w.maskTW, 0, (size_t)w.BT * w.Np * 4, s);
-        const int64_t mx = w.Bp > w.Np ? w.Bp : w.Np;
-        mask_pad_kernel<<<dim3((unsigned)((mx + 255) / 256)), 256, 0, s>>>(w.maskW, w.maskTW, B, N, w.Bp, w.Np, w.BT, w.NT);
+        (void)hipMemsetAsync(w.htab, 0x80, (size_t)w.Bp * w.slots * 8, s);
         const int64_t nthreads = B * (P + 1);
-        mask_build_kernel<<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(item_idx, pos_idx, w.perm, w.skeys, B, N, P,
-                                                                                   w.Bp, w.Np, w.maskW, w.maskTW);
+        ht_insert_kernel<<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(item_idx, pos_idx, B, P, w.slots, w.htab);
+        int gy = (w.NT + 7) / 8;
+        if (gy > 16) gy = 16;
+        if (gy * w.BT < 1024) gy = (1024 + w.BT - 1) / w.BT;   // enough blocks when B is small
+        if (gy > (w.NT + 7) / 8) gy = (w.NT + 7) / 8;
+        if (w.slots <= 256)
+            mask_sweep_kernel<true><<<dim3((unsigned)w.BT, (unsigned)gy), 256, (size_t)32 * w.slots * 8, s>>>(
+                item_idx, w.htab, w.slots, B, N, w.Bp, w.Np, w.NT, w.maskW, w.maskTW);
+        else
+            mask_sweep_kernel<false><<<dim3((unsigned)w.BT, (unsigned)gy), 256, 0, s>>>(
+                item_idx, w.htab, w.slots, B, N, w.Bp, w.Np, w.NT, w.maskW, w.maskTW);
     }
     // logq is read by whole float4s up to the padded width: keep a zero-padded copy in ws
     const float* logq_p = nullptr;

@@ -2,8 +2,8 @@
 //
 // Replaces ItemProcessor.search (xfmr_rec/data/lightning.py:237-259, LanceDB cosine
 // ANN + prefilter) by an exact scan: score tiles from the fp32 MFMA engine, streaming
-// per-query selection (mf_select.h), exclusion lists checked only for the few
-// survivors of the running threshold, then an exact ordered merge per query.
+// per-query selection (mf_select.h), exclusion lists scattered once into a
+// bitmask (one coalesced word per query and tile), then an exact ordered merge per query.
 // The same merge kernel joins the all-gathered partial top-k of a row-sharded
 // catalog (mf_topk_merge).
 #include <cmath>
@@ -11,43 +11,46 @@
 #include "mf_common.h"
 #include "mf_select.h"
 
+// Exclusion prefilter as a bitmask: exclW[tile][query] holds the 32 "excluded" bits of
+// that query for that item tile (the lists are sparse -- ~10^2 of 10^4..10^8 rows --
+// so the words are scattered once per call and read with one coalesced load per tile).
 struct RetrievalPolicy {
     struct Params {
-        const int64_t* excl_off;   // [Q + 1] or null
-        const int64_t* excl_idx;   // sorted ascending inside each query's range
-        int64_t idx_base, nY, nX;
+        const uint32_t* exclW;     // [NT][Qp] or null
+        int64_t Qp, nY;
     };
-    struct Row {
-        int64_t lo, hi;
+    struct Row {};
+    struct Tile {
+        uint32_t ew;
     };
-    struct Tile {};
-    static __device__ __forceinline__ Row row_init(const Params& p, int64_t x, bool valid) {
-        if (!p.excl_off || !valid) return Row{0, 0};
-        return Row{p.excl_off[x], p.excl_off[x + 1]};
+    static __device__ __forceinline__ Row row_init(const Params&, int64_t, bool) { return Row{}; }
+    static __device__ __forceinline__ Tile tile_init(const Params& p, const Row&, int64_t y0, int64_t x) {
+        return Tile{p.exclW ? p.exclW[(y0 >> 5) * p.Qp + x] : 0u};
     }
-    static __device__ __forceinline__ Tile tile_init(const Params&, const Row&, int64_t, int64_t) { return Tile{}; }
-    static __device__ __forceinline__ unsigned long long key(const Params& p, const Row&, const Tile&, float score,
-                                                            int, int, int64_t y) {
+    static __device__ __forceinline__ unsigned long long key(const Params& p, const Row&, const Tile& t, float score,
+                                                            int e, int h, int64_t y) {
+        if ((t.ew >> mf_acc_row(e, h)) & 1u) return 0ull;
         return y < p.nY ? mf_key_retrieval(score, (unsigned)y) : 0ull;
     }
-    static __device__ __forceinline__ bool excluded(const Params& p, const Row& r, int64_t y) {
-        const int64_t want = p.idx_base + y;
-        int64_t lo = r.lo, hi = r.hi;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            const int64_t v = p.excl_idx[mid];
-            if (v == want) return true;
-            if (v < want) lo = mid + 1; else hi = mid;
-        }
-        return false;
-    }
+    static __device__ __forceinline__ bool excluded(const Params&, const Row&, int64_t) { return false; }
 };
+
+__global__ __launch_bounds__(256) void excl_scatter_kernel(const int64_t* __restrict__ excl_off,
+                                                           const int64_t* __restrict__ excl_idx, int64_t idx_base,
+                                                           int64_t N, int64_t Qp, uint32_t* __restrict__ exclW) {
+    const int64_t r = blockIdx.x;
+    for (int64_t e = excl_off[r] + threadIdx.x; e < excl_off[r + 1]; e += 256) {
+        const int64_t y = excl_idx[e] - idx_base;
+        if (y >= 0 && y < N) atomicOr(&exclW[(y >> 5) * Qp + r], 1u << (y & 31));
+    }
+}
 
 struct TopkWs {
     int64_t Qp;
     int QT, NT, T, CAP, nchunk, tpc;
     unsigned long long* cand;
     int32_t* cand_cnt;
+    uint32_t* exclW;
     size_t total;
 };
 
@@ -68,6 +71,7 @@ static TopkWs topk_ws(void* base, int64_t Q, int64_t N, int k) {
     MfArena a(base);
     w.cand = a.take<unsigned long long>((size_t)w.nchunk * w.Qp * w.CAP);
     w.cand_cnt = a.take<int32_t>((size_t)w.nchunk * w.Qp);
+    w.exclW = a.take<uint32_t>((size_t)w.NT * w.Qp);
     w.total = a.used();
     return w;
 }
@@ -159,7 +163,13 @@ extern "C" int mf_topk(const float* q, int64_t Q, const float* items, int64_t N,
     if (ws_bytes < mf_topk_ws_bytes(Q, N, d, k)) return mf_set_error(MF_ENOSPC, "mf_topk: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     TopkWs w = topk_ws(ws, Q, N, k);
-    RetrievalPolicy::Params rp{excl_off, excl_idx, idx_base, N, Q};
+    const uint32_t* exclW = nullptr;
+    if (excl_off) {
+        (void)hipMemsetAsync(w.exclW, 0, (size_t)w.NT * w.Qp * 4, s);
+        excl_scatter_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.Qp, w.exclW);
+        exclW = w.exclW;
+    }
+    RetrievalPolicy::Params rp{exclW, w.Qp, N};
     SelectCommon sc{q, Q, items, N, w.NT, w.tpc, w.Qp, k, w.cand, w.cand_cnt};
     MF_DISPATCH_D(d, { MF_TIMED("topk_select", s, launch_topk_select<D>(w, rp, sc, s)); });
     topk_merge_cand_kernel<<<dim3((unsigned)Q), 64, (size_t)w.nchunk * w.CAP * 8, s>>>(w.cand, w.cand_cnt, w.nchunk, w.Qp, w.CAP, k,

@@ -196,6 +196,7 @@ def test_sparse_update_matches_oracle(mf, d, normalize, opt):
     table0 = torch.randn(rows, d, generator=g)
     idx = torch.randint(0, 40, (n,), generator=g)          # heavy duplicates
     idx[:50] = torch.randint(0, rows, (50,), generator=g)
+    idx[100:400] = 5                                       # one run far longer than a 32-row chunk
     tower = mf.models.EmbeddingTower(rows, d, normalize=normalize, device=DEV)
     with torch.no_grad():
         tower.weight.copy_(table0.to(DEV))
