@@ -18,6 +18,7 @@
 
 #include "mf_common.h"
 #include "mf_select.h"
+#include "mf_stream.h"
 
 static constexpr int NSTAT = 8;  // cnt, A(contrastive), mx, se, H, Hc, Lg, Ls
 enum { ST_CNT = 0, ST_A = 1, ST_MX = 2, ST_SE = 3, ST_H = 4, ST_HC = 5, ST_LG = 6, ST_LS = 7 };
@@ -44,18 +45,20 @@ struct LossWs {
     int nsplit_v, tps_v;          // dV pass: user-range splits
     int T, CAP, nchunk, tpc;      // mining select geometry
     float *nu, *nv, *lii, *dii, *sgn, *logq;
-    long long* htab;
-    int slots;
+    long long* gtab;
+    int M;
+    int32_t* colslot;
+    uint32_t* ubits;
     uint32_t *maskW, *maskTW;
-    float *part, *stats, *rowloss, *rowc, *dpart;
+    float *part, *stats, *rowloss, *rowc, *dpart, *stash;
     unsigned long long* cand;
     int32_t *cand_cnt, *sel, *sel_cnt;
     float* sel_L;
     size_t total;
 };
 
-static void split_geometry(int x_tiles, int y_tiles, int* nsplit, int* tps) {
-    int want = (2048 + x_tiles - 1) / x_tiles;
+static void split_geometry(int x_tiles, int y_tiles, int* nsplit, int* tps, int target_blocks) {
+    int want = (target_blocks + x_tiles - 1) / x_tiles;
     if (want < 1) want = 1;
     if (want > y_tiles) want = y_tiles;
     *tps = (y_tiles + want - 1) / want;
@@ -67,15 +70,18 @@ static bool mining_on(int num_negatives, int64_t N) { return num_negatives > 0 &
 static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_negatives) {
     LossWs w{};
     w.B = B; w.N = N; w.d = d;
-    w.Bp = mf_pad32(B); w.Np = mf_pad32(N);
+    w.Bp = (B + 127) / 128 * 128; w.Np = (N + 127) / 128 * 128;   // 4 waves x 32 rows per workgroup
     w.BT = (int)(w.Bp / 32); w.NT = (int)(w.Np / 32);
     w.mined = mining_on(num_negatives, N);
-    split_geometry(w.BT, w.NT, &w.nsplit_f, &w.tps_f);
-    w.nsplit_u = w.nsplit_f; w.tps_u = w.tps_f;
-    split_geometry(w.NT, w.BT, &w.nsplit_v, &w.tps_v);
+    split_geometry(w.BT / 4, w.NT, &w.nsplit_f, &w.tps_f, 512);
+    split_geometry(w.BT / 4, w.NT, &w.nsplit_u, &w.tps_u, 256);
+    split_geometry(w.NT / 4, w.BT, &w.nsplit_v, &w.tps_v, 256);
     const int k = num_negatives;
-    w.T = k <= 4 ? 2 : k <= 8 ? 4 : k <= 16 ? 8 : k <= 24 ? 12 : k <= 32 ? 16 : 32;
-    w.CAP = k <= 24 ? 64 : 128;
+    {
+        int capl;
+        mf_select_geometry(k, &w.T, &capl);
+        w.CAP = 2 * capl;
+    }
     {
         int maxchunk = (64 * 1024) / (w.CAP * 8);
         int want = (2048 + w.BT - 1) / w.BT;
@@ -89,9 +95,12 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.nu = a.take<float>(w.Bp); w.nv = a.take<float>(w.Np);
     w.lii = a.take<float>(w.Bp); w.dii = a.take<float>(w.Bp); w.sgn = a.take<float>(w.Bp);
     w.logq = a.take<float>(w.Np);
-    w.slots = 8;
-    while (w.slots < 2 * (P + 1)) w.slots *= 2;
-    w.htab = a.take<long long>((size_t)w.Bp * w.slots);
+    (void)P;
+    w.M = 64;
+    while (w.M < 2 * w.Np) w.M *= 2;
+    w.gtab = a.take<long long>((size_t)w.M);
+    w.colslot = a.take<int32_t>((size_t)w.Np);
+    w.ubits = a.take<uint32_t>((size_t)(w.M / 32) * w.Bp);
     w.maskW = a.take<uint32_t>((size_t)w.NT * w.Bp);
     w.maskTW = a.take<uint32_t>((size_t)w.BT * w.Np);
     w.part = a.take<float>((size_t)w.nsplit_f * NSTAT * w.Bp);
@@ -110,6 +119,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
         size_t rows_v = (size_t)w.nsplit_v * w.Np;
         if (rows_v > rows) rows = rows_v;
         w.dpart = a.take<float>(rows * d);
+        w.stash = a.take<float>((size_t)w.Bp * w.Np);
     }
     w.total = a.used();
     return w;
@@ -146,70 +156,76 @@ __global__ __launch_bounds__(256) void diag_kernel(const float* __restrict__ u, 
 // maskTW[ti][j]  bit r : user 32 ti + r  x  item j   (same bit, transposed words)
 //
 // The reference compares every (user, column, positive) triple (B x N x P bools,
-// losses.py:108).  Here each user's positives (plus its own item, the accidental-hit
-// term of losses.py:103) go into a small open-addressing hash set, and the B x N
-// membership tests are one dense, atomic-free sweep: a half-wave holds 32 users on
-// its lanes and walks column tiles; each lane ORs its own word of maskW, and the
-// ballot of a column over the 32 lanes IS that column's maskTW word.
+// losses.py:108).  Here:
+//   1. the batch's item ids go into ONE open-addressing table (M >= 2N slots); the
+//      slot an id lands in is its dense "batch id" (duplicate columns share it);
+//   2. each user's positives (plus its own item: the accidental-hit term,
+//      losses.py:103) are looked up there and set one bit of that user's row of
+//      ubits[slot / 32][user] -- positives absent from the batch cost nothing more;
+//   3. the B x N membership tests are then a branch-free sweep: one coalesced word
+//      load and a shift per (user, column).  A half-wave holds 32 users on its lanes
+//      and walks column tiles; each lane ORs its own maskW word and the ballot of a
+//      column over the 32 lanes IS that column's maskTW word.
 static constexpr long long HT_EMPTY = (long long)0x8080808080808080ull;   // memset(0x80)
 
 __device__ __forceinline__ unsigned ht_hash(long long id, unsigned slots_mask) {
-    return (((unsigned)id * 2654435761u) ^ (unsigned)((unsigned long long)id >> 32) * 40503u) >> 7 & slots_mask;
+    return ((((unsigned)id * 2654435761u) ^ ((unsigned)((unsigned long long)id >> 32) * 40503u)) >> 5) & slots_mask;
 }
 
-__global__ __launch_bounds__(256) void ht_insert_kernel(const int64_t* __restrict__ item_idx,
-                                                        const int64_t* __restrict__ pos_idx, int64_t B, int P,
-                                                        int slots, long long* __restrict__ htab) {
+__global__ __launch_bounds__(256) void gt_insert_kernel(const int64_t* __restrict__ item_idx, int64_t N, int M,
+                                                        long long* __restrict__ gtab, int32_t* __restrict__ colslot) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const long long key = item_idx[j];
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(gtab);
+    unsigned hpos = ht_hash(key, M - 1);
+    for (int probe = 0; probe < M; ++probe) {
+        const unsigned long long old = atomicCAS(&tab[hpos], (unsigned long long)HT_EMPTY, (unsigned long long)key);
+        if (old == (unsigned long long)HT_EMPTY || old == (unsigned long long)key) break;
+        hpos = (hpos + 1) & (M - 1);
+    }
+    colslot[j] = (int32_t)hpos;
+}
+
+__global__ __launch_bounds__(256) void ubits_kernel(const int64_t* __restrict__ item_idx,
+                                                    const int64_t* __restrict__ pos_idx, int64_t B, int P, int M,
+                                                    const long long* __restrict__ gtab, int64_t Bp,
+                                                    uint32_t* __restrict__ ubits) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / (P + 1);
     const int p = (int)(t % (P + 1));
     if (i >= B) return;
     const long long key = (p == P) ? item_idx[i] : pos_idx[i * P + p];
-    unsigned long long* tab = reinterpret_cast<unsigned long long*>(htab + i * slots);
-    unsigned hpos = ht_hash(key, slots - 1);
-    for (int probe = 0; probe < slots; ++probe) {
-        const unsigned long long old = atomicCAS(&tab[hpos], (unsigned long long)HT_EMPTY, (unsigned long long)key);
-        if (old == (unsigned long long)HT_EMPTY || old == (unsigned long long)key) return;
-        hpos = (hpos + 1) & (slots - 1);
+    unsigned hpos = ht_hash(key, M - 1);
+    for (int probe = 0; probe < M; ++probe) {
+        const long long sv = gtab[hpos];
+        if (sv == key) {
+            atomicOr(&ubits[(int64_t)(hpos >> 5) * Bp + i], 1u << (hpos & 31));
+            return;
+        }
+        if (sv == HT_EMPTY) return;           // this positive is not in the batch
+        hpos = (hpos + 1) & (M - 1);
     }
 }
 
-template <bool IN_LDS>
-__global__ __launch_bounds__(256) void mask_sweep_kernel(const int64_t* __restrict__ item_idx,
-                                                         const long long* __restrict__ htab, int slots, int64_t B,
-                                                         int64_t N, int64_t Bp, int64_t Np, int NT,
+__global__ __launch_bounds__(256) void mask_sweep_kernel(const int32_t* __restrict__ colslot,
+                                                         const uint32_t* __restrict__ ubits, int64_t B, int64_t N,
+                                                         int64_t Bp, int64_t Np, int NT,
                                                          uint32_t* __restrict__ maskW, uint32_t* __restrict__ maskTW) {
-    extern __shared__ __attribute__((aligned(16))) long long s_tab[];   // [32][slots] when IN_LDS
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int ti = blockIdx.x;
     const int64_t i = (int64_t)ti * 32 + c;
-    const long long* tab = htab + i * slots;
-    if (IN_LDS) {
-        for (int t = threadIdx.x; t < 32 * slots; t += 256) s_tab[t] = htab[(int64_t)ti * 32 * slots + t];
-        __syncthreads();
-        tab = s_tab + c * slots;
-    }
-    const unsigned smask = slots - 1;
     const bool user_ok = i < B;
     const int hw = (threadIdx.x >> 6) * 2 + h;            // half-wave id inside the block: 0..7
     for (int tj = blockIdx.y * 8 + hw; tj < NT; tj += 8 * gridDim.y) {
         const int64_t j0 = (int64_t)tj * 32;
+        const int myslot = j0 + c < N ? colslot[j0 + c] : -1;
         uint32_t word = 0u, tword = 0u;
-#pragma unroll 4
+#pragma unroll 8
         for (int c2 = 0; c2 < 32; ++c2) {
-            const int64_t j = j0 + c2;
+            const int slot = __shfl(myslot, c2 + 32 * h, 64);
             bool hit = true;                                // padding column / padding user: never a negative
-            if (j < N && user_ok) {
-                const long long id = item_idx[j];
-                unsigned hpos = ht_hash(id, smask);
-                hit = false;
-                for (int probe = 0; probe < slots; ++probe) {
-                    const long long sv = tab[hpos];
-                    if (sv == id) { hit = true; break; }
-                    if (sv == HT_EMPTY) break;
-                    hpos = (hpos + 1) & smask;
-                }
-            }
+            if (slot >= 0 && user_ok) hit = (ubits[(int64_t)(slot >> 5) * Bp + i] >> (slot & 31)) & 1u;
             word |= (hit ? 1u : 0u) << c2;
             const unsigned long long bal = __ballot(hit);
             const uint32_t mine = h ? (uint32_t)(bal >> 32) : (uint32_t)bal;
@@ -225,6 +241,7 @@ struct FwdParams {
     const float *u, *v, *nu, *nv, *lii, *sgn, *logq;
     const uint32_t* maskW;
     float* part;
+    float* stash;          // [Bp/32][NT] blocks of 32 x 32 logits (see BwdParams)
     int64_t B, N, Bp;
     int NT, tps, need;
     float sigma, margin;
@@ -269,10 +286,26 @@ __device__ __forceinline__ void stats_add(RowStats& s, int need, float L, float 
     }
 }
 
+// Workgroup = 4 waves x 32 users; item tiles arrive through the LDS ring of
+// mf_stream.h together with their mask words, norms and logQ.
 template <int D>
-__global__ __launch_bounds__(64) void loss_fwd_dense_kernel(FwdParams p) {
+struct FwdLds {
+    using G = TileGeom<D>;
+    static constexpr int AUX_MASK = 0, AUX_NV = 512, AUX_LQ = 640, AUX_PAD = 768, AUXB = 1024;
+    static constexpr int SLOT = G::TILEB + AUXB;
+    static constexpr int BYTES = 3 * SLOT;
+    static constexpr int NDMA = G::PPW + 1;    // DMA instructions per wave per stage (+ 4 stash stores per tile)
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = TileGeom<D>;
+    using L = FwdLds<D>;
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
-    const int64_t i = (int64_t)blockIdx.x * 32 + c;
+    const int wave = mf_wave_id();
+    const int64_t i0 = (int64_t)blockIdx.x * 128;
+    const int64_t i = i0 + wave * 32 + c;
     const int t0 = blockIdx.y * p.tps, t1 = min(p.NT, t0 + p.tps);
     RowFrag<D> xf;
     mf_load_frag<D>(xf, p.u, i, i < p.B);
@@ -280,26 +313,53 @@ __global__ __launch_bounds__(64) void loss_fwd_dense_kernel(FwdParams p) {
     const float sm = s_i * p.margin;
     RowStats st;
     stats_init(st);
+
+    auto stage = [&](int t, int slot_idx) {
+        char* slot = smem + slot_idx * L::SLOT;
+        const int64_t j0 = (int64_t)t * 32;
+        mf_stage_tile<D>(slot, p.v, j0, p.N);
+        char* aux = slot + G::TILEB;
+        if (wave == 0) mf_stage_small(aux + L::AUX_MASK, p.maskW + (int64_t)t * p.Bp + i0, 512);
+        else if (wave == 1) mf_stage_small(aux + L::AUX_NV, p.nv + j0, 128);
+        else if (wave == 2) mf_stage_small(aux + L::AUX_LQ, (p.logq ? p.logq : p.nv) + j0, 128);
+        else mf_stage_small(aux + L::AUX_PAD, p.nv + j0, 128);
+    };
+    if (t0 < t1) stage(t0, 0);
+    if (t0 + 1 < t1) stage(t0 + 1, 1);
+    int cur = 0;
     for (int tj = t0; tj < t1; ++tj) {
-        const int64_t j0 = (int64_t)tj * 32;
+        // queue, oldest first: [DMA(tj)] [stores(tj-2)] [DMA(tj+1)] [stores(tj-1)]
+        if (tj + 1 >= t1) mf_wait_vmcnt<0>();
+        else if (tj == t0) mf_wait_vmcnt<L::NDMA>();
+        else mf_wait_vmcnt<L::NDMA + 4>();
+        mf_block_barrier();
+        if (tj + 2 < t1) stage(tj + 2, cur >= 1 ? cur - 1 : 2);
+        const char* slot = smem + cur * L::SLOT;
+        const char* aux = slot + G::TILEB;
         RowFrag<D> yf;
-        mf_load_frag<D>(yf, p.v, j0 + c, j0 + c < p.N);
+        mf_lds_frag<D>(yf, slot);
         const f32x16 acc = mf_tile_scores<D>(yf, xf);
-        const uint32_t mw = p.maskW[(int64_t)tj * p.Bp + i];
+        const uint32_t mw = reinterpret_cast<const uint32_t*>(aux + L::AUX_MASK)[wave * 32 + c];
         f32x4 nv4[4], lq4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            nv4[q] = *reinterpret_cast<const f32x4*>(p.nv + j0 + 8 * q + 4 * h);
-            lq4[q] = p.logq ? *reinterpret_cast<const f32x4*>(p.logq + j0 + 8 * q + 4 * h)
+            nv4[q] = *reinterpret_cast<const f32x4*>(aux + L::AUX_NV + (8 * q + 4 * h) * 4);
+            lq4[q] = p.logq ? *reinterpret_cast<const f32x4*>(aux + L::AUX_LQ + (8 * q + 4 * h) * 4)
                             : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        float L[16];
+        float Lg[16];
         float tmax = -FLT_MAX;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            L[e] = mf_logit(nu_i, nv4[e >> 2][e & 3], acc[e], s_i, p.sigma, lq4[e >> 2][e & 3]);
+            Lg[e] = mf_logit(nu_i, nv4[e >> 2][e & 3], acc[e], s_i, p.sigma, lq4[e >> 2][e & 3]);
             const bool ok = !((mw >> mf_acc_row(e, h)) & 1u);
-            if (ok) tmax = fmaxf(tmax, L[e]);
+            if (ok) tmax = fmaxf(tmax, Lg[e]);
+        }
+        {   // stash the logits block for the backward sweeps
+            float* blk = p.stash + ((int64_t)(i0 / 32 + wave) * p.NT + tj) * 1024 + lane * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(blk + q * 256) = f32x4{Lg[4 * q], Lg[4 * q + 1], Lg[4 * q + 2], Lg[4 * q + 3]};
         }
         float nmx = fmaxf(st.mx, tmax);
         if (p.need & NEED_LSE) st.se *= __expf(st.mx - nmx);
@@ -307,11 +367,12 @@ __global__ __launch_bounds__(64) void loss_fwd_dense_kernel(FwdParams p) {
         for (int e = 0; e < 16; ++e) {
             const bool ok = !((mw >> mf_acc_row(e, h)) & 1u);
             if (ok) {
-                stats_add(st, p.need, L[e], sm, lii, p.margin);
-                if (p.need & NEED_LSE) st.se += __expf(L[e] - nmx);
+                stats_add(st, p.need, Lg[e], sm, lii, p.margin);
+                if (p.need & NEED_LSE) st.se += __expf(Lg[e] - nmx);
             }
         }
         st.mx = nmx;
+        cur = cur == 2 ? 0 : cur + 1;
     }
     // the row's other half of the columns lives in lane ^ 32
     {
@@ -438,7 +499,6 @@ struct MiningPolicy {
         const float L = mf_logit(r.nu, t.nv4[e >> 2][e & 3], score, r.sgn, p.sigma, t.lq4[e >> 2][e & 3]);
         return mf_key_mining(L - r.lii, (unsigned)y);
     }
-    static __device__ __forceinline__ bool excluded(const Params&, const Row&, int64_t) { return false; }
 };
 
 // one wave per user: exact ordered top-k of the chunk candidates -> sel[i][0..cnt)
@@ -559,36 +619,50 @@ __device__ __forceinline__ float g_of(int gmode, float x) {
     return x >= 0.f ? r : e * r;
 }
 
+// The forward stashes the logits of every 32 x 32 (user tile, item tile) block in HBM
+// (B x N fp32: 0.5 GB at B = 8192 -- MI355X has 288 GB) so that the two backward
+// sweeps only contract: they never recompute the score tile.  Block (ti, tj) is 4 KiB:
+// [q = e / 4][lane][e % 4] in the forward's accumulator layout (lane = user), i.e.
+// four whole-KiB coalesced stores per tile and a linear LDS-DMA on the way back.
 struct BwdParams {
-    const float *u, *v, *nu, *nv, *sgn, *logq, *rowc;
+    const float *u, *v, *rowc, *stash;
     const uint32_t *maskW, *maskTW;
     float* dpart;
     int64_t B, N, Bp, Np;
-    int YT, tps, gmode;
-    float sigma;
+    int NT, YT, tps, gmode;
+};
+
+template <int D, bool XU>
+struct BwdLds {
+    using G = TileGeom<D>;
+    static constexpr int LT = G::TILEB;                  // 4 x 4 KiB logits blocks (one per wave)
+    static constexpr int AUX = G::TILEB + 4 * 4096;      // 4 x 128 B mask words, then 4 x 128 B rowc (dV)
+    static constexpr int SLOT = AUX + 1024;
+    static constexpr int EXTRA = XU ? 0 : 4 * 33 * 32 * 4;
+    static constexpr int NSLOT = (3 * SLOT + EXTRA <= 160 * 1024) ? 3 : 2;   // d = 256: 2-deep ring, 2 barriers
+    static constexpr int TR = NSLOT * SLOT;              // dV: per-wave 32 x 33 transpose scratch
+    static constexpr int BYTES = TR + EXTRA;
+    static constexpr int NWAIT = G::PPW + 4 + (XU ? 1 : 2);   // DMA instructions per wave per stage
 };
 
 // XU = true : lanes hold users, item tiles stream, result d loss / d u
 // XU = false: lanes hold items, user tiles stream, result d loss / d v
 template <int D, bool XU>
-__global__ __launch_bounds__(64) void loss_bwd_dense_kernel(BwdParams p) {
+__global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using L = BwdLds<D, XU>;
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
-    const int64_t x = (int64_t)blockIdx.x * 32 + c;
+    const int wave = mf_wave_id();
+    const int64_t x0 = (int64_t)blockIdx.x * 128 + wave * 32;     // this wave's X tile
+    const int64_t x = x0 + c;
+    const int xt = (int)(x0 >> 5);
     const int64_t nX = XU ? p.B : p.N, nY = XU ? p.N : p.B;
     const int64_t Xp = XU ? p.Bp : p.Np;
     const float* X = XU ? p.u : p.v;
     const float* Y = XU ? p.v : p.u;
     const int t0 = blockIdx.y * p.tps, t1 = min(p.YT, t0 + p.tps);
-    RowFrag<D> xf;
-    mf_load_frag<D>(xf, X, x, x < nX);
-    // per-lane constants of the X row
-    float xa = 0.f, xb = 0.f, xc = 0.f, xd = 0.f, xn, xs = 0.f, xq = 0.f;
-    if (XU) {
-        xn = p.nu[x]; xs = p.sgn[x];
-        xa = p.rowc[x]; xb = p.rowc[p.Bp + x]; xc = p.rowc[2 * p.Bp + x]; xd = p.rowc[3 * p.Bp + x];
-    } else {
-        xn = p.nv[x]; xq = p.logq ? p.logq[x] : 0.f;
-    }
+    float xa = 0.f, xb = 0.f, xc = 0.f, xd = 0.f;
+    if (XU) { xa = p.rowc[x]; xb = p.rowc[p.Bp + x]; xc = p.rowc[2 * p.Bp + x]; xd = p.rowc[3 * p.Bp + x]; }
     f32x16 dacc[D / 32];
 #pragma unroll
     for (int mb = 0; mb < D / 32; ++mb)
@@ -596,45 +670,65 @@ __global__ __launch_bounds__(64) void loss_bwd_dense_kernel(BwdParams p) {
         for (int e = 0; e < 16; ++e) dacc[mb][e] = 0.f;
     float rsum = 0.f;
 
+    auto stage = [&](int t, int slot_idx) {
+        char* slot = smem + slot_idx * L::SLOT;
+        mf_stage_tile<D>(slot, Y, (int64_t)t * 32, nY);
+        const int64_t blk = XU ? ((int64_t)xt * p.NT + t) : ((int64_t)t * p.NT + xt);
+        const char* lsrc = reinterpret_cast<const char*>(p.stash + blk * 1024) + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((mf_glb_ptr)(lsrc + q * 1024),
+                                             (mf_lds_ptr)(slot + L::LT + wave * 4096 + q * 1024), 16, 0, 0);
+        const uint32_t* mw = XU ? p.maskW + (int64_t)t * p.Bp + x0 : p.maskTW + (int64_t)t * p.Np + x0;
+        mf_stage_small(slot + L::AUX + wave * 128, mw, 128);
+        if (!XU) mf_stage_small(slot + L::AUX + 512 + wave * 128, p.rowc + (int64_t)wave * p.Bp + (int64_t)t * 32, 128);
+    };
+    if (t0 < t1) stage(t0, 0);
+    if (t0 + 1 < t1) stage(t0 + 1, 1);
+    int cur = 0;
     for (int ty = t0; ty < t1; ++ty) {
+        if (ty + 1 < t1) mf_wait_vmcnt<L::NWAIT>(); else mf_wait_vmcnt<0>();
+        mf_block_barrier();
+        if (L::NSLOT == 3 && ty + 2 < t1) stage(ty + 2, cur >= 1 ? cur - 1 : 2);
+        const char* slot = smem + cur * L::SLOT;
+        const char* lt = slot + L::LT + wave * 4096;
         const int64_t y0 = (int64_t)ty * 32;
-        RowFrag<D> yf;
-        mf_load_frag<D>(yf, Y, y0 + c, y0 + c < nY);
-        const f32x16 acc = mf_tile_scores<D>(yf, xf);
-        const uint32_t mw = XU ? p.maskW[(int64_t)ty * p.Bp + x] : p.maskTW[(int64_t)ty * p.Np + x];
-        f32x4 yn4[4], yq4[4], ys4[4], ya4[4], yb4[4], yc4[4], yd4[4];
+        const uint32_t mw = reinterpret_cast<const uint32_t*>(slot + L::AUX + wave * 128)[c];
+        float Lv[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int64_t o = y0 + 8 * q + 4 * h;
-            if (XU) {
-                yn4[q] = *reinterpret_cast<const f32x4*>(p.nv + o);
-                yq4[q] = p.logq ? *reinterpret_cast<const f32x4*>(p.logq + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
-                yn4[q] = *reinterpret_cast<const f32x4*>(p.nu + o);
-                ys4[q] = *reinterpret_cast<const f32x4*>(p.sgn + o);
-                ya4[q] = *reinterpret_cast<const f32x4*>(p.rowc + o);
-                yb4[q] = *reinterpret_cast<const f32x4*>(p.rowc + p.Bp + o);
-                yc4[q] = *reinterpret_cast<const f32x4*>(p.rowc + 2 * p.Bp + o);
-                yd4[q] = *reinterpret_cast<const f32x4*>(p.rowc + 3 * p.Bp + o);
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(lt + q * 1024 + lane * 16);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Lv[4 * q + t] = t4[t];
+        }
+        f32x4 ya4[4], yb4[4], yc4[4], yd4[4];
+        if (!XU) {
+            // stash layout is (lane = user, register = item row): transpose to (lane = item, register = user row)
+            float* tr = reinterpret_cast<float*>(smem + L::TR) + wave * (33 * 32);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tr[mf_acc_row(e, h) * 33 + c] = Lv[e];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Lv[e] = tr[c * 33 + mf_acc_row(e, h)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const char* rc = slot + L::AUX + 512 + (8 * q + 4 * h) * 4;
+                ya4[q] = *reinterpret_cast<const f32x4*>(rc);
+                yb4[q] = *reinterpret_cast<const f32x4*>(rc + 128);
+                yc4[q] = *reinterpret_cast<const f32x4*>(rc + 256);
+                yd4[q] = *reinterpret_cast<const f32x4*>(rc + 384);
             }
         }
-        float G[16];
+        float Gv[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int q = e >> 2, t = e & 3;
             const int64_t y = y0 + mf_acc_row(e, h);
-            float L, a, b, cg, gd;
-            if (XU) {
-                L = mf_logit(xn, yn4[q][t], acc[e], xs, p.sigma, yq4[q][t]);
-                a = xa; b = xb; cg = xc; gd = xd;
-            } else {
-                L = mf_logit(yn4[q][t], xn, acc[e], ys4[q][t], p.sigma, xq);
-                a = ya4[q][t]; b = yb4[q][t]; cg = yc4[q][t]; gd = yd4[q][t];
-            }
-            float g = cg * g_of(p.gmode, (L - a) + b);
+            const float a = XU ? xa : ya4[q][t], b = XU ? xb : yb4[q][t];
+            const float cg = XU ? xc : yc4[q][t], gd = XU ? xd : yd4[q][t];
+            float g = cg * g_of(p.gmode, (Lv[e] - a) + b);
             if ((mw >> mf_acc_row(e, h)) & 1u) g = 0.f;
             if (x == y) g = gd;
-            G[e] = g;
+            Gv[e] = g;
             rsum += g;
         }
         // dX[m][x] += sum_y Y[y][m] * G[y][x]   (the G tile is already a B operand)
@@ -642,25 +736,30 @@ __global__ __launch_bounds__(64) void loss_bwd_dense_kernel(BwdParams p) {
         for (int mb = 0; mb < D / 32; ++mb) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                int64_t y = y0 + mf_acc_row(t, h);
-                y = y < nY ? y : 0;                      // G is 0 there (padding bit)
-                const float yv = Y[y * D + mb * 32 + c];
-                dacc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv, G[t], dacc[mb], 0, 0, 0);
+                const float yv = mf_lds_elem<D>(slot, mf_acc_row(t, h), mb * 32 + c);
+                dacc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv, Gv[t], dacc[mb], 0, 0, 0);
             }
         }
+        if (L::NSLOT == 2) {            // the slot just read is the one tile ty+2 lands in
+            mf_block_barrier();
+            if (ty + 2 < t1) stage(ty + 2, cur);
+        }
+        cur = cur + 1 == L::NSLOT ? 0 : cur + 1;
     }
     rsum += mf_shfl_xor32(rsum);
     // dX[x][m] = dacc - rsum * X[x][m];  register e of block mb is m = 8 (4 mb + (e>>2)) + 4 h + (e&3)
     if (x < nX) {
         float* o = p.dpart + ((int64_t)blockIdx.y * Xp + x) * D;
+        const f32x4* xr = reinterpret_cast<const f32x4*>(X + x * D + 4 * h);
 #pragma unroll
         for (int mb = 0; mb < D / 32; ++mb) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int g = 4 * mb + q;
+                const f32x4 xv = xr[2 * g];
                 f32x4 r;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) r[t] = dacc[mb][4 * q + t] - rsum * xf.v[g][t];
+                for (int t = 0; t < 4; ++t) r[t] = dacc[mb][4 * q + t] - rsum * xv[t];
                 *reinterpret_cast<f32x4*>(o + 8 * g + 4 * h) = r;
             }
         }
@@ -731,6 +830,10 @@ __global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ C ABI ------
+static void set_lds_limit(const void* fn, int bytes) {
+    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 static int check_loss_args(const char* what, int64_t B, int64_t N, int d, int P, int num_negatives,
                            const void* u, const void* v, const void* target, void* ws, size_t ws_bytes) {
     if (B <= 0 || N < B) return mf_set_error(MF_EINVAL, "%s: need 0 < B <= N (B=%lld N=%lld)", what, (long long)B, (long long)N);
@@ -751,12 +854,12 @@ static void launch_mining_select(const LossWs& w, const MiningPolicy::Params& mp
     dim3 grid((unsigned)w.BT, (unsigned)w.nchunk);
 #define MF_SEL(TT, CC) select_kernel<D, TT, CC, MiningPolicy><<<grid, 64, 0, s>>>(mp, sc)
     switch (w.T) {
-        case 2: MF_SEL(2, 64); break;
-        case 4: MF_SEL(4, 64); break;
-        case 8: MF_SEL(8, 64); break;
-        case 12: MF_SEL(12, 64); break;
-        case 16: MF_SEL(16, 128); break;
-        default: MF_SEL(32, 128); break;
+        case 2: MF_SEL(2, 40); break;
+        case 4: MF_SEL(4, 40); break;
+        case 8: MF_SEL(8, 40); break;
+        case 12: MF_SEL(12, 40); break;
+        case 16: MF_SEL(16, 48); break;
+        default: MF_SEL(32, 80); break;
     }
 #undef MF_SEL
 }
@@ -781,19 +884,17 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     diag_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(u, v, target, logq, w.nu, w.nv, B, w.Bp, d, sigma,
                                                                      w.lii, w.dii, w.sgn);
     if (scores_needed) {
-        (void)hipMemsetAsync(w.htab, 0x80, (size_t)w.Bp * w.slots * 8, s);
+        (void)hipMemsetAsync(w.gtab, 0x80, (size_t)w.M * 8, s);
+        (void)hipMemsetAsync(w.ubits, 0, (size_t)(w.M / 32) * w.Bp * 4, s);
+        gt_insert_kernel<<<dim3((unsigned)((N + 255) / 256)), 256, 0, s>>>(item_idx, N, w.M, w.gtab, w.colslot);
         const int64_t nthreads = B * (P + 1);
-        ht_insert_kernel<<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(item_idx, pos_idx, B, P, w.slots, w.htab);
+        ubits_kernel<<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(item_idx, pos_idx, B, P, w.M, w.gtab, w.Bp, w.ubits);
         int gy = (w.NT + 7) / 8;
         if (gy > 16) gy = 16;
         if (gy * w.BT < 1024) gy = (1024 + w.BT - 1) / w.BT;   // enough blocks when B is small
         if (gy > (w.NT + 7) / 8) gy = (w.NT + 7) / 8;
-        if (w.slots <= 256)
-            mask_sweep_kernel<true><<<dim3((unsigned)w.BT, (unsigned)gy), 256, (size_t)32 * w.slots * 8, s>>>(
-                item_idx, w.htab, w.slots, B, N, w.Bp, w.Np, w.NT, w.maskW, w.maskTW);
-        else
-            mask_sweep_kernel<false><<<dim3((unsigned)w.BT, (unsigned)gy), 256, 0, s>>>(
-                item_idx, w.htab, w.slots, B, N, w.Bp, w.Np, w.NT, w.maskW, w.maskTW);
+        mask_sweep_kernel<<<dim3((unsigned)w.BT, (unsigned)gy), 256, 0, s>>>(w.colslot, w.ubits, B, N, w.Bp, w.Np, w.NT,
+                                                                            w.maskW, w.maskTW);
     }
     // logq is read by whole float4s up to the padded width: keep a zero-padded copy in ws
     const float* logq_p = nullptr;
@@ -803,14 +904,15 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
         logq_p = w.logq;
     }
     if (scores_needed && !w.mined) {
-        FwdParams fp{u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.part, B, N, w.Bp, w.NT, w.tps_f, need, sigma, margin};
+        FwdParams fp{u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.part, w.stash, B, N, w.Bp, w.NT, w.tps_f, need, sigma, margin};
         MF_DISPATCH_D(d, {
-            dim3 grid((unsigned)w.BT, (unsigned)w.nsplit_f);
-            MF_TIMED("loss_fwd_dense", s, loss_fwd_dense_kernel<D><<<grid, 64, 0, s>>>(fp));
+            dim3 grid((unsigned)(w.BT / 4), (unsigned)w.nsplit_f);
+            set_lds_limit((const void*)loss_fwd_dense_kernel<D>, FwdLds<D>::BYTES);
+            MF_TIMED("loss_fwd_dense", s, (loss_fwd_dense_kernel<D><<<grid, 256, FwdLds<D>::BYTES, s>>>(fp)));
         });
         stats_merge_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(w.part, w.nsplit_f, w.Bp, w.stats);
         if (out_mask_bits)
-            mask_export_dense_kernel<<<dim3((unsigned)((B * w.NT + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, w.NT, out_mask_bits);
+            mask_export_dense_kernel<<<dim3((unsigned)((B * ((N + 31) / 32) + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, (int)((N + 31) / 32), out_mask_bits);
     } else if (scores_needed) {
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
         SelectCommon sc{u, B, v, N, w.NT, w.tpc, w.Bp, num_negatives, w.cand, w.cand_cnt};
@@ -821,8 +923,8 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
                                                                                 w.sel_cnt, B, w.Bp, d, sigma, margin, need,
                                                                                 w.sel_L, w.stats);
         if (out_mask_bits) {
-            (void)hipMemsetAsync(out_mask_bits, 0, (size_t)B * w.NT * 4, s);
-            mask_export_mined_kernel<<<dim3((unsigned)((B + 255) / 256)), 256, 0, s>>>(w.sel, w.sel_cnt, B, w.NT, out_mask_bits);
+            (void)hipMemsetAsync(out_mask_bits, 0, (size_t)B * ((N + 31) / 32) * 4, s);
+            mask_export_mined_kernel<<<dim3((unsigned)((B + 255) / 256)), 256, 0, s>>>(w.sel, w.sel_cnt, B, (int)((N + 31) / 32), out_mask_bits);
         }
     } else {
         (void)hipMemsetAsync(w.stats, 0, (size_t)NSTAT * w.Bp * 4, s);
@@ -858,13 +960,15 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
                                                                                         w.Bp, gmode, du, dv);
         });
     } else {
-        BwdParams bp{u, v, w.nu, w.nv, w.sgn, logq ? w.logq : nullptr, w.rowc, w.maskW, w.maskTW, w.dpart, B, N, w.Bp, w.Np, 0, 0, gmode, sigma};
+        BwdParams bp{u, v, w.rowc, w.stash, w.maskW, w.maskTW, w.dpart, B, N, w.Bp, w.Np, w.NT, 0, 0, gmode};
         MF_DISPATCH_D(d, {
+            set_lds_limit((const void*)loss_bwd_dense_kernel<D, true>, BwdLds<D, true>::BYTES);
+            set_lds_limit((const void*)loss_bwd_dense_kernel<D, false>, BwdLds<D, false>::BYTES);
             bp.YT = w.NT; bp.tps = w.tps_u;
-            MF_TIMED("loss_bwd_du", s, (loss_bwd_dense_kernel<D, true><<<dim3((unsigned)w.BT, (unsigned)w.nsplit_u), 64, 0, s>>>(bp)));
+            MF_TIMED("loss_bwd_du", s, (loss_bwd_dense_kernel<D, true><<<dim3((unsigned)(w.BT / 4), (unsigned)w.nsplit_u), 256, BwdLds<D, true>::BYTES, s>>>(bp)));
             sum_parts_kernel<<<dim3((unsigned)((B * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_u, B, w.Bp, D, du);
             bp.YT = w.BT; bp.tps = w.tps_v;
-            MF_TIMED("loss_bwd_dv", s, (loss_bwd_dense_kernel<D, false><<<dim3((unsigned)w.NT, (unsigned)w.nsplit_v), 64, 0, s>>>(bp)));
+            MF_TIMED("loss_bwd_dv", s, (loss_bwd_dense_kernel<D, false><<<dim3((unsigned)(w.NT / 4), (unsigned)w.nsplit_v), 256, BwdLds<D, false>::BYTES, s>>>(bp)));
             sum_parts_kernel<<<dim3((unsigned)((N * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_v, N, w.Np, D, dv);
         });
     }

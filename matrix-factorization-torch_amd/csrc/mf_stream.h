@@ -1,0 +1,101 @@
+// mf_stream.h -- LDS-staged tile streaming for the score engines (gfx950).
+//
+// A 256-thread workgroup (4 wavefronts, each owning 32 "X" rows in registers) walks
+// a range of 32-row "Y" tiles.  Every tile is brought from HBM/L2 into LDS ONCE per
+// workgroup by LDS-DMA (global_load_lds_dwordx4: whole 1 KiB pieces, full cache
+// lines, no VGPR staging) into a 3-deep ring, two tiles ahead of the MFMAs, with a
+// counted s_waitcnt vmcnt(N) and ONE raw s_barrier per tile:
+//
+//     wait(tile t landed)  ->  barrier  ->  issue DMA of tile t+2  ->  compute tile t
+//
+// (the barrier also proves every wave has finished tile t-1, whose slot tile t+2
+// overwrites).  The small per-tile side inputs (mask words, norms, logQ, per-row
+// coefficients) travel the same way, so the loop contains no VGPR-destination global
+// load that would make hipcc drain the DMA queue (cdna_hip_programming.md 5, "Three
+// .s-level traps" (b)).
+//
+// LDS image of a tile: [32 rows][D floats], linear for the DMA, with the 16-byte
+// chunks of a row XOR-swizzled on the SOURCE address (rule 21) so that
+//   * the MFMA A-fragment read (lane = row, ds_read_b128 of chunk 2g+h) and
+//   * the transposed read of the backward (lane = column, ds_read_b32 along a row)
+// are both bank-conflict-free.
+#pragma once
+
+#include "mf_common.h"
+
+#ifdef __HIPCC__
+
+typedef __attribute__((address_space(3))) void* mf_lds_ptr;
+typedef const __attribute__((address_space(1))) void* mf_glb_ptr;
+
+template <int D>
+struct TileGeom {
+    static constexpr int ROWB = D * 4;            // bytes per row
+    static constexpr int TILEB = 32 * ROWB;       // bytes per tile
+    static constexpr int CPR = D / 4;             // 16-byte chunks per row
+    static constexpr int PIECES = TILEB / 1024;   // 1 KiB DMA pieces per tile (D / 8)
+    static constexpr int PPW = PIECES / 4;        // pieces per wave
+    static __device__ __forceinline__ int swz(int row) { return CPR >= 16 ? (row & 15) : ((row >> 1) & 7); }
+};
+
+__device__ __forceinline__ int mf_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// DMA one tile (rows y0 .. y0+31 of Y, rows past nY clamped to the last row) into `lds_tile`.
+template <int D>
+__device__ __forceinline__ void mf_stage_tile(char* lds_tile, const float* __restrict__ Y, int64_t y0, int64_t nY) {
+    using G = TileGeom<D>;
+    const int lane = mf_lane();
+    const int wave = mf_wave_id();
+#pragma unroll
+    for (int q = 0; q < G::PPW; ++q) {
+        const int p = wave * G::PPW + q;
+        const int off = p * 1024 + lane * 16;
+        const int row = off / G::ROWB;
+        const int chp = (off % G::ROWB) >> 4;
+        const int ch = chp ^ G::swz(row);
+        int64_t y = y0 + row;
+        y = y < nY ? y : nY - 1;
+        const char* src = reinterpret_cast<const char*>(Y + y * D) + ch * 16;
+        __builtin_amdgcn_global_load_lds((mf_glb_ptr)src, (mf_lds_ptr)(lds_tile + p * 1024), 16, 0, 0);
+    }
+}
+
+// DMA `nbytes` (multiple of 16, <= 1024) from src to lds_dst by the calling wave.
+__device__ __forceinline__ void mf_stage_small(char* lds_dst, const void* src, int nbytes) {
+    const int lane = mf_lane();
+    if (lane * 16 < nbytes)
+        __builtin_amdgcn_global_load_lds((mf_glb_ptr)(reinterpret_cast<const char*>(src) + lane * 16),
+                                         (mf_lds_ptr)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void mf_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void mf_block_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the previous tile have returned
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// MFMA A-fragment of the staged tile: lane (row r = lane & 31, half h) gets chunks 2g + h.
+template <int D>
+__device__ __forceinline__ void mf_lds_frag(RowFrag<D>& f, const char* lds_tile) {
+    using G = TileGeom<D>;
+    const int lane = mf_lane(), r = lane & 31, h = lane >> 5;
+    const char* rowp = lds_tile + r * G::ROWB;
+    const int sw = G::swz(r);
+#pragma unroll
+    for (int g = 0; g < D / 8; ++g)
+        f.v[g] = *reinterpret_cast<const f32x4*>(rowp + (((2 * g + h) ^ sw) << 4));
+}
+
+// element [row][m] of the staged tile (transposed operand of the backward)
+template <int D>
+__device__ __forceinline__ float mf_lds_elem(const char* lds_tile, int row, int m) {
+    using G = TileGeom<D>;
+    return *reinterpret_cast<const float*>(lds_tile + row * G::ROWB + ((((m >> 2) ^ G::swz(row)) << 4) | ((m & 3) << 2)));
+}
+
+#endif  // __HIPCC__

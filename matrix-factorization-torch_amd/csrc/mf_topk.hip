@@ -32,7 +32,6 @@ struct RetrievalPolicy {
         if ((t.ew >> mf_acc_row(e, h)) & 1u) return 0ull;
         return y < p.nY ? mf_key_retrieval(score, (unsigned)y) : 0ull;
     }
-    static __device__ __forceinline__ bool excluded(const Params&, const Row&, int64_t) { return false; }
 };
 
 __global__ __launch_bounds__(256) void excl_scatter_kernel(const int64_t* __restrict__ excl_off,
@@ -59,8 +58,9 @@ static TopkWs topk_ws(void* base, int64_t Q, int64_t N, int k) {
     w.Qp = mf_pad32(Q);
     w.QT = (int)(w.Qp / 32);
     w.NT = (int)(mf_pad32(N) / 32);
-    w.T = k <= 4 ? 2 : k <= 8 ? 4 : k <= 16 ? 8 : k <= 24 ? 12 : k <= 32 ? 16 : 32;
-    w.CAP = k <= 24 ? 64 : 128;
+    int capl;
+    mf_select_geometry(k, &w.T, &capl);
+    w.CAP = 2 * capl;
     int maxchunk = (64 * 1024) / (w.CAP * 8);
     int want = (2048 + w.QT - 1) / w.QT;
     if (want > maxchunk) want = maxchunk;
@@ -140,12 +140,12 @@ static void launch_topk_select(const TopkWs& w, const RetrievalPolicy::Params& r
     dim3 grid((unsigned)w.QT, (unsigned)w.nchunk);
 #define MF_SEL(TT, CC) select_kernel<D, TT, CC, RetrievalPolicy><<<grid, 64, 0, s>>>(rp, sc)
     switch (w.T) {
-        case 2: MF_SEL(2, 64); break;
-        case 4: MF_SEL(4, 64); break;
-        case 8: MF_SEL(8, 64); break;
-        case 12: MF_SEL(12, 64); break;
-        case 16: MF_SEL(16, 128); break;
-        default: MF_SEL(32, 128); break;
+        case 2: MF_SEL(2, 40); break;
+        case 4: MF_SEL(4, 40); break;
+        case 8: MF_SEL(8, 40); break;
+        case 12: MF_SEL(12, 40); break;
+        case 16: MF_SEL(16, 48); break;
+        default: MF_SEL(32, 80); break;
     }
 #undef MF_SEL
 }
