@@ -647,7 +647,7 @@ struct BwdLds {
 
 // XU = true : lanes hold users, item tiles stream, result d loss / d u
 // XU = false: lanes hold items, user tiles stream, result d loss / d v
-template <int D, bool XU>
+template <int D, bool XU, int GMODE>
 __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using L = BwdLds<D, XU>;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
             const int64_t y = y0 + mf_acc_row(e, h);
             const float a = XU ? xa : ya4[q][t], b = XU ? xb : yb4[q][t];
             const float cg = XU ? xc : yc4[q][t], gd = XU ? xd : yd4[q][t];
-            float g = cg * g_of(p.gmode, (Lv[e] - a) + b);
+            float g = cg * g_of(GMODE, (Lv[e] - a) + b);
             if ((mw >> mf_acc_row(e, h)) & 1u) g = 0.f;
             if (x == y) g = gd;
             Gv[e] = g;
@@ -733,12 +733,12 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
         }
         // dX[m][x] += sum_y Y[y][m] * G[y][x]   (the G tile is already a B operand)
 #pragma unroll
-        for (int mb = 0; mb < D / 32; ++mb) {
+        for (int t = 0; t < 16; ++t) {
+            float yv[D / 32];
+            mf_lds_cols<D>(yv, slot, mf_acc_row(t, h), c);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float yv = mf_lds_elem<D>(slot, mf_acc_row(t, h), mb * 32 + c);
-                dacc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv, Gv[t], dacc[mb], 0, 0, 0);
-            }
+            for (int j = 0; j < D / 32; ++j)
+                dacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv[j], Gv[t], dacc[j], 0, 0, 0);
         }
         if (L::NSLOT == 2) {            // the slot just read is the one tile ty+2 lands in
             mf_block_barrier();
@@ -747,21 +747,16 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
         cur = cur + 1 == L::NSLOT ? 0 : cur + 1;
     }
     rsum += mf_shfl_xor32(rsum);
-    // dX[x][m] = dacc - rsum * X[x][m];  register e of block mb is m = 8 (4 mb + (e>>2)) + 4 h + (e&3)
+    // dX[x][m] = dacc - rsum * X[x][m];  register e of block j is feature m = NB * row(e, h) + j
     if (x < nX) {
+        constexpr int NB = D / 32;
         float* o = p.dpart + ((int64_t)blockIdx.y * Xp + x) * D;
-        const f32x4* xr = reinterpret_cast<const f32x4*>(X + x * D + 4 * h);
+        const float* xr = X + x * D;
 #pragma unroll
-        for (int mb = 0; mb < D / 32; ++mb) {
+        for (int e = 0; e < 16; ++e) {
+            const int m0 = NB * mf_acc_row(e, h);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int g = 4 * mb + q;
-                const f32x4 xv = xr[2 * g];
-                f32x4 r;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) r[t] = dacc[mb][4 * q + t] - rsum * xv[t];
-                *reinterpret_cast<f32x4*>(o + 8 * g + 4 * h) = r;
-            }
+            for (int j = 0; j < NB; ++j) o[m0 + j] = dacc[j][e] - rsum * xr[m0 + j];
         }
     }
 }
@@ -830,8 +825,25 @@ __global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ C ABI ------
+template <int D, bool XU>
+static void launch_bwd(int gmode, dim3 grid, const BwdParams& bp, hipStream_t s);
+
 static void set_lds_limit(const void* fn, int bytes) {
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int D, bool XU, int GMODE>
+static void launch_bwd_g(dim3 grid, const BwdParams& bp, hipStream_t s) {
+    auto fn = loss_bwd_dense_kernel<D, XU, GMODE>;
+    if (BwdLds<D, XU>::BYTES > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, BwdLds<D, XU>::BYTES);
+    fn<<<grid, 256, BwdLds<D, XU>::BYTES, s>>>(bp);
+}
+template <int D, bool XU>
+static void launch_bwd(int gmode, dim3 grid, const BwdParams& bp, hipStream_t s) {
+    if (gmode == G_EXP) launch_bwd_g<D, XU, G_EXP>(grid, bp, s);
+    else if (gmode == G_STEP) launch_bwd_g<D, XU, G_STEP>(grid, bp, s);
+    else launch_bwd_g<D, XU, G_SIGM>(grid, bp, s);
 }
 
 static int check_loss_args(const char* what, int64_t B, int64_t N, int d, int P, int num_negatives,
@@ -962,13 +974,11 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
     } else {
         BwdParams bp{u, v, w.rowc, w.stash, w.maskW, w.maskTW, w.dpart, B, N, w.Bp, w.Np, w.NT, 0, 0, gmode};
         MF_DISPATCH_D(d, {
-            set_lds_limit((const void*)loss_bwd_dense_kernel<D, true>, BwdLds<D, true>::BYTES);
-            set_lds_limit((const void*)loss_bwd_dense_kernel<D, false>, BwdLds<D, false>::BYTES);
             bp.YT = w.NT; bp.tps = w.tps_u;
-            MF_TIMED("loss_bwd_du", s, (loss_bwd_dense_kernel<D, true><<<dim3((unsigned)(w.BT / 4), (unsigned)w.nsplit_u), 256, BwdLds<D, true>::BYTES, s>>>(bp)));
+            MF_TIMED("loss_bwd_du", s, (launch_bwd<D, true>(gmode, dim3((unsigned)(w.BT / 4), (unsigned)w.nsplit_u), bp, s)));
             sum_parts_kernel<<<dim3((unsigned)((B * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_u, B, w.Bp, D, du);
             bp.YT = w.BT; bp.tps = w.tps_v;
-            MF_TIMED("loss_bwd_dv", s, (loss_bwd_dense_kernel<D, false><<<dim3((unsigned)(w.NT / 4), (unsigned)w.nsplit_v), 256, BwdLds<D, false>::BYTES, s>>>(bp)));
+            MF_TIMED("loss_bwd_dv", s, (launch_bwd<D, false>(gmode, dim3((unsigned)(w.NT / 4), (unsigned)w.nsplit_v), bp, s)));
             sum_parts_kernel<<<dim3((unsigned)((N * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_v, N, w.Np, D, dv);
         });
     }

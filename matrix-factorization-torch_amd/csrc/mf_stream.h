@@ -91,11 +91,29 @@ __device__ __forceinline__ void mf_lds_frag(RowFrag<D>& f, const char* lds_tile)
         f.v[g] = *reinterpret_cast<const f32x4*>(rowp + (((2 * g + h) ^ sw) << 4));
 }
 
-// element [row][m] of the staged tile (transposed operand of the backward)
+// Transposed operand of the backward: lane c gets the D/32 consecutive floats
+// [NB c, NB c + NB) of `row` (NB = D / 32) in one wide LDS read; v[j] is the A operand
+// of accumulator block j, whose MFMA row index r then stands for feature NB r + j.
 template <int D>
-__device__ __forceinline__ float mf_lds_elem(const char* lds_tile, int row, int m) {
+__device__ __forceinline__ void mf_lds_cols(float (&v)[D / 32], const char* lds_tile, int row, int c) {
     using G = TileGeom<D>;
-    return *reinterpret_cast<const float*>(lds_tile + row * G::ROWB + ((((m >> 2) ^ G::swz(row)) << 4) | ((m & 3) << 2)));
+    const char* rowp = lds_tile + row * G::ROWB;
+    const int sw = G::swz(row);
+    if (D == 128) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(rowp + ((c ^ sw) << 4));
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else if (D == 256) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(rowp + (((2 * c) ^ sw) << 4));
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(rowp + (((2 * c + 1) ^ sw) << 4));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = t0[j]; v[4 + j] = t1[j]; }
+    } else if (D == 64) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 t = *reinterpret_cast<const f32x2*>(rowp + ((((c >> 1) ^ sw) << 4) | ((c & 1) << 3)));
+        v[0] = t[0]; v[1] = t[1];
+    } else {
+        v[0] = *reinterpret_cast<const float*>(rowp + ((((c >> 2) ^ sw) << 4) | ((c & 3) << 2)));
+    }
 }
 
 #endif  // __HIPCC__
