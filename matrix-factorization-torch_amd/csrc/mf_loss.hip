@@ -43,7 +43,8 @@ struct LossWs {
     int nsplit_f, tps_f;          // dense fwd: item-range splits
     int nsplit_u, tps_u;          // dU pass: item-range splits
     int nsplit_v, tps_v;          // dV pass: user-range splits
-    int T, CAP, nchunk, tpc;      // mining select geometry
+    int T, CAP, nchunk, tpc;      // mining select geometry (nchunk = candidate sets per row)
+    SelectPlan plan;
     float *nu, *nv, *lii, *dii, *sgn, *logq;
     long long* gtab;
     int M;
@@ -77,20 +78,8 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     split_geometry(w.BT / 4, w.NT, &w.nsplit_u, &w.tps_u, 256);
     split_geometry(w.NT / 4, w.BT, &w.nsplit_v, &w.tps_v, 256);
     const int k = num_negatives;
-    {
-        int capl;
-        mf_select_geometry(k, &w.T, &capl);
-        w.CAP = 2 * capl;
-    }
-    {
-        int maxchunk = (64 * 1024) / (w.CAP * 8);
-        int want = (2048 + w.BT - 1) / w.BT;
-        if (want > maxchunk) want = maxchunk;
-        if (want > w.NT) want = w.NT;
-        if (want < 1) want = 1;
-        w.tpc = (w.NT + want - 1) / want;
-        w.nchunk = (w.NT + w.tpc - 1) / w.tpc;
-    }
+    w.plan = mf_select_plan(B, N, d, k);
+    w.T = w.plan.T; w.CAP = w.plan.CAP; w.nchunk = w.plan.nsets; w.tpc = w.plan.tpc;
     MfArena a(base);
     w.nu = a.take<float>(w.Bp); w.nv = a.take<float>(w.Np);
     w.lii = a.take<float>(w.Bp); w.dii = a.take<float>(w.Bp); w.sgn = a.take<float>(w.Bp);
@@ -478,17 +467,22 @@ struct MiningPolicy {
         uint32_t mw;
         f32x4 nv4[4], lq4[4];
     };
+    static constexpr int AUX_DMA = 2;
+    static __device__ __forceinline__ void stage_aux(const Params& p, char* aux, int wave, int t, int64_t x0) {
+        mf_stage_small(aux + wave * 128, p.maskW + (int64_t)t * p.Bp + x0, 128);
+        const float* src = (wave == 1 && p.logq) ? p.logq : p.nv;
+        mf_stage_small(aux + 512 + wave * 128, src + (int64_t)t * 32, 128);   // 512: nv, 640: logq, rest: padding
+    }
     static __device__ __forceinline__ Row row_init(const Params& p, int64_t x, bool) {
         return Row{p.nu[x], p.sgn[x], p.lii[x]};
     }
-    static __device__ __forceinline__ Tile tile_init(const Params& p, const Row&, int64_t y0, int64_t x) {
+    static __device__ __forceinline__ Tile tile_init(const Params& p, const Row&, const char* aux, int wave, int c, int h) {
         Tile t;
-        const int h = mf_lane() >> 5;
-        t.mw = p.maskW[(y0 >> 5) * p.Bp + x];
+        t.mw = reinterpret_cast<const uint32_t*>(aux + wave * 128)[c];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            t.nv4[q] = *reinterpret_cast<const f32x4*>(p.nv + y0 + 8 * q + 4 * h);
-            t.lq4[q] = p.logq ? *reinterpret_cast<const f32x4*>(p.logq + y0 + 8 * q + 4 * h)
+            t.nv4[q] = *reinterpret_cast<const f32x4*>(aux + 512 + (8 * q + 4 * h) * 4);
+            t.lq4[q] = p.logq ? *reinterpret_cast<const f32x4*>(aux + 640 + (8 * q + 4 * h) * 4)
                               : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         return t;
@@ -852,28 +846,34 @@ static int check_loss_args(const char* what, int64_t B, int64_t N, int d, int P,
     if (!mf_width_ok(d)) return mf_set_error(MF_EINVAL, "%s: embedding width %d not in {32,64,128,256}", what, d);
     if (P < 0 || !u || !v || !target || !ws) return mf_set_error(MF_EINVAL, "%s: bad argument", what);
     if (N >= (1 << 24)) return mf_set_error(MF_ENOTSUP, "%s: N >= 2^24", what);
-    if (mining_on(num_negatives, N) && num_negatives > KSEL_MAX)
-        return mf_set_error(MF_ENOTSUP, "%s: mining with num_negatives = %d > %d", what, num_negatives, KSEL_MAX);
+    if (mining_on(num_negatives, N) && (num_negatives > KSEL_MAX || !mf_select_plan(B, N, d, num_negatives).ok))
+        return mf_set_error(MF_ENOTSUP, "%s: mining with num_negatives = %d unsupported (max %d; 32 at d = 256)", what,
+                            num_negatives, KSEL_MAX);
     if (ws_bytes < mf_loss_ws_bytes(B, N, d, P, num_negatives))
         return mf_set_error(MF_ENOSPC, "%s: workspace too small (%zu < %zu)", what, ws_bytes,
                             mf_loss_ws_bytes(B, N, d, P, num_negatives));
     return MF_OK;
 }
 
+template <int D, int T>
+static void launch_mining_select_t(const LossWs& w, const MiningPolicy::Params& mp, const SelectCommon& sc, hipStream_t s) {
+    auto fn = select_kernel<D, T, MiningPolicy>;
+    const int bytes = SelectLds<D>::bytes(sc.capl);
+    (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    fn<<<dim3((unsigned)w.plan.gx, (unsigned)w.plan.nchunk), 256, bytes, s>>>(mp, sc);
+}
 template <int D>
 static void launch_mining_select(const LossWs& w, const MiningPolicy::Params& mp, const SelectCommon& sc,
                                  hipStream_t s) {
-    dim3 grid((unsigned)w.BT, (unsigned)w.nchunk);
-#define MF_SEL(TT, CC) select_kernel<D, TT, CC, MiningPolicy><<<grid, 64, 0, s>>>(mp, sc)
     switch (w.T) {
-        case 2: MF_SEL(2, 40); break;
-        case 4: MF_SEL(4, 40); break;
-        case 8: MF_SEL(8, 40); break;
-        case 12: MF_SEL(12, 40); break;
-        case 16: MF_SEL(16, 48); break;
-        default: MF_SEL(32, 80); break;
+        case 2: launch_mining_select_t<D, 2>(w, mp, sc, s); break;
+        case 4: launch_mining_select_t<D, 4>(w, mp, sc, s); break;
+        case 8: launch_mining_select_t<D, 8>(w, mp, sc, s); break;
+        case 10: launch_mining_select_t<D, 10>(w, mp, sc, s); break;
+        case 12: launch_mining_select_t<D, 12>(w, mp, sc, s); break;
+        case 16: launch_mining_select_t<D, 16>(w, mp, sc, s); break;
+        default: launch_mining_select_t<D, 32>(w, mp, sc, s); break;
     }
-#undef MF_SEL
 }
 
 extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
@@ -927,7 +927,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
             mask_export_dense_kernel<<<dim3((unsigned)((B * ((N + 31) / 32) + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, (int)((N + 31) / 32), out_mask_bits);
     } else if (scores_needed) {
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
-        SelectCommon sc{u, B, v, N, w.NT, w.tpc, w.Bp, num_negatives, w.cand, w.cand_cnt};
+        SelectCommon sc{u, B, v, N, (int)((N + 31) / 32), w.tpc, w.Bp, num_negatives, w.plan.xw, w.plan.CAPL, w.cand, w.cand_cnt};
         MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, launch_mining_select<D>(w, mp, sc, s)); });
         mined_merge_kernel<<<dim3((unsigned)B), 64, (size_t)w.nchunk * w.CAP * 8, s>>>(w.cand, w.cand_cnt, w.nchunk, w.Bp, w.CAP,
                                                                                       num_negatives, w.sel, w.sel_cnt);

@@ -26,13 +26,21 @@
 
 #include "mf_common.h"
 
-// (T, CAPL) by k: CAPL >= 2 T + 16 so that a filtered segment always has room for a tile
-static inline void mf_select_geometry(int k, int* T, int* CAPL) {
-    *T = k <= 4 ? 2 : k <= 8 ? 4 : k <= 16 ? 8 : k <= 24 ? 12 : k <= 32 ? 16 : 32;
-    *CAPL = *T <= 12 ? 40 : *T == 16 ? 48 : 80;
+// T = per-lane register list length (>= ceil(k / 2)); CAPL = per-lane LDS segment capacity: as
+// large as the 160 KiB of LDS allow next to the tile ring (a segment is re-filtered only when it
+// could overflow on the next tile, so a roomy segment means almost never).
+static inline int mf_select_T(int k) { return k <= 4 ? 2 : k <= 8 ? 4 : k <= 16 ? 8 : k <= 20 ? 10 : k <= 24 ? 12 : k <= 32 ? 16 : 32; }
+static inline int mf_select_nslot(int d) { return d == 256 ? 2 : 3; }
+static inline int mf_select_capl(int d) {
+    const int ring = mf_select_nslot(d) * (32 * d * 4 + 1024);
+    int capl = (160 * 1024 - ring - 1024) / (4 * 64 * 8) - 1;
+    capl = capl > 64 ? 64 : capl;
+    return capl & ~1;        // even capacity -> odd segment stride: lanes of a half hit distinct banks
 }
 
 #ifdef __HIPCC__
+
+#include "mf_stream.h"
 
 struct SelectCommon {
     const float* X;      // [nX, D] rows kept on the lanes
@@ -41,10 +49,13 @@ struct SelectCommon {
     int64_t nY;
     int YT;              // number of 32-row Y tiles
     int tiles_per_chunk;
-    int64_t Xp;          // nX padded to 32
+    int64_t Xp;          // nX padded to 128
     int k;
-    unsigned long long* cand;   // [nchunk][Xp][2 CAPL]
-    int32_t* cand_cnt;          // [nchunk][Xp]
+    int xw;              // X tiles per workgroup (1, 2 or 4); the 4 / xw waves that share an X tile
+                         // deal the chunk's Y tiles round-robin and emit separate candidate sets
+    int capl;            // per-lane LDS segment capacity
+    unsigned long long* cand;   // [nchunk * 4 / xw][Xp][2 capl]
+    int32_t* cand_cnt;          // [nchunk * 4 / xw][Xp]
 };
 
 template <int T>
@@ -59,23 +70,47 @@ __device__ __forceinline__ void mf_tlist_insert(unsigned (&tl)[T], unsigned rank
     }
 }
 
+__device__ __forceinline__ void mf_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int D>
+struct SelectLds {
+    using G = TileGeom<D>;
+    static constexpr int AUXB = 1024;                    // [4 x 128 B per-wave words][nv 128][logq 128][pad]
+    static constexpr int SLOT = G::TILEB + AUXB;
+    static constexpr int NSLOT = D == 256 ? 2 : 3;       // d = 256: 2-deep ring, 2 barriers per tile
+    static constexpr int RING = NSLOT * SLOT;
+    static __host__ __device__ int seg(int capl) { return 64 * (capl + 1) * 8; }   // one wave's 64 lane-private segments
+    static __host__ __device__ int bytes(int capl) { return RING + 4 * seg(capl) + 4 * 32 * 8; }
+};
+
 // Policy interface:
-//   struct Params;                         kernel-argument block
-//   struct Row;                            per-lane state of X row x
-//   struct Tile;                           per-lane state of the current Y tile
+//   struct Params;  struct Row;  struct Tile;
+//   static constexpr int AUX_DMA;                   DMA instructions per wave per stage for side inputs
+//   static void stage_aux(P, aux, wave, t, x0)      issue them (side inputs of Y tile t for X rows x0..x0+31)
 //   static Row  row_init(P, x, valid)
-//   static Tile tile_init(P, row, y0, x)
+//   static Tile tile_init(P, row, aux, wave, c, h)  read the staged side inputs
 //   static u64  key(P, row, tile, score, e, h, y)   0 = never a candidate
-template <int D, int T, int CAPL, class Policy>
-__global__ __launch_bounds__(64) void select_kernel(typename Policy::Params pp, SelectCommon sc) {
-    __shared__ unsigned long long buf[64][CAPL + 1];   // +1: the 32 lanes of a half hit distinct banks
-    __shared__ unsigned long long floor64[32];
+template <int D, int T, class Policy>
+__global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp, SelectCommon sc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = TileGeom<D>;
+    using L = SelectLds<D>;
+    constexpr int NWAIT = G::PPW + Policy::AUX_DMA;
+    const int CAPL = sc.capl;
 
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
-    const int64_t x = (int64_t)blockIdx.x * 32 + c;
+    const int wave = mf_wave_id();
+    const int nsub = 4 / sc.xw;
+    const int sub = wave / sc.xw;
+    const int64_t x0 = ((int64_t)blockIdx.x * sc.xw + (wave % sc.xw)) * 32;
+    const int64_t x = x0 + c;
     const int chunk = blockIdx.y;
     const int t0 = chunk * sc.tiles_per_chunk;
     const int t1 = min(sc.YT, t0 + sc.tiles_per_chunk);
+
+    unsigned long long* buf = reinterpret_cast<unsigned long long*>(smem + L::RING + wave * L::seg(CAPL));
+    unsigned long long* floor64 = reinterpret_cast<unsigned long long*>(smem + L::RING + 4 * L::seg(CAPL)) + wave * 32;
+#define MF_BUF(l, i) buf[(l) * (CAPL + 1) + (i)]
 
     RowFrag<D> xf;
     mf_load_frag<D>(xf, sc.X, x, x < sc.nX);
@@ -88,28 +123,43 @@ __global__ __launch_bounds__(64) void select_kernel(typename Policy::Params pp, 
     unsigned long long fl = 0ull;
     int cnt = 0;
     if (lane < 32) floor64[lane] = 0ull;
-    __syncthreads();
 
+    auto stage = [&](int t, int slot_idx) {
+        char* slot = smem + slot_idx * L::SLOT;
+        mf_stage_tile<D>(slot, sc.Y, (int64_t)t * 32, sc.nY);
+        Policy::stage_aux(pp, slot + G::TILEB, wave, t, x0);
+    };
+    if (t0 < t1) stage(t0, 0);
+    if (t0 + 1 < t1) stage(t0 + 1, 1);
+    int cur = 0;
     for (int ty = t0; ty < t1; ++ty) {
+        if (ty + 1 < t1) mf_wait_vmcnt<NWAIT>(); else mf_wait_vmcnt<0>();
+        mf_block_barrier();
+        if (L::NSLOT == 3 && ty + 2 < t1) stage(ty + 2, cur >= 1 ? cur - 1 : 2);
+        const char* slot = smem + cur * L::SLOT;
+        const int cur_slot = cur;
+        cur = cur + 1 == L::NSLOT ? 0 : cur + 1;
+        if ((ty - t0) % nsub == sub) {                  // else another wave of this X tile takes this Y tile
+
         const int64_t y0 = (int64_t)ty * 32;
         RowFrag<D> yf;
-        mf_load_frag<D>(yf, sc.Y, y0 + c, y0 + c < sc.nY);
+        mf_lds_frag<D>(yf, slot);
         const f32x16 acc = mf_tile_scores<D>(yf, xf);
-        typename Policy::Tile tile = Policy::tile_init(pp, row, y0, x);
+        typename Policy::Tile tile = Policy::tile_init(pp, row, slot + G::TILEB, wave, c, h);
         const int cnt0 = cnt;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int64_t y = y0 + mf_acc_row(e, h);
             const unsigned long long key = Policy::key(pp, row, tile, acc[e], e, h, y);
             if (key != 0ull && (unsigned)(key >> 32) >= tau_row && key >= fl) {
-                buf[lane][cnt] = key;
+                MF_BUF(lane, cnt) = key;
                 ++cnt;
             }
         }
         // refresh the T-list from this tile's accepted keys (few per lane)
         for (int i = cnt0; __any(i < cnt); ++i) {
             if (i < cnt) {
-                const unsigned r = (unsigned)(buf[lane][i] >> 32);
+                const unsigned r = (unsigned)(MF_BUF(lane, i) >> 32);
                 if (r > tl[T - 1]) mf_tlist_insert<T>(tl, r);
             }
         }
@@ -121,12 +171,12 @@ __global__ __launch_bounds__(64) void select_kernel(typename Policy::Params pp, 
             {   // drop, in place, what has fallen below the row's current bound
                 int w = 0;
                 for (int t = 0; t < cnt; ++t) {
-                    const unsigned long long kk = buf[lane][t];
-                    if ((unsigned)(kk >> 32) >= tau_row && kk >= fl) buf[lane][w++] = kk;
+                    const unsigned long long kk = MF_BUF(lane, t);
+                    if ((unsigned)(kk >> 32) >= tau_row && kk >= fl) MF_BUF(lane, w++) = kk;
                 }
                 cnt = w;
             }
-            // rare: a row still too full -> exact selection of its k best keys
+            // rare: a row still too full -> exact selection of its k best keys (wave-local)
             const unsigned long long ovb = __ballot(cnt > CAPL - 16);
             unsigned rows = (unsigned)(ovb | (ovb >> 32));
             while (rows) {
@@ -134,13 +184,14 @@ __global__ __launch_bounds__(64) void select_kernel(typename Policy::Params pp, 
                 rows &= rows - 1;
                 const int n0 = __shfl(cnt, r, 64), n1 = __shfl(cnt, r + 32, 64);
                 const int m = n0 + n1;                       // <= 2 CAPL <= 160
+                mf_wave_sync();
                 unsigned long long ev[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int t = lane + 64 * q;
-                    ev[q] = t < m ? (t < n0 ? buf[r][t] : buf[r + 32][t - n0]) : 0ull;
+                    ev[q] = t < m ? (t < n0 ? MF_BUF(r, t) : MF_BUF(r + 32, t - n0)) : 0ull;
                 }
-                __syncthreads();
+                mf_wave_sync();
                 unsigned long long kth = 0ull;
                 const int keep = min(sc.k, m);
                 for (int t = 0; t < keep; ++t) {
@@ -150,15 +201,20 @@ __global__ __launch_bounds__(64) void select_kernel(typename Policy::Params pp, 
                     if (ev[0] == best) ev[0] = 0ull;
                     else if (ev[1] == best) ev[1] = 0ull;
                     else if (ev[2] == best) ev[2] = 0ull;
-                    if (lane == 0) buf[r + 32 * (t & 1)][t >> 1] = best;
+                    if (lane == 0) MF_BUF(r + 32 * (t & 1), t >> 1) = best;
                     kth = best;
                 }
                 if (lane == r) cnt = (keep + 1) >> 1;
                 if (lane == r + 32) cnt = keep >> 1;
                 if (lane == 0) floor64[r] = (m >= sc.k) ? kth : 0ull;
-                __syncthreads();
+                mf_wave_sync();
             }
             fl = floor64[c];
+        }
+        }
+        if (L::NSLOT == 2) {            // the slot just read is the one tile ty+2 lands in
+            mf_block_barrier();
+            if (ty + 2 < t1) stage(ty + 2, cur_slot);
         }
     }
 
@@ -166,15 +222,46 @@ __global__ __launch_bounds__(64) void select_kernel(typename Policy::Params pp, 
     {
         int w = 0;
         for (int t = 0; t < cnt; ++t) {
-            const unsigned long long kk = buf[lane][t];
-            if ((unsigned)(kk >> 32) >= tau_row && kk >= fl) buf[lane][w++] = kk;
+            const unsigned long long kk = MF_BUF(lane, t);
+            if ((unsigned)(kk >> 32) >= tau_row && kk >= fl) MF_BUF(lane, w++) = kk;
         }
         cnt = w;
     }
     const int n_other = __shfl_xor(cnt, 32, 64);
-    unsigned long long* dst = sc.cand + ((int64_t)chunk * sc.Xp + x) * (2 * CAPL) + (h ? n_other : 0);
-    for (int t = 0; t < cnt; ++t) dst[t] = buf[lane][t];
-    if (h == 0) sc.cand_cnt[(int64_t)chunk * sc.Xp + x] = cnt + n_other;
+    const int64_t set = (int64_t)chunk * nsub + sub;
+    unsigned long long* dst = sc.cand + (set * sc.Xp + x) * (2 * CAPL) + (h ? n_other : 0);
+    for (int t = 0; t < cnt; ++t) dst[t] = MF_BUF(lane, t);
+    if (h == 0) sc.cand_cnt[set * sc.Xp + x] = cnt + n_other;
+#undef MF_BUF
+}
+
+// geometry shared by the two users of select_kernel
+struct SelectPlan {
+    int T, CAPL, CAP, xw, nsub, gx, nchunk, tpc, nsets;
+    int64_t Xp;
+    bool ok;             // false: k too large for the LDS budget at this width
+};
+static inline SelectPlan mf_select_plan(int64_t nX, int64_t nY, int d, int k) {
+    SelectPlan s;
+    s.T = mf_select_T(k);
+    s.CAPL = mf_select_capl(d);
+    s.ok = s.CAPL >= s.T + 16;
+    s.CAP = 2 * s.CAPL;
+    s.Xp = (nX + 127) / 128 * 128;
+    const int xt = (int)((nX + 31) / 32);
+    s.xw = xt >= 4 ? 4 : xt >= 2 ? 2 : 1;
+    s.nsub = 4 / s.xw;
+    s.gx = (xt + s.xw - 1) / s.xw;
+    const int YT = (int)((nY + 31) / 32);
+    const int max_sets = (64 * 1024) / (s.CAP * 8);          // merge kernel stages all sets of a row in <= 64 KiB LDS
+    int want = (256 + s.gx - 1) / s.gx;                      // ~ one workgroup per CU
+    if (want * s.nsub > max_sets) want = max_sets / s.nsub;
+    if (want > YT) want = YT;
+    if (want < 1) want = 1;
+    s.tpc = (YT + want - 1) / want;
+    s.nchunk = (YT + s.tpc - 1) / s.tpc;
+    s.nsets = s.nchunk * s.nsub;
+    return s;
 }
 
 // Exact ordered selection of the k largest keys staged in LDS `s[0..total)`, by one

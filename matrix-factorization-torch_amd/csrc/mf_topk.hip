@@ -16,16 +16,20 @@
 // so the words are scattered once per call and read with one coalesced load per tile).
 struct RetrievalPolicy {
     struct Params {
-        const uint32_t* exclW;     // [NT][Qp] or null
+        const uint32_t* exclW;     // [NT][Qp], all zero when nothing is excluded
         int64_t Qp, nY;
     };
     struct Row {};
     struct Tile {
         uint32_t ew;
     };
+    static constexpr int AUX_DMA = 1;
+    static __device__ __forceinline__ void stage_aux(const Params& p, char* aux, int wave, int t, int64_t x0) {
+        mf_stage_small(aux + wave * 128, p.exclW + (int64_t)t * p.Qp + x0, 128);
+    }
     static __device__ __forceinline__ Row row_init(const Params&, int64_t, bool) { return Row{}; }
-    static __device__ __forceinline__ Tile tile_init(const Params& p, const Row&, int64_t y0, int64_t x) {
-        return Tile{p.exclW ? p.exclW[(y0 >> 5) * p.Qp + x] : 0u};
+    static __device__ __forceinline__ Tile tile_init(const Params&, const Row&, const char* aux, int wave, int c, int) {
+        return Tile{reinterpret_cast<const uint32_t*>(aux + wave * 128)[c]};
     }
     static __device__ __forceinline__ unsigned long long key(const Params& p, const Row&, const Tile& t, float score,
                                                             int e, int h, int64_t y) {
@@ -45,41 +49,29 @@ __global__ __launch_bounds__(256) void excl_scatter_kernel(const int64_t* __rest
 }
 
 struct TopkWs {
-    int64_t Qp;
-    int QT, NT, T, CAP, nchunk, tpc;
+    SelectPlan plan;
+    int NT;
     unsigned long long* cand;
     int32_t* cand_cnt;
     uint32_t* exclW;
     size_t total;
 };
 
-static TopkWs topk_ws(void* base, int64_t Q, int64_t N, int k) {
+static TopkWs topk_ws(void* base, int64_t Q, int64_t N, int d, int k) {
     TopkWs w{};
-    w.Qp = mf_pad32(Q);
-    w.QT = (int)(w.Qp / 32);
-    w.NT = (int)(mf_pad32(N) / 32);
-    int capl;
-    mf_select_geometry(k, &w.T, &capl);
-    w.CAP = 2 * capl;
-    int maxchunk = (64 * 1024) / (w.CAP * 8);
-    int want = (2048 + w.QT - 1) / w.QT;
-    if (want > maxchunk) want = maxchunk;
-    if (want > w.NT) want = w.NT;
-    if (want < 1) want = 1;
-    w.tpc = (w.NT + want - 1) / want;
-    w.nchunk = (w.NT + w.tpc - 1) / w.tpc;
+    w.plan = mf_select_plan(Q, N, d, k);
+    w.NT = (int)((N + 31) / 32);
     MfArena a(base);
-    w.cand = a.take<unsigned long long>((size_t)w.nchunk * w.Qp * w.CAP);
-    w.cand_cnt = a.take<int32_t>((size_t)w.nchunk * w.Qp);
-    w.exclW = a.take<uint32_t>((size_t)w.NT * w.Qp);
+    w.cand = a.take<unsigned long long>((size_t)w.plan.nsets * w.plan.Xp * w.plan.CAP);
+    w.cand_cnt = a.take<int32_t>((size_t)w.plan.nsets * w.plan.Xp);
+    w.exclW = a.take<uint32_t>((size_t)w.NT * w.plan.Xp);
     w.total = a.used();
     return w;
 }
 
 extern "C" size_t mf_topk_ws_bytes(int64_t Q, int64_t N, int d, int k) {
-    (void)d;
-    if (Q <= 0 || N <= 0 || k <= 0) return 0;
-    return topk_ws(nullptr, Q, N, k).total;
+    if (Q <= 0 || N <= 0 || k <= 0 || !mf_width_ok(d)) return 0;
+    return topk_ws(nullptr, Q, N, d, k).total;
 }
 
 // one wave per query: candidates of all chunks -> ordered top-k
@@ -135,19 +127,24 @@ __global__ __launch_bounds__(64) void topk_merge_parts_kernel(const float* __res
     });
 }
 
+template <int D, int T>
+static void launch_topk_select_t(const TopkWs& w, const RetrievalPolicy::Params& rp, const SelectCommon& sc, hipStream_t s) {
+    auto fn = select_kernel<D, T, RetrievalPolicy>;
+    const int bytes = SelectLds<D>::bytes(sc.capl);
+    (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    fn<<<dim3((unsigned)w.plan.gx, (unsigned)w.plan.nchunk), 256, bytes, s>>>(rp, sc);
+}
 template <int D>
 static void launch_topk_select(const TopkWs& w, const RetrievalPolicy::Params& rp, const SelectCommon& sc, hipStream_t s) {
-    dim3 grid((unsigned)w.QT, (unsigned)w.nchunk);
-#define MF_SEL(TT, CC) select_kernel<D, TT, CC, RetrievalPolicy><<<grid, 64, 0, s>>>(rp, sc)
-    switch (w.T) {
-        case 2: MF_SEL(2, 40); break;
-        case 4: MF_SEL(4, 40); break;
-        case 8: MF_SEL(8, 40); break;
-        case 12: MF_SEL(12, 40); break;
-        case 16: MF_SEL(16, 48); break;
-        default: MF_SEL(32, 80); break;
+    switch (w.plan.T) {
+        case 2: launch_topk_select_t<D, 2>(w, rp, sc, s); break;
+        case 4: launch_topk_select_t<D, 4>(w, rp, sc, s); break;
+        case 8: launch_topk_select_t<D, 8>(w, rp, sc, s); break;
+        case 10: launch_topk_select_t<D, 10>(w, rp, sc, s); break;
+        case 12: launch_topk_select_t<D, 12>(w, rp, sc, s); break;
+        case 16: launch_topk_select_t<D, 16>(w, rp, sc, s); break;
+        default: launch_topk_select_t<D, 32>(w, rp, sc, s); break;
     }
-#undef MF_SEL
 }
 
 extern "C" int mf_topk(const float* q, int64_t Q, const float* items, int64_t N, int d, int k,
@@ -162,17 +159,14 @@ extern "C" int mf_topk(const float* q, int64_t Q, const float* items, int64_t N,
     if ((excl_off == nullptr) != (excl_idx == nullptr)) return mf_set_error(MF_EINVAL, "mf_topk: excl_off/excl_idx mismatch");
     if (ws_bytes < mf_topk_ws_bytes(Q, N, d, k)) return mf_set_error(MF_ENOSPC, "mf_topk: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    TopkWs w = topk_ws(ws, Q, N, k);
-    const uint32_t* exclW = nullptr;
-    if (excl_off) {
-        (void)hipMemsetAsync(w.exclW, 0, (size_t)w.NT * w.Qp * 4, s);
-        excl_scatter_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.Qp, w.exclW);
-        exclW = w.exclW;
-    }
-    RetrievalPolicy::Params rp{exclW, w.Qp, N};
-    SelectCommon sc{q, Q, items, N, w.NT, w.tpc, w.Qp, k, w.cand, w.cand_cnt};
+    TopkWs w = topk_ws(ws, Q, N, d, k);
+    if (!w.plan.ok) return mf_set_error(MF_ENOTSUP, "mf_topk: k = %d too large at d = %d", k, d);
+    (void)hipMemsetAsync(w.exclW, 0, (size_t)w.NT * w.plan.Xp * 4, s);
+    if (excl_off) excl_scatter_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.plan.Xp, w.exclW);
+    RetrievalPolicy::Params rp{w.exclW, w.plan.Xp, N};
+    SelectCommon sc{q, Q, items, N, w.NT, w.plan.tpc, w.plan.Xp, k, w.plan.xw, w.plan.CAPL, w.cand, w.cand_cnt};
     MF_DISPATCH_D(d, { MF_TIMED("topk_select", s, launch_topk_select<D>(w, rp, sc, s)); });
-    topk_merge_cand_kernel<<<dim3((unsigned)Q), 64, (size_t)w.nchunk * w.CAP * 8, s>>>(w.cand, w.cand_cnt, w.nchunk, w.Qp, w.CAP, k,
+    topk_merge_cand_kernel<<<dim3((unsigned)Q), 64, (size_t)w.plan.nsets * w.plan.CAP * 8, s>>>(w.cand, w.cand_cnt, w.plan.nsets, w.plan.Xp, w.plan.CAP, k,
                                                                                       idx_base, out_scores, out_idx);
     return mf_check_launch("mf_topk");
 }
