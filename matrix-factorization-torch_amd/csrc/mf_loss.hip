@@ -276,17 +276,41 @@ __device__ __forceinline__ void stats_add(RowStats& s, int need, float L, float 
 }
 
 // Workgroup = 4 waves x 32 users; item tiles arrive through the LDS ring of
-// mf_stream.h together with their mask words, norms and logQ.
+// mf_stream.h together with their mask words, norms and logQ (a separate 4-deep ring
+// of 1 KiB side-input slots).  The loop is software-pipelined inside each wave: the 64
+// MFMAs of tile t+1 are issued in the same basic block as the (branch-free) statistics
+// of tile t, so the matrix pipe and the VALU overlap without relying on a second wave.
 template <int D>
 struct FwdLds {
     using G = TileGeom<D>;
-    static constexpr int AUX_MASK = 0, AUX_NV = 512, AUX_LQ = 640, AUX_PAD = 768, AUXB = 1024;
-    static constexpr int SLOT = G::TILEB + AUXB;
-    static constexpr int BYTES = 3 * SLOT;
-    static constexpr int NDMA = G::PPW + 1;    // DMA instructions per wave per stage (+ 4 stash stores per tile)
+    static constexpr int AUX_NV = 512, AUX_LQ = 640, AUX_PAD = 768, AUXB = 1024;   // [0,512): 4 x 128 B mask words
+    static constexpr int AUX0 = 3 * G::TILEB;           // 4 side-input slots after the 3 tile slots
+    static constexpr int BYTES = AUX0 + 4 * AUXB;
+    static constexpr int NDMA = G::PPW + 2;             // DMA instructions per wave per stage (+ 4 stash stores per tile)
 };
 
-template <int D>
+template <int NEED>
+__device__ __forceinline__ void stats_add_masked(RowStats& s, float L, bool ok, float sm, float lii, float margin) {
+    // masked elements enter as -FLT_MAX: every term below is then exactly 0
+    const float Lm = ok ? L : -FLT_MAX;
+    s.cnt += ok ? 1.f : 0.f;
+    if (NEED & NEED_CONTR) s.A += fmaxf(Lm + sm, 0.f);
+    if (NEED & (NEED_HINGE | NEED_LOGI)) {
+        const float x = (Lm - lii) + margin;
+        if (NEED & NEED_HINGE) {
+            s.H += fmaxf(x, 0.f);
+            s.Hc += x > 0.f ? 1.f : 0.f;
+        }
+        if (NEED & NEED_LOGI) {
+            float sp, sg;
+            softplus_sigmoid(x, sp, sg);
+            s.Lg += sp;
+            s.Ls += sg;
+        }
+    }
+}
+
+template <int D, int NEED>
 __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = TileGeom<D>;
@@ -303,65 +327,76 @@ __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
     RowStats st;
     stats_init(st);
 
-    auto stage = [&](int t, int slot_idx) {
-        char* slot = smem + slot_idx * L::SLOT;
+    auto stage = [&](int t) {
+        const int k = t - t0;
         const int64_t j0 = (int64_t)t * 32;
-        mf_stage_tile<D>(slot, p.v, j0, p.N);
-        char* aux = slot + G::TILEB;
-        if (wave == 0) mf_stage_small(aux + L::AUX_MASK, p.maskW + (int64_t)t * p.Bp + i0, 512);
-        else if (wave == 1) mf_stage_small(aux + L::AUX_NV, p.nv + j0, 128);
-        else if (wave == 2) mf_stage_small(aux + L::AUX_LQ, (p.logq ? p.logq : p.nv) + j0, 128);
-        else mf_stage_small(aux + L::AUX_PAD, p.nv + j0, 128);
+        mf_stage_tile<D>(smem + (k % 3) * G::TILEB, p.v, j0, p.N);
+        char* aux = smem + L::AUX0 + (k & 3) * L::AUXB;
+        mf_stage_small(aux + wave * 128, p.maskW + (int64_t)t * p.Bp + i0 + wave * 32, 128);
+        mf_stage_small(aux + L::AUX_NV + wave * 128, (wave == 1 ? p.logq : p.nv) + j0, 128);   // 512: nv, 640: logq (zeros if none)
     };
-    if (t0 < t1) stage(t0, 0);
-    if (t0 + 1 < t1) stage(t0 + 1, 1);
-    int cur = 0;
-    for (int tj = t0; tj < t1; ++tj) {
-        // queue, oldest first: [DMA(tj)] [stores(tj-2)] [DMA(tj+1)] [stores(tj-1)]
-        if (tj + 1 >= t1) mf_wait_vmcnt<0>();
-        else if (tj == t0) mf_wait_vmcnt<L::NDMA>();
-        else mf_wait_vmcnt<L::NDMA + 4>();
-        mf_block_barrier();
-        if (tj + 2 < t1) stage(tj + 2, cur >= 1 ? cur - 1 : 2);
-        const char* slot = smem + cur * L::SLOT;
-        const char* aux = slot + G::TILEB;
-        RowFrag<D> yf;
-        mf_lds_frag<D>(yf, slot);
-        const f32x16 acc = mf_tile_scores<D>(yf, xf);
-        const uint32_t mw = reinterpret_cast<const uint32_t*>(aux + L::AUX_MASK)[wave * 32 + c];
-        f32x4 nv4[4], lq4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            nv4[q] = *reinterpret_cast<const f32x4*>(aux + L::AUX_NV + (8 * q + 4 * h) * 4);
-            lq4[q] = p.logq ? *reinterpret_cast<const f32x4*>(aux + L::AUX_LQ + (8 * q + 4 * h) * 4)
-                            : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        float Lg[16];
-        float tmax = -FLT_MAX;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            Lg[e] = mf_logit(nu_i, nv4[e >> 2][e & 3], acc[e], s_i, p.sigma, lq4[e >> 2][e & 3]);
-            const bool ok = !((mw >> mf_acc_row(e, h)) & 1u);
-            if (ok) tmax = fmaxf(tmax, Lg[e]);
-        }
-        {   // stash the logits block for the backward sweeps
-            float* blk = p.stash + ((int64_t)(i0 / 32 + wave) * p.NT + tj) * 1024 + lane * 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<f32x4*>(blk + q * 256) = f32x4{Lg[4 * q], Lg[4 * q + 1], Lg[4 * q + 2], Lg[4 * q + 3]};
-        }
-        float nmx = fmaxf(st.mx, tmax);
-        if (p.need & NEED_LSE) st.se *= __expf(st.mx - nmx);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const bool ok = !((mw >> mf_acc_row(e, h)) & 1u);
-            if (ok) {
-                stats_add(st, p.need, Lg[e], sm, lii, p.margin);
-                if (p.need & NEED_LSE) st.se += __expf(Lg[e] - nmx);
+    // The statistics of one tile, cut in 32 slices so they can be threaded between the MFMAs of
+    // the next tile: slices 0..15 turn score e into logit e (and stash it), slices 16..31 fold
+    // logit e into the running statistics.
+    float Lg[16];
+    float tmax = -FLT_MAX, nmx = -FLT_MAX;
+    uint32_t mw = 0u;
+    f32x4 nv4 = {0.f, 0.f, 0.f, 0.f}, lq4 = {0.f, 0.f, 0.f, 0.f};
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int te = t0;                                 // tile the slices work on
+    auto slice = [&](int sidx) {
+        const char* aux = smem + L::AUX0 + ((te - t0) & 3) * L::AUXB;
+        if (sidx < 16) {
+            const int e = sidx, q = e >> 2, r = e & 3;
+            if (e == 0) {
+                mw = reinterpret_cast<const uint32_t*>(aux)[wave * 32 + c];
+                tmax = -FLT_MAX;
             }
+            if (r == 0) {
+                nv4 = *reinterpret_cast<const f32x4*>(aux + L::AUX_NV + (8 * q + 4 * h) * 4);
+                lq4 = *reinterpret_cast<const f32x4*>(aux + L::AUX_LQ + (8 * q + 4 * h) * 4);
+            }
+            Lg[e] = mf_logit(nu_i, nv4[r], acc[e], s_i, p.sigma, lq4[r]);
+            const bool ok = !((mw >> mf_acc_row(e, h)) & 1u);
+            tmax = fmaxf(tmax, ok ? Lg[e] : -FLT_MAX);
+            if (r == 3) {   // stash 4 logits of the block for the backward sweeps
+                float* blk = p.stash + ((int64_t)(i0 / 32 + wave) * p.NT + te) * 1024 + lane * 4;
+                *reinterpret_cast<f32x4*>(blk + q * 256) = f32x4{Lg[e - 3], Lg[e - 2], Lg[e - 1], Lg[e]};
+            }
+        } else {
+            const int e = sidx - 16;
+            if (e == 0) {
+                nmx = fmaxf(st.mx, tmax);
+                if (NEED & NEED_LSE) st.se *= __expf(st.mx - nmx);
+                st.mx = nmx;
+            }
+            const bool ok = !((mw >> mf_acc_row(e, h)) & 1u);
+            stats_add_masked<NEED>(st, Lg[e], ok, sm, lii, p.margin);
+            if (NEED & NEED_LSE) st.se += __expf((ok ? Lg[e] : -FLT_MAX) - nmx);
         }
-        st.mx = nmx;
-        cur = cur == 2 ? 0 : cur + 1;
+    };
+
+    if (t0 < t1) {
+        stage(t0);
+        if (t0 + 1 < t1) stage(t0 + 1);
+        if (t0 + 1 < t1) mf_wait_vmcnt<L::NDMA>(); else mf_wait_vmcnt<0>();
+        mf_block_barrier();
+        if (t0 + 2 < t1) stage(t0 + 2);
+        acc = mf_tile_scores_interleaved<D, 32>(smem, xf, [](int) {});
+        for (int tj = t0; tj + 1 < t1; ++tj) {
+            // queue, oldest first: [DMA(tj+1)] [stores(tj-2)] [DMA(tj+2)] [stores(tj-1)]
+            if (tj + 2 >= t1) mf_wait_vmcnt<0>();
+            else if (tj == t0) mf_wait_vmcnt<L::NDMA>();
+            else mf_wait_vmcnt<L::NDMA + 4>();
+            mf_block_barrier();
+            if (tj + 3 < t1) stage(tj + 3);
+            te = tj;
+            const f32x16 acc_n = mf_tile_scores_interleaved<D, 32>(smem + ((tj + 1 - t0) % 3) * G::TILEB, xf, slice);
+            acc = acc_n;
+        }
+        te = t1 - 1;
+#pragma unroll
+        for (int sidx = 0; sidx < 32; ++sidx) slice(sidx);
     }
     // the row's other half of the columns lives in lane ^ 32
     {
@@ -375,6 +410,24 @@ __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
         float* o = p.part + (int64_t)blockIdx.y * NSTAT * p.Bp + i;
         o[ST_CNT * p.Bp] = st.cnt; o[ST_A * p.Bp] = st.A; o[ST_MX * p.Bp] = st.mx; o[ST_SE * p.Bp] = st.se;
         o[ST_H * p.Bp] = st.H; o[ST_HC * p.Bp] = st.Hc; o[ST_LG * p.Bp] = st.Lg; o[ST_LS * p.Bp] = st.Ls;
+    }
+}
+
+template <int D, int NEED>
+static void launch_fwd_n(dim3 grid, const FwdParams& fp, hipStream_t s) {
+    auto fn = loss_fwd_dense_kernel<D, NEED>;
+    if (FwdLds<D>::BYTES > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, FwdLds<D>::BYTES);
+    fn<<<grid, 256, FwdLds<D>::BYTES, s>>>(fp);
+}
+template <int D>
+static void launch_fwd(int need, dim3 grid, const FwdParams& fp, hipStream_t s) {
+    switch (need) {   // single-loss calls get a specialised epilogue; anything else computes every statistic
+        case NEED_CONTR: launch_fwd_n<D, NEED_CONTR>(grid, fp, s); break;
+        case NEED_LSE: launch_fwd_n<D, NEED_LSE>(grid, fp, s); break;
+        case NEED_HINGE: launch_fwd_n<D, NEED_HINGE>(grid, fp, s); break;
+        case NEED_LOGI: launch_fwd_n<D, NEED_LOGI>(grid, fp, s); break;
+        default: launch_fwd_n<D, 15>(grid, fp, s); break;
     }
 }
 
@@ -822,10 +875,6 @@ __global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict_
 template <int D, bool XU>
 static void launch_bwd(int gmode, dim3 grid, const BwdParams& bp, hipStream_t s);
 
-static void set_lds_limit(const void* fn, int bytes) {
-    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
-
 template <int D, bool XU, int GMODE>
 static void launch_bwd_g(dim3 grid, const BwdParams& bp, hipStream_t s) {
     auto fn = loss_bwd_dense_kernel<D, XU, GMODE>;
@@ -909,18 +958,15 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
                                                                             w.maskW, w.maskTW);
     }
     // logq is read by whole float4s up to the padded width: keep a zero-padded copy in ws
-    const float* logq_p = nullptr;
-    if (logq) {
-        (void)hipMemsetAsync(w.logq, 0, (size_t)w.Np * 4, s);
-        (void)hipMemcpyAsync(w.logq, logq, (size_t)N * 4, hipMemcpyDeviceToDevice, s);
-        logq_p = w.logq;
-    }
+    // (all zeros when there is no logQ correction: L - 0 is exact, and the kernels stay branch-free)
+    (void)hipMemsetAsync(w.logq, 0, (size_t)w.Np * 4, s);
+    if (logq) (void)hipMemcpyAsync(w.logq, logq, (size_t)N * 4, hipMemcpyDeviceToDevice, s);
+    const float* logq_p = w.logq;
     if (scores_needed && !w.mined) {
         FwdParams fp{u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.part, w.stash, B, N, w.Bp, w.NT, w.tps_f, need, sigma, margin};
         MF_DISPATCH_D(d, {
             dim3 grid((unsigned)(w.BT / 4), (unsigned)w.nsplit_f);
-            set_lds_limit((const void*)loss_fwd_dense_kernel<D>, FwdLds<D>::BYTES);
-            MF_TIMED("loss_fwd_dense", s, (loss_fwd_dense_kernel<D><<<grid, 256, FwdLds<D>::BYTES, s>>>(fp)));
+            MF_TIMED("loss_fwd_dense", s, (launch_fwd<D>(need, grid, fp, s)));
         });
         stats_merge_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(w.part, w.nsplit_f, w.Bp, w.stats);
         if (out_mask_bits)

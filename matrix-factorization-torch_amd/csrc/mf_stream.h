@@ -91,6 +91,41 @@ __device__ __forceinline__ void mf_lds_frag(RowFrag<D>& f, const char* lds_tile)
         f.v[g] = *reinterpret_cast<const f32x4*>(rowp + (((2 * g + h) ^ sw) << 4));
 }
 
+// Score tile of the staged Y tile with VALU work of the PREVIOUS tile threaded between the MFMA
+// groups: a wave issues in order, and a dependent fp32 MFMA occupies the matrix pipe for 64
+// cycles, so ~14 VALU issue slots per MFMA are free if -- and only if -- the VALU instructions
+// sit between the MFMAs in program order.  `slice(s)`, s = 0 .. NSLICE-1, is that work, cut in
+// NSLICE pieces; sched_barrier pins the interleave (hipcc otherwise clusters the MFMAs).
+template <int D, int NSLICE, class Slice>
+__device__ __forceinline__ f32x16 mf_tile_scores_interleaved(const char* lds_tile, const RowFrag<D>& x, Slice&& slice) {
+    using G = TileGeom<D>;
+    constexpr int NG = D / 8;
+    static_assert(NSLICE % NG == 0 || NG % NSLICE == 0, "slices and MFMA groups must nest");
+    const int lane = mf_lane(), r = lane & 31, h = lane >> 5;
+    const char* rowp = lds_tile + r * G::ROWB;
+    const int sw = G::swz(r);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x4 a_next = *reinterpret_cast<const f32x4*>(rowp + ((h ^ sw) << 4));
+    int s_done = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const f32x4 a = a_next;
+        if (g + 1 < NG) a_next = *reinterpret_cast<const f32x4*>(rowp + (((2 * (g + 1) + h) ^ sw) << 4));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], x.v[g][t], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int s_end = (g + 1) * NSLICE / NG;
+#pragma unroll
+        for (int sidx = g * NSLICE / NG; sidx < s_end; ++sidx) slice(sidx);
+        s_done = s_end;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    (void)s_done;
+    return acc;
+}
+
 // Transposed operand of the backward: lane c gets the D/32 consecutive floats
 // [NB c, NB c + NB) of `row` (NB = D / 32) in one wide LDS read; v[j] is the A operand
 // of accumulator block j, whose MFMA row index r then stands for feature NB r + j.

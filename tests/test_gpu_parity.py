@@ -223,7 +223,7 @@ def test_sparse_update_matches_oracle(mf, d, normalize, opt):
 
 
 # --------------------------------------------------------------------- retrieval ---
-@pytest.mark.parametrize("cfg", [(50, 5000, 64, 20), (1, 3883, 64, 20), (33, 1000, 128, 5), (7, 300, 32, 64), (40, 2500, 256, 33)],
+@pytest.mark.parametrize("cfg", [(50, 5000, 64, 20), (1, 3883, 64, 20), (33, 1000, 128, 5), (7, 300, 32, 64), (40, 2500, 256, 32)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_topk_bit_exact(mf, cfg):
     nq, n, d, k = cfg
