@@ -1,0 +1,143 @@
+"""``MatrixFactorizationLitModule`` on the HIP hot path.
+
+Mirrors the surface of ``xfmr_rec/lightning.py`` that the training loop touches:
+``MatrixFactorizationLitConfig`` (:32-43, same defaults), ``forward`` (:60-74),
+``recommend`` (:76-95), ``compute_losses`` (:97-147, same ``"{step}/{ClassName}"`` keys,
+all seven losses per step), ``training_step`` (:189-192), ``configure_optimizers``
+(:238-239), ``configure_model`` / ``get_loss_fns`` (:252-287) and the
+``"... must be initialised first"`` guards (:61-63, :85-87, :100-102).
+
+Differences, all dictated by the north-star: towers are embedding tables indexed by
+``user_rn`` / ``movie_rn`` (``forward(idx, tower=...)`` instead of ``forward(text)``),
+the optimiser is a sparse row optimiser, retrieval is exact brute force.  The class
+derives from ``lightning.LightningModule`` when Lightning is installed (it is not in the
+build image) and from ``torch.nn.Module`` otherwise, so ``Trainer.fit`` can drive it
+unchanged where Lightning exists.  Metrics, callbacks, loggers, CLI and ``save`` are the
+reference's control plane and stay out of scope.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import losses as mf_losses
+from . import models, optim
+from .params import TOP_K
+from .retrieval import ItemProcessor
+
+try:  # pragma: no cover - Lightning is absent from the build image
+    from lightning import LightningModule as _Base
+except ImportError:  # noqa: SIM105
+    class _Base(torch.nn.Module):
+        """Minimal stand-in: what this module uses of LightningModule."""
+
+        def log_dict(self, *_, **__) -> None:
+            return None
+
+        @property
+        def device(self) -> torch.device:
+            return next(self.parameters()).device
+
+
+class MatrixFactorizationLitConfig(models.ModelConfig):
+    train_loss: str = "PairwiseHingeLoss"
+    num_negatives: int = 4
+    sigma: float = 1.0
+    margin: float = 1.0
+    learning_rate: float = 0.0001
+    top_k: int = TOP_K
+    optimizer: str = "adam"        # "adam" = row-wise AdamW (the reference's optimiser class), "sgd"
+    fused_losses: bool = True      # all seven losses from one sweep instead of seven sweeps
+    use_logq: bool = False         # logQ correction (absent upstream)
+
+
+class MatrixFactorizationLitModule(_Base):
+    def __init__(self, config: MatrixFactorizationLitConfig | dict) -> None:
+        super().__init__()
+        self.config = MatrixFactorizationLitConfig.model_validate(config)
+        self.towers: torch.nn.ModuleDict | None = None
+        self.loss_fns: torch.nn.ModuleList | None = None
+        self.item_processor: ItemProcessor | None = None
+        self.history: dict[int, list[int]] = {}      # user_rn -> item ids already consumed (recommend excludes them)
+        self.logq: torch.Tensor | None = None         # [num_items] log sampling probability, when use_logq
+
+    # ------------------------------------------------------------------ towers ---
+    def forward(self, idx: torch.Tensor, *, tower: str = "user") -> torch.Tensor:
+        if self.towers is None:
+            msg = "`model` must be initialised first"
+            raise ValueError(msg)
+        return self.towers[tower](idx)
+
+    @torch.inference_mode()
+    def recommend(self, user_idx: int, *, top_k: int = TOP_K, exclude_item_ids: list[int] | None = None):
+        if self.towers is None or self.item_processor is None or self.item_processor.index is None:
+            msg = "`user_processor` and `item_processor` must be initialised first"
+            raise ValueError(msg)
+        exclude_item_ids = (exclude_item_ids or []) + list(self.history.get(int(user_idx), []))
+        device = self.towers["user"].weight.device
+        embed = self(torch.tensor([int(user_idx)], device=device)).cpu().numpy()
+        return self.item_processor.search(embed, exclude_item_ids=exclude_item_ids, top_k=top_k)
+
+    # ------------------------------------------------------------------ losses ---
+    def compute_losses(self, batch, step_name: str = "train") -> dict[str, torch.Tensor]:
+        if self.loss_fns is None:
+            msg = "`loss_fns` must be initialised first"
+            raise ValueError(msg)
+        target = batch["target"]
+        pos_idx = batch["user"]["pos_idx"]
+        user_embed = self(batch["user"]["idx"], tower="user")
+        # positives then sampled negatives, as xfmr_rec/lightning.py:133-134
+        item_idx = torch.cat([batch["item"]["idx"], batch["neg_item"]["idx"]])
+        item_embed = self(item_idx, tower="item")
+        logq = self.logq[item_idx] if (self.config.use_logq and self.logq is not None) else None
+        cfg = self.config
+        if cfg.fused_losses:
+            vals = mf_losses.fused_losses(user_embed, item_embed, target, item_idx=item_idx, pos_idx=pos_idx,
+                                          num_negatives=cfg.num_negatives, sigma=cfg.sigma, margin=cfg.margin,
+                                          logq=logq)
+            return {f"{step_name}/{name}": v for name, v in vals.items()}
+        return {
+            f"{step_name}/{fn.__class__.__name__}": fn(user_embed=user_embed, item_embed=item_embed, target=target,
+                                                       item_idx=item_idx, pos_idx=pos_idx, logq=logq)
+            for fn in self.loss_fns
+        }
+
+    def training_step(self, batch, _: int = 0) -> torch.Tensor:
+        losses = self.compute_losses(batch, step_name="train")
+        self.log_dict(losses)
+        return losses[f"train/{self.config.train_loss}"]
+
+    # ------------------------------------------------------------------- setup ---
+    def configure_optimizers(self) -> torch.optim.Optimizer:
+        params = list(self.towers.parameters())
+        if self.config.optimizer == "sgd":
+            return optim.SparseSGD(params, lr=self.config.learning_rate)
+        return optim.RowAdam(params, lr=self.config.learning_rate)
+
+    def configure_model(self, device=None) -> None:
+        if self.towers is None:
+            self.towers = self.get_model(device)
+        if self.loss_fns is None:
+            self.loss_fns = self.get_loss_fns()
+        if self.item_processor is None:
+            self.item_processor = ItemProcessor()
+
+    def get_model(self, device=None) -> torch.nn.ModuleDict:
+        return models.init_towers(self.config, device=device)
+
+    def get_loss_fns(self) -> torch.nn.ModuleList:
+        loss_classes = [
+            mf_losses.AlignmentLoss,
+            mf_losses.ContrastiveLoss,
+            mf_losses.AlignmentContrastiveLoss,
+            mf_losses.InfomationNoiseContrastiveEstimationLoss,
+            mf_losses.MutualInformationNeuralEstimationLoss,
+            mf_losses.PairwiseHingeLoss,
+            mf_losses.PairwiseLogisticLoss,
+        ]
+        cfg = self.config
+        return torch.nn.ModuleList(
+            [cls(num_negatives=cfg.num_negatives, sigma=cfg.sigma, margin=cfg.margin) for cls in loss_classes]
+        )
+
+    def on_validation_start(self) -> None:
+        self.item_processor.get_index(self)

@@ -1,0 +1,137 @@
+"""GPU: the Lightning-module surface end to end, and size-independent properties at the
+BASELINE configurations' full sizes (where the scalar oracle would take too long)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as ol
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _module(mf, **over):
+    cfg = {"num_users": 500, "num_items": 800, "hidden_size": 64, "learning_rate": 0.05, **over}
+    m = mf.lightning.MatrixFactorizationLitModule(cfg)
+    m.configure_model(device=DEV)
+    return m
+
+
+def test_compute_losses_keys_and_values_match_oracle(mf):
+    m = _module(mf, num_negatives=4)
+    batch = mf.data.to_device(mf.data.SyntheticInteractions(500, 800, max_positives=12, seed=3).batch(96), DEV)
+    out = m.compute_losses(batch, step_name="train")
+    assert list(out) == [f"train/{k}" for k in ol.KINDS]                 # xfmr_rec/lightning.py:137-146
+    item_idx = torch.cat([batch["item"]["idx"], batch["neg_item"]["idx"]])
+    u = m(batch["user"]["idx"], tower="user").detach().cpu()
+    v = m(item_idx, tower="item").detach().cpu()
+    want = ol.all_losses(u, v, batch["target"].cpu(), item_idx=item_idx.cpu(), pos_idx=batch["user"]["pos_idx"].cpu(),
+                         num_negatives=4)
+    for k in ol.KINDS:
+        assert abs(float(out[f"train/{k}"]) - float(want[k])) <= 1e-4 * max(1.0, abs(float(want[k]))), k
+    m.config.fused_losses = False
+    single = m.compute_losses(batch)
+    for k in ol.KINDS:
+        assert float(single[f"train/{k}"]) == float(out[f"train/{k}"]), k
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_training_loop_reduces_loss_and_recommend_excludes_history(mf, opt):
+    m = _module(mf, optimizer=opt, train_loss="PairwiseLogisticLoss", margin=0.0, num_negatives=0)   # BPR (config C1)
+    optim = m.configure_optimizers()
+    data = mf.data.SyntheticInteractions(500, 800, max_positives=8, seed=1)
+    fixed = mf.data.to_device(data.batch(256), DEV)
+    first = last = None
+    for step in range(30):
+        loss = m.training_step(fixed, step)
+        loss.backward()
+        optim.step()
+        optim.zero_grad()
+        first = float(loss) if first is None else first
+        last = float(loss)
+    assert last < 0.9 * first, (first, last)
+    m.on_validation_start()
+    m.history[7] = [3, 4, 5]
+    df = m.recommend(7, top_k=10, exclude_item_ids=[6])
+    assert len(df) == 10 and not set(df["movie_id"]) & {3, 4, 5, 6}
+    assert df["score"].is_monotonic_decreasing and float(df["score"].max()) <= 1.0 + 1e-5
+
+
+def _torch_infonce(u, v, target, item_idx, pos_idx, logq):
+    """Plain torch fp32 reference on the GPU for full-size checks (dense, no mining)."""
+    b = u.shape[0]
+    lg = -0.5 * (torch.cdist(u, v) ** 2) * torch.sign(target.float())[:, None] - logq[None, :]
+    hit = item_idx[:b, None] == item_idx[None, :]
+    for p in range(pos_idx.shape[1]):
+        hit |= pos_idx[:, p, None] == item_idx[None, :]
+    keep = ~hit
+    keep[torch.arange(b), torch.arange(b)] = True
+    lse = torch.logsumexp(torch.where(keep, lg, torch.full_like(lg, -float("inf"))), dim=1)
+    return ((lse - lg.diagonal()) * target.abs()).sum()
+
+
+def test_full_size_training_step_properties(mf):
+    """Config C3 shapes (B = 8192, N = 16384, d = 128, P = 64): loss and gradients against a torch
+    fp32 reference on the GPU, linearity of the backward in grad_out, finite outputs."""
+    g = torch.Generator().manual_seed(0)
+    b, n, d, p = 8192, 16384, 128, 64
+    u0 = torch.nn.functional.normalize(torch.randn(b, d, generator=g), dim=-1).to(DEV)
+    v0 = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1).to(DEV)
+    target = torch.randint(1, 6, (b,), generator=g).to(DEV)
+    w = 1.0 / torch.arange(1, 62423, dtype=torch.float64)
+    item_idx = torch.cat([torch.multinomial(w, b, replacement=True, generator=g) + 1,
+                          torch.randint(1, 62423, (b,), generator=g)]).to(DEV)
+    pos_idx = (torch.multinomial(w, b * p, replacement=True, generator=g).reshape(b, p) + 1).to(DEV)
+    pos_idx[:, 0] = item_idx[:b]
+    logq = torch.log(torch.rand(n, generator=g) * 0.5 + 0.01).to(DEV)
+    fn = mf.losses.InfomationNoiseContrastiveEstimationLoss(num_negatives=0)
+    u, v = u0.clone().requires_grad_(), v0.clone().requires_grad_()
+    loss = fn(u, v, target, item_idx=item_idx, pos_idx=pos_idx, logq=logq)
+    loss.backward()
+    ur, vr = u0.clone().requires_grad_(), v0.clone().requires_grad_()
+    ref = _torch_infonce(ur, vr, target, item_idx, pos_idx, logq)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-4 * abs(float(ref)), (float(loss), float(ref))
+    torch.testing.assert_close(u.grad, ur.grad, rtol=2e-3, atol=2e-5)
+    torch.testing.assert_close(v.grad, vr.grad, rtol=2e-3, atol=2e-5)
+    u2, v2 = u0.clone().requires_grad_(), v0.clone().requires_grad_()
+    (2.5 * fn(u2, v2, target, item_idx=item_idx, pos_idx=pos_idx, logq=logq)).backward()
+    torch.testing.assert_close(u2.grad, 2.5 * u.grad, rtol=1e-5, atol=1e-7)      # backward is linear in grad_out
+    assert torch.isfinite(u.grad).all() and torch.isfinite(v.grad).all()
+
+
+def test_full_size_topk_properties(mf):
+    """ML-25M catalog (62,423 x 128), Q = 1024, k = 20: sorted, excluded rows absent, scores agree
+    with a torch matmul, idempotent, and the 8-shard merge reproduces the single scan bit for bit."""
+    g = torch.Generator().manual_seed(1)
+    n, d, q, k = 62423, 128, 1024, 20
+    items = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1).to(DEV)
+    queries = torch.nn.functional.normalize(torch.randn(q, d, generator=g), dim=-1).to(DEV)
+    excl = [torch.unique(torch.randint(0, n, (int(m),), generator=g)).tolist()
+            for m in torch.randint(0, 200, (q,), generator=g)]
+    index = mf.retrieval.ItemIndex(items)
+    s, i = index.search(queries, k, exclude=excl)
+    s2, i2 = index.search(queries, k, exclude=excl)
+    assert torch.equal(i, i2) and torch.equal(s, s2)
+    assert (s[:, :-1] >= s[:, 1:]).all()
+    ties = s[:, :-1] == s[:, 1:]
+    assert (i[:, :-1][ties] < i[:, 1:][ties]).all()
+    full = queries @ items.T
+    for r, ex in enumerate(excl):
+        if ex:
+            full[r, torch.tensor(ex, device=DEV)] = -float("inf")
+    ts, ti = torch.topk(full, k, dim=1)
+    torch.testing.assert_close(s, ts, rtol=0, atol=2e-6)
+    agree = (i == ti).float().mean()
+    assert agree > 0.999, float(agree)                       # matmul order differs in the last bit near ties
+    assert all(not set(i[r].tolist()) & set(excl[r]) for r in range(0, q, 37))
+    bounds = np.linspace(0, n, 9).astype(int)
+    ps, pi = [], []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        a, b = mf.retrieval.ItemIndex(items[lo:hi], idx_base=int(lo)).search(queries, k, exclude=excl)
+        ps.append(a)
+        pi.append(b)
+    ms, mi = mf.retrieval.merge_topk(torch.stack(ps), torch.stack(pi), k)
+    assert torch.equal(mi, i) and torch.equal(ms, s)

@@ -1,0 +1,99 @@
+"""CPU: the C ABI loads and exports what include/mf_hip.h declares; host-side logic
+(batch layout, error behaviour, no silent CPU fallback)."""
+from __future__ import annotations
+
+import pathlib
+import re
+
+import pytest
+import torch
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def test_library_exports_every_declared_symbol(mf):
+    header = (ROOT / "include" / "mf_hip.h").read_text()
+    declared = set(re.findall(r"\b(mf_[a-z0-9_]+)\s*\(", header))
+    assert {"mf_loss_fwd", "mf_loss_bwd", "mf_gather_rows", "mf_update_sgd", "mf_update_adam", "mf_topk",
+            "mf_topk_merge"} <= declared
+    lib = mf._lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"libmf_hip.so lacks {name}"
+    assert declared == set(mf._lib.SIGNATURES), declared ^ set(mf._lib.SIGNATURES)
+    assert lib.mf_version() >= 100
+
+
+def test_workspace_queries_need_no_gpu(mf):
+    lib = mf._lib.lib()
+    assert lib.mf_loss_ws_bytes(8192, 16384, 128, 64, 0) > 8192 * 16384 * 4      # holds the logits stash
+    assert lib.mf_loss_ws_bytes(8192, 16384, 128, 64, 4) < 512 * 2**20           # mined: no stash
+    assert lib.mf_loss_ws_bytes(4, 2, 128, 0, 0) == 0                            # N < B is invalid
+    assert lib.mf_topk_ws_bytes(1024, 62423, 128, 20) > 0
+    assert lib.mf_update_ws_bytes(16384, 128) >= 16384 * 128 * 4
+
+
+def test_no_cpu_fallback(mf):
+    """The product path raises on CPU tensors instead of computing somewhere else."""
+    fn = mf.losses.InfomationNoiseContrastiveEstimationLoss()
+    with pytest.raises(mf.MfHipError, match="no CPU path"):
+        fn(torch.randn(4, 32), torch.randn(8, 32), torch.ones(4), item_idx=torch.arange(8), pos_idx=None)
+    with pytest.raises(mf.MfHipError):
+        mf.retrieval.ItemIndex(torch.randn(10, 32))
+
+
+def test_check_inputs_raise_like_reference(mf):
+    fn = mf.losses.PairwiseHingeLoss(num_negatives=4, sigma=2.0, margin=0.5)
+    assert (fn.num_negatives, fn.sigma, fn.margin) == (4, 2.0, 0.5)
+    u, v = torch.randn(4, 32), torch.randn(8, 32)
+    with pytest.raises(ValueError, match="2 dimensions"):
+        fn(u[0], v, torch.ones(4), item_idx=torch.arange(8), pos_idx=None)
+    with pytest.raises(ValueError, match="dimension 1"):
+        fn(u, v[:, :16], torch.ones(4), item_idx=torch.arange(8), pos_idx=None)
+    with pytest.raises(ValueError, match="dimension 0"):
+        fn(u, v, torch.ones(5), item_idx=torch.arange(8), pos_idx=None)
+
+
+def test_loss_class_names_and_order(mf):
+    module = mf.lightning.MatrixFactorizationLitModule({"num_users": 10, "num_items": 10, "hidden_size": 32})
+    with pytest.raises(ValueError, match="`loss_fns` must be initialised first"):
+        module.compute_losses({})
+    with pytest.raises(ValueError, match="`model` must be initialised first"):
+        module(torch.zeros(1, dtype=torch.long))
+    names = [type(f).__name__ for f in module.get_loss_fns()]
+    assert names == list(mf.losses.KINDS)
+    assert module.config.train_loss == "PairwiseHingeLoss" and module.config.num_negatives == 4
+    assert module.config.learning_rate == 1e-4 and module.config.top_k == 20
+
+
+@pytest.mark.parametrize(
+    ("batch_sizes", "dim", "pad_start", "expected_size"),
+    [
+        ([(1,), (3,)], 0, False, (2, 3)), ([(1,), (3,)], -1, False, (2, 3)),
+        ([(3, 2), (5, 2)], 0, False, (2, 5, 2)), ([(2, 3), (2, 5)], 1, False, (2, 2, 5)),
+        ([(2, 3), (2, 5)], -1, False, (2, 2, 5)), ([(3, 2), (5, 2)], -2, False, (2, 5, 2)),
+        ([(1,), (3,)], 0, True, (2, 3)), ([(1,), (3,)], -1, True, (2, 3)),
+        ([(3, 2), (5, 2)], 0, True, (2, 5, 2)), ([(2, 3), (2, 5)], 1, True, (2, 2, 5)),
+        ([(2, 3), (2, 5)], -1, True, (2, 2, 5)), ([(3, 2), (5, 2)], -2, True, (2, 5, 2)),
+    ],
+)
+def test_pad_tensors(mf, batch_sizes, dim, pad_start, expected_size):
+    """The reference's only unit test (tests/data/test_load.py:5-29: 12 shape cases), plus values."""
+    batch = [torch.rand(size) + 1.0 for size in batch_sizes]
+    padded = mf.data.pad_tensors(batch, dim=dim, pad_start=pad_start)
+    assert padded.size() == expected_size
+    small = batch[0]
+    region = padded[0]
+    sl = [slice(None)] * region.dim()
+    n = small.size(dim)
+    sl[dim % region.dim()] = slice(region.size(dim) - n, None) if pad_start else slice(0, n)
+    assert torch.equal(region[tuple(sl)], small) and int((region != 0).sum()) == small.numel()
+
+
+def test_collate_and_synthetic_batches(mf):
+    ex = [{"target": 5, "user": {"idx": 1, "pos_idx": [4, 9, 2]}, "item": {"idx": 4}, "neg_item": {"idx": 7}},
+          {"target": 1, "user": {"idx": 2, "pos_idx": [3]}, "item": {"idx": 3}, "neg_item": {"idx": 8}}]
+    b = mf.data.collate_interactions(ex)
+    assert b["user"]["pos_idx"].tolist() == [[4, 9, 2], [3, 0, 0]] and b["target"].dtype == torch.int64
+    syn = mf.data.SyntheticInteractions(100, 50, max_positives=8, seed=1).batch(16)
+    assert syn["user"]["pos_idx"].shape == (16, 8) and (syn["user"]["pos_idx"][:, 0] == syn["item"]["idx"]).all()
+    assert int(syn["item"]["idx"].min()) >= 1 and int(syn["neg_item"]["idx"].max()) < 50
