@@ -134,6 +134,16 @@ def timed(fn, n_steps: int, dist_on: bool) -> float:
     return dt
 
 
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), or None."""
+    try:
+        data = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())
+        return data["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def kernel_span(lib, name: str):
     tot = ctypes.c_double(0.0)
     n = lib.mf_timing_get(name.encode(), ctypes.byref(tot))
@@ -207,7 +217,8 @@ def main() -> None:
         flops = 2.0 * B * N * DIM                      # one B x N x d contraction per launch
         ach = flops / (dense[dom] * 1e-3) / 1e12
         train_roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                      "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                      "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                      "traffic": measured_traffic(dom) if (B, DIM, world) == (8192, 128, 1) else None,
                       "avg_ms": round(dense[dom], 4),
                       "all_kernels_avg_ms": {k: round(v, 4) for k, v in spans.items() if v}}
 
@@ -245,7 +256,8 @@ def main() -> None:
         ach = flops / (span * 1e-3) / 1e12
         topk_roof = {"kernel": "select_kernel<RetrievalPolicy>", "bound": "mfma", "achieved": round(ach, 2),
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                     "traffic": None, "avg_ms": round(span, 4)}
+                     "traffic": measured_traffic("topk_select") if (Q, DIM, world) == (1024, 128, 1) else None,
+                     "avg_ms": round(span, 4)}
 
     # --------------------------------------------------------------------- CPU leg ----
     cpu = None
