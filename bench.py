@@ -182,11 +182,14 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or os.environ.get("MF_BENCH_FORCE_DIST") == "1"   # the override rehearses the sharded path on one GPU
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.distributed.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
     mf = importlib.import_module("matrix-factorization-torch_amd")
     lib = mf._lib.lib()
@@ -198,6 +201,9 @@ def main() -> None:
     if dist_on:
         trainer = mf.distributed.ShardedTrainer(mf, device, args.optimizer, args.num_negatives,
                                                 num_users=NUM_USERS, num_items=NUM_ITEMS, dim=DIM, logq=logq_table(device))
+        span_u = trainer.user_hi - trainer.user_lo          # pairs are partitioned by user shard
+        for b in batches:
+            b["user"] = trainer.user_lo + b["user"] % span_u
     else:
         trainer = Trainer(mf, device, args.optimizer, args.num_negatives)
     for i in range(W):

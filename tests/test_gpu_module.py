@@ -135,3 +135,44 @@ def test_full_size_topk_properties(mf):
         pi.append(b)
     ms, mi = mf.retrieval.merge_topk(torch.stack(ps), torch.stack(pi), k)
     assert torch.equal(mi, i) and torch.equal(ms, s)
+
+
+def test_sharded_classes_on_one_rank_use_the_hip_path(mf):
+    """world_size 1 over RCCL: ShardedTrainer / ShardedIndex with HipOps reproduce the single-GPU API."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        nu, ni, d, b = 300, 500, 64, 64
+        tr = mf.distributed.ShardedTrainer(mf, DEV, "sgd", 0, num_users=nu, num_items=ni, dim=d, lr=0.1,
+                                           kind="InfomationNoiseContrastiveEstimationLoss")
+        g = torch.Generator().manual_seed(2)
+        batch = {"user": torch.randint(0, nu, (b,), generator=g).to(DEV), "item": torch.randint(0, ni, (2 * b,), generator=g).to(DEV),
+                 "target": torch.randint(1, 6, (b,), generator=g).to(DEV), "pos": torch.randint(0, ni, (b, 5), generator=g).to(DEV)}
+        towers = mf.models.init_towers(mf.models.ModelConfig(num_users=nu, num_items=ni, hidden_size=d), device=DEV)
+        with torch.no_grad():
+            towers["user"].weight.copy_(tr.user_table)
+            towers["item"].weight.copy_(tr.item_table)
+        opt = mf.optim.SparseSGD(towers.parameters(), lr=0.1)
+        fn = mf.losses.InfomationNoiseContrastiveEstimationLoss(num_negatives=0)
+        want = fn(towers["user"](batch["user"]), towers["item"](batch["item"]), batch["target"], item_idx=batch["item"],
+                  pos_idx=batch["pos"])
+        want.backward()
+        opt.step()
+        got = tr.step(batch)
+        assert float(got) == float(want)
+        torch.testing.assert_close(tr.item_table, towers["item"].weight.detach(), rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(tr.user_table, towers["user"].weight.detach(), rtol=1e-6, atol=1e-7)
+        q = tr.user_vectors(torch.arange(1, 9, device=DEV))
+        s1, i1 = mf.distributed.ShardedIndex(tr.item_shard(), tr.item_shard_base(), ni).search(q, 10)
+        s2, i2 = mf.retrieval.ItemIndex(tr.item_shard()).search(q, 10)
+        assert torch.equal(i1, i2) and torch.equal(s1, s2)
+    finally:
+        dist.destroy_process_group()
