@@ -95,17 +95,26 @@ MF_HD float mf_unorderable(unsigned k) {
  *     reference's (it only decides what torch.topk leaves unspecified).
  *     key = cls << 62 | orderable(cls==2 ? Dm : -Dm) << 30 | (0x3FFFFFFF - col)
  */
+/* the keys are built from two 32-bit halves so that the hot loops never touch 64-bit ALU ops */
+MF_HD unsigned mf_key_retrieval_hi(float score) { return mf_orderable(score); }
+MF_HD unsigned mf_key_retrieval_lo(unsigned col) { return ~col; }
 MF_HD unsigned long long mf_key_retrieval(float score, unsigned col) {
-    return ((unsigned long long)mf_orderable(score) << 32) | (unsigned long long)(~col);
+    return ((unsigned long long)mf_key_retrieval_hi(score) << 32) | (unsigned long long)mf_key_retrieval_lo(col);
 }
 MF_HD unsigned mf_key_retrieval_col(unsigned long long key) { return ~(unsigned)(key & 0xFFFFFFFFull); }
 MF_HD float mf_key_retrieval_score(unsigned long long key) { return mf_unorderable((unsigned)(key >> 32)); }
 
+MF_HD unsigned mf_key_mining_hi(float dm) {
+    const unsigned cls = (dm < 0.0f) ? 2u : 1u;
+    const unsigned ord = mf_orderable((dm < 0.0f) ? dm : -dm);
+    return (cls << 30) | (ord >> 2);
+}
+MF_HD unsigned mf_key_mining_lo(float dm, unsigned col) {
+    const unsigned ord = mf_orderable((dm < 0.0f) ? dm : -dm);
+    return (ord << 30) | (0x3FFFFFFFu - col);
+}
 MF_HD unsigned long long mf_key_mining(float dm, unsigned col) {
-    unsigned long long cls = (dm < 0.0f) ? 2ull : 1ull;
-    float k = (dm < 0.0f) ? dm : -dm;
-    return (cls << 62) | ((unsigned long long)mf_orderable(k) << 30) |
-           (unsigned long long)(0x3FFFFFFFu - col);
+    return ((unsigned long long)mf_key_mining_hi(dm) << 32) | (unsigned long long)mf_key_mining_lo(dm, col);
 }
 MF_HD unsigned mf_key_mining_col(unsigned long long key) {
     return 0x3FFFFFFFu - (unsigned)(key & 0x3FFFFFFFull);

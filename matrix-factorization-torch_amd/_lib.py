@@ -6,13 +6,14 @@ a contiguous fp32/int64 tensor on the GPU, the call raises.
 from __future__ import annotations
 
 import ctypes
+import os
 import pathlib
 import subprocess
 
 import torch
 
 _PKG = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libmf_hip.so"
+LIB_PATH = pathlib.Path(os.environ.get("MF_HIP_LIB", _PKG / "lib" / "libmf_hip.so"))   # override: A/B builds
 
 c_i64, c_int, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 

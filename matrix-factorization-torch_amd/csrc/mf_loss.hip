@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
         if (t0 + 1 < t1) mf_wait_vmcnt<L::NDMA>(); else mf_wait_vmcnt<0>();
         mf_block_barrier();
         if (t0 + 2 < t1) stage(t0 + 2);
-        acc = mf_tile_scores_interleaved<D, 32>(smem, xf, [](int) {});
+        acc = mf_tile_scores_interleaved<D, 32, (40 * 32 / D)>(smem, xf, [](int) {});
         for (int tj = t0; tj + 1 < t1; ++tj) {
             // queue, oldest first: [DMA(tj+1)] [stores(tj-2)] [DMA(tj+2)] [stores(tj-1)]
             if (tj + 2 >= t1) mf_wait_vmcnt<0>();
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
             mf_block_barrier();
             if (tj + 3 < t1) stage(tj + 3);
             te = tj;
-            const f32x16 acc_n = mf_tile_scores_interleaved<D, 32>(smem + ((tj + 1 - t0) % 3) * G::TILEB, xf, slice);
+            const f32x16 acc_n = mf_tile_scores_interleaved<D, 32, (40 * 32 / D)>(smem + ((tj + 1 - t0) % 3) * G::TILEB, xf, slice);
             acc = acc_n;
         }
         te = t1 - 1;
@@ -540,11 +540,13 @@ struct MiningPolicy {
         }
         return t;
     }
-    static __device__ __forceinline__ unsigned long long key(const Params& p, const Row& r, const Tile& t,
-                                                            float score, int e, int h, int64_t y) {
-        if ((t.mw >> mf_acc_row(e, h)) & 1u) return 0ull;   // hit, diagonal or padding column
+    static __device__ __forceinline__ bool key(const Params& p, const Row& r, const Tile& t, float score, int e, int h,
+                                               unsigned y, unsigned& hi, unsigned& lo) {
         const float L = mf_logit(r.nu, t.nv4[e >> 2][e & 3], score, r.sgn, p.sigma, t.lq4[e >> 2][e & 3]);
-        return mf_key_mining(L - r.lii, (unsigned)y);
+        const float dm = L - r.lii;
+        hi = mf_key_mining_hi(dm);
+        lo = mf_key_mining_lo(dm, y);
+        return !((t.mw >> mf_acc_row(e, h)) & 1u);          // hit, diagonal or padding column
     }
 };
 
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
             // stash layout is (lane = user, register = item row): transpose to (lane = item, register = user row)
             float* tr = reinterpret_cast<float*>(smem + L::TR) + wave * (33 * 32);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) tr[mf_acc_row(e, h) * 33 + c] = Lv[e];
+            for (int e = 0; e < 16; ++e) mf_lds_store_b32(tr + mf_acc_row(e, h) * 33 + c, Lv[e]);   // asm: no DMA drain
 #pragma unroll
             for (int e = 0; e < 16; ++e) Lv[e] = tr[c * 33 + mf_acc_row(e, h)];
 #pragma unroll

@@ -13,8 +13,8 @@
 //      are dropped by one compare.
 //   2. a surviving key is appended to the lane's PRIVATE LDS segment (one ds_write,
 //      the fill count lives in a register: no atomics, no cross-lane traffic).  The
-//      T-list is refreshed from the few new entries once per tile, outside the
-//      per-element branch (rare per lane, but "some lane of 64" is the common case).
+//      T-list takes only the best accepted rank of each tile (one branch-free insertion
+//      per tile; per-element insertion would run whenever "some lane of 64" needs it).
 //      A segment that could overflow on the next tile is filtered in place by its
 //      owner against the current tau_row (no sort needed).
 //   3. pathological inputs (e.g. all scores equal) defeat 1-2; then the wave selects
@@ -32,7 +32,7 @@
 static inline int mf_select_T(int k) { return k <= 4 ? 2 : k <= 8 ? 4 : k <= 16 ? 8 : k <= 20 ? 10 : k <= 24 ? 12 : k <= 32 ? 16 : 32; }
 static inline int mf_select_nslot(int d) { return d == 256 ? 2 : 3; }
 static inline int mf_select_capl(int d) {
-    const int ring = mf_select_nslot(d) * (32 * d * 4 + 1024);
+    const int ring = mf_select_nslot(d) * (32 * d * 4) + 4 * 1024;
     int capl = (160 * 1024 - ring - 1024) / (4 * 64 * 8) - 1;
     capl = capl > 64 ? 64 : capl;
     return capl & ~1;        // even capacity -> odd segment stride: lanes of a half hit distinct banks
@@ -76,9 +76,9 @@ template <int D>
 struct SelectLds {
     using G = TileGeom<D>;
     static constexpr int AUXB = 1024;                    // [4 x 128 B per-wave words][nv 128][logq 128][pad]
-    static constexpr int SLOT = G::TILEB + AUXB;
-    static constexpr int NSLOT = D == 256 ? 2 : 3;       // d = 256: 2-deep ring, 2 barriers per tile
-    static constexpr int RING = NSLOT * SLOT;
+    static constexpr int NSLOT = D == 256 ? 2 : 3;       // d = 256: 2-deep tile ring, 2 barriers per tile
+    static constexpr int AUX0 = NSLOT * G::TILEB;        // 4 side-input slots after the tile slots
+    static constexpr int RING = AUX0 + 4 * AUXB;
     static __host__ __device__ int seg(int capl) { return 64 * (capl + 1) * 8; }   // one wave's 64 lane-private segments
     static __host__ __device__ int bytes(int capl) { return RING + 4 * seg(capl) + 4 * 32 * 8; }
 };
@@ -89,7 +89,7 @@ struct SelectLds {
 //   static void stage_aux(P, aux, wave, t, x0)      issue them (side inputs of Y tile t for X rows x0..x0+31)
 //   static Row  row_init(P, x, valid)
 //   static Tile tile_init(P, row, aux, wave, c, h)  read the staged side inputs
-//   static u64  key(P, row, tile, score, e, h, y)   0 = never a candidate
+//   static bool key(P, row, tile, score, e, h, y, hi&, lo&)   false = never a candidate; (hi, lo) = key halves
 template <int D, int T, class Policy>
 __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp, SelectCommon sc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,58 +124,70 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
     int cnt = 0;
     if (lane < 32) floor64[lane] = 0ull;
 
-    auto stage = [&](int t, int slot_idx) {
-        char* slot = smem + slot_idx * L::SLOT;
-        mf_stage_tile<D>(slot, sc.Y, (int64_t)t * 32, sc.nY);
-        Policy::stage_aux(pp, slot + G::TILEB, wave, t, x0);
+    auto stage = [&](int t) {
+        const int kk = t - t0;
+        mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, sc.Y, (int64_t)t * 32, sc.nY);
+        Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t, x0);
     };
-    if (t0 < t1) stage(t0, 0);
-    if (t0 + 1 < t1) stage(t0 + 1, 1);
-    int cur = 0;
-    for (int ty = t0; ty < t1; ++ty) {
-        if (ty + 1 < t1) mf_wait_vmcnt<NWAIT>(); else mf_wait_vmcnt<0>();
-        mf_block_barrier();
-        if (L::NSLOT == 3 && ty + 2 < t1) stage(ty + 2, cur >= 1 ? cur - 1 : 2);
-        const char* slot = smem + cur * L::SLOT;
-        const int cur_slot = cur;
-        cur = cur + 1 == L::NSLOT ? 0 : cur + 1;
-        if ((ty - t0) % nsub == sub) {                  // else another wave of this X tile takes this Y tile
+    auto mine = [&](int t) { return (t - t0) % nsub == sub; };   // else another wave of this X tile takes tile t
 
-        const int64_t y0 = (int64_t)ty * 32;
-        RowFrag<D> yf;
-        mf_lds_frag<D>(yf, slot);
-        const f32x16 acc = mf_tile_scores<D>(yf, xf);
-        typename Policy::Tile tile = Policy::tile_init(pp, row, slot + G::TILEB, wave, c, h);
-        const int cnt0 = cnt;
+    // Software pipeline inside the wave (as in the loss forward): the MFMAs of tile t+1 are issued
+    // in the same basic block as the per-element key work of tile t (16 slices).
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    typename Policy::Tile tile;
+    unsigned tmaxr = 0u;                         // best rank this lane accepted in the current tile
+    const bool row_ok = x < sc.nX;               // padding rows (all-zero X) never collect candidates
+    unsigned y0 = 0u;                            // first Y row of the current tile (rows < 2^32)
+    // 32-bit-only fast path: rank (= high key word) against the row bound; the exact 64-bit floor of
+    // the degenerate path is checked by halves as well
+    auto slice = [&](int e) {
+        unsigned hi, lo;
+        const bool ok = Policy::key(pp, row, tile, acc[e], e, h, y0 + (unsigned)mf_acc_row(e, h), hi, lo);
+        const unsigned fhi = (unsigned)(fl >> 32), flo = (unsigned)fl;
+        const bool above_floor = hi > fhi || (hi == fhi && lo >= flo);
+        if (ok && row_ok && hi >= tau_row && above_floor) {
+            mf_lds_store_b64(buf + lane * (CAPL + 1) + cnt, lo, hi);     // asm store: must not drain the DMA queue
+            ++cnt;
+            tmaxr = max(tmaxr, hi);
+        }
+    };
+    // In-place filter of the lane's own segment against the current bound, 8 independent LDS reads
+    // per round (writes only go to positions already read).
+    auto filter_segment = [&]() {
+        int w = 0;
+        for (int t0f = 0; __any(t0f < cnt); t0f += 8) {
+            unsigned long long kk[8];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t y = y0 + mf_acc_row(e, h);
-            const unsigned long long key = Policy::key(pp, row, tile, acc[e], e, h, y);
-            if (key != 0ull && (unsigned)(key >> 32) >= tau_row && key >= fl) {
-                MF_BUF(lane, cnt) = key;
-                ++cnt;
-            }
+            for (int j = 0; j < 8; ++j) kk[j] = (t0f + j < cnt) ? MF_BUF(lane, t0f + j) : 0ull;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (kk[j] != 0ull && (unsigned)(kk[j] >> 32) >= tau_row && kk[j] >= fl) MF_BUF(lane, w++) = kk[j];
         }
-        // refresh the T-list from this tile's accepted keys (few per lane)
-        for (int i = cnt0; __any(i < cnt); ++i) {
-            if (i < cnt) {
-                const unsigned r = (unsigned)(MF_BUF(lane, i) >> 32);
-                if (r > tl[T - 1]) mf_tlist_insert<T>(tl, r);
+        cnt = w;
+    };
+    // after the slices of a tile: refresh the bound, keep the segments from overflowing.
+    // Only the tile's BEST accepted rank enters the lane's T-list: its entries are then T distinct
+    // accepted elements (one per tile), so tl[T-1] stays a valid -- and, with the row's best spread
+    // over many tiles, nearly tight -- lower bound, at the cost of one branch-free insertion per tile.
+    // While the lists fill (the first T tiles of the chunk) every accepted key is inserted instead.
+    auto settle = [&](int cnt0, bool warm) {
+        if (warm) {
+            for (int i = cnt0; __any(i < cnt); ++i) {
+                if (i < cnt) {
+                    const unsigned r = (unsigned)(MF_BUF(lane, i) >> 32);
+                    if (r > tl[T - 1]) mf_tlist_insert<T>(tl, r);
+                }
             }
+        } else if (tmaxr > tl[T - 1]) {
+            mf_tlist_insert<T>(tl, tmaxr);
         }
+        tmaxr = 0u;
         {
             const unsigned own = tl[T - 1];
             tau_row = min(own, mf_shfl_xor32u(own));
         }
         if (__any(cnt > CAPL - 16)) {
-            {   // drop, in place, what has fallen below the row's current bound
-                int w = 0;
-                for (int t = 0; t < cnt; ++t) {
-                    const unsigned long long kk = MF_BUF(lane, t);
-                    if ((unsigned)(kk >> 32) >= tau_row && kk >= fl) MF_BUF(lane, w++) = kk;
-                }
-                cnt = w;
-            }
+            filter_segment();   // drop, in place, what has fallen below the row's current bound
             // rare: a row still too full -> exact selection of its k best keys (wave-local)
             const unsigned long long ovb = __ballot(cnt > CAPL - 16);
             unsigned rows = (unsigned)(ovb | (ovb >> 32));
@@ -211,22 +223,47 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
             }
             fl = floor64[c];
         }
-        }
-        if (L::NSLOT == 2) {            // the slot just read is the one tile ty+2 lands in
-            mf_block_barrier();
-            if (ty + 2 < t1) stage(ty + 2, cur_slot);
+    };
+
+    if (t0 < t1) {
+        stage(t0);
+        if (t0 + 1 < t1) stage(t0 + 1);
+        if (t0 + 1 < t1) mf_wait_vmcnt<NWAIT>(); else mf_wait_vmcnt<0>();
+        mf_block_barrier();
+        if (L::NSLOT == 3 && t0 + 2 < t1) stage(t0 + 2);
+        if (mine(t0)) acc = mf_tile_scores_interleaved<D, 16, (48 * 32 / D)>(smem, xf, [](int) {});
+        for (int ty = t0; ty < t1; ++ty) {
+            const bool cur = mine(ty), nxt = ty + 1 < t1 && mine(ty + 1);
+            if (L::NSLOT == 2) {                      // tile ty's slot is free now: tile ty+2 lands there
+                mf_block_barrier();
+                if (ty + 2 < t1) stage(ty + 2);
+            }
+            if (ty + 1 < t1) {
+                if (ty + 2 < t1) mf_wait_vmcnt<NWAIT>(); else mf_wait_vmcnt<0>();
+                mf_block_barrier();
+                if (L::NSLOT == 3 && ty + 3 < t1) stage(ty + 3);
+            }
+            const int cnt0 = cnt;
+            if (cur) {
+                tile = Policy::tile_init(pp, row, smem + L::AUX0 + ((ty - t0) & 3) * L::AUXB, wave, c, h);
+                y0 = (unsigned)ty * 32u;
+            }
+            const char* next_tile = smem + ((ty + 1 - t0) % L::NSLOT) * G::TILEB;
+            if (cur && nxt) {
+                const f32x16 acc_n = mf_tile_scores_interleaved<D, 16, (48 * 32 / D)>(next_tile, xf, slice);
+                acc = acc_n;
+            } else if (cur) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) slice(e);
+            } else if (nxt) {
+                acc = mf_tile_scores_interleaved<D, 16, (48 * 32 / D)>(next_tile, xf, [](int) {});
+            }
+            if (cur) settle(cnt0, (ty - t0) < (T + 1) * nsub);
         }
     }
 
     // final filter with the final bound, then ship every row's survivors
-    {
-        int w = 0;
-        for (int t = 0; t < cnt; ++t) {
-            const unsigned long long kk = MF_BUF(lane, t);
-            if ((unsigned)(kk >> 32) >= tau_row && kk >= fl) MF_BUF(lane, w++) = kk;
-        }
-        cnt = w;
-    }
+    filter_segment();
     const int n_other = __shfl_xor(cnt, 32, 64);
     const int64_t set = (int64_t)chunk * nsub + sub;
     unsigned long long* dst = sc.cand + (set * sc.Xp + x) * (2 * CAPL) + (h ? n_other : 0);

@@ -46,17 +46,30 @@ __device__ __forceinline__ void mf_stage_tile(char* lds_tile, const float* __res
     using G = TileGeom<D>;
     const int lane = mf_lane();
     const int wave = mf_wave_id();
+    const char* tile_src = reinterpret_cast<const char*>(Y) + y0 * G::ROWB;   // wave-uniform
+    if (y0 + 32 <= nY) {
+        // interior tile: the per-lane offsets below depend only on (wave, lane) -> hoisted out of the tile loop
 #pragma unroll
-    for (int q = 0; q < G::PPW; ++q) {
-        const int p = wave * G::PPW + q;
-        const int off = p * 1024 + lane * 16;
-        const int row = off / G::ROWB;
-        const int chp = (off % G::ROWB) >> 4;
-        const int ch = chp ^ G::swz(row);
-        int64_t y = y0 + row;
-        y = y < nY ? y : nY - 1;
-        const char* src = reinterpret_cast<const char*>(Y + y * D) + ch * 16;
-        __builtin_amdgcn_global_load_lds((mf_glb_ptr)src, (mf_lds_ptr)(lds_tile + p * 1024), 16, 0, 0);
+        for (int q = 0; q < G::PPW; ++q) {
+            const int p = wave * G::PPW + q;
+            const int off = p * 1024 + lane * 16;
+            const int row = off / G::ROWB;
+            const int ch = ((off % G::ROWB) >> 4) ^ G::swz(row);
+            __builtin_amdgcn_global_load_lds((mf_glb_ptr)(tile_src + row * G::ROWB + ch * 16),
+                                             (mf_lds_ptr)(lds_tile + p * 1024), 16, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < G::PPW; ++q) {
+            const int p = wave * G::PPW + q;
+            const int off = p * 1024 + lane * 16;
+            const int row = off / G::ROWB;
+            const int ch = ((off % G::ROWB) >> 4) ^ G::swz(row);
+            int64_t y = y0 + row;
+            y = y < nY ? y : nY - 1;                                           // ragged last tile: clamp (masked later)
+            const char* src = reinterpret_cast<const char*>(Y + y * D) + ch * 16;
+            __builtin_amdgcn_global_load_lds((mf_glb_ptr)src, (mf_lds_ptr)(lds_tile + p * 1024), 16, 0, 0);
+        }
     }
 }
 
@@ -66,6 +79,22 @@ __device__ __forceinline__ void mf_stage_small(char* lds_dst, const void* src, i
     if (lane * 16 < nbytes)
         __builtin_amdgcn_global_load_lds((mf_glb_ptr)(reinterpret_cast<const char*>(src) + lane * 16),
                                          (mf_lds_ptr)lds_dst, 16, 0, 0);
+}
+
+// LDS stores that must not drain the DMA queue: while a global_load_lds is in flight, hipcc puts
+// `s_waitcnt vmcnt(0)` in front of EVERY compiler-visible LDS store (it cannot prove the store does
+// not alias the DMA destination).  These go through inline asm instead; the "memory" clobber keeps
+// their order against the surrounding C++ accesses, and the LDS itself executes a wave's
+// operations in order.
+__device__ __forceinline__ unsigned mf_lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void mf_lds_store_b64(void* p, unsigned lo, unsigned hi) {
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    asm volatile("ds_write_b64 %0, %1" ::"v"(mf_lds_addr(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ void mf_lds_store_b32(void* p, float v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(mf_lds_addr(p)), "v"(v) : "memory");
 }
 
 template <int N>
@@ -95,8 +124,9 @@ __device__ __forceinline__ void mf_lds_frag(RowFrag<D>& f, const char* lds_tile)
 // groups: a wave issues in order, and a dependent fp32 MFMA occupies the matrix pipe for 64
 // cycles, so ~14 VALU issue slots per MFMA are free if -- and only if -- the VALU instructions
 // sit between the MFMAs in program order.  `slice(s)`, s = 0 .. NSLICE-1, is that work, cut in
-// NSLICE pieces; sched_barrier pins the interleave (hipcc otherwise clusters the MFMAs).
-template <int D, int NSLICE, class Slice>
+// NSLICE pieces; VPM = VALU/SALU instructions to place behind each MFMA.  sched_barrier /
+// sched_group_barrier pin the interleave (hipcc otherwise clusters the MFMAs).
+template <int D, int NSLICE, int VPM, class Slice>
 __device__ __forceinline__ f32x16 mf_tile_scores_interleaved(const char* lds_tile, const RowFrag<D>& x, Slice&& slice) {
     using G = TileGeom<D>;
     constexpr int NG = D / 8;
@@ -115,11 +145,17 @@ __device__ __forceinline__ f32x16 mf_tile_scores_interleaved(const char* lds_til
         if (g + 1 < NG) a_next = *reinterpret_cast<const f32x4*>(rowp + (((2 * (g + 1) + h) ^ sw) << 4));
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], x.v[g][t], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
         const int s_end = (g + 1) * NSLICE / NG;
 #pragma unroll
         for (int sidx = g * NSLICE / NG; sidx < s_end; ++sidx) slice(sidx);
         s_done = s_end;
+        // inside this group: one MFMA, then a share of the group's VALU/SALU/LDS work, four times
+        // (a burst of VALU after four back-to-back MFMAs would only overlap the last of them)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, VPM, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     (void)s_done;

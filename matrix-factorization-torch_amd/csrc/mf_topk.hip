@@ -31,10 +31,11 @@ struct RetrievalPolicy {
     static __device__ __forceinline__ Tile tile_init(const Params&, const Row&, const char* aux, int wave, int c, int) {
         return Tile{reinterpret_cast<const uint32_t*>(aux + wave * 128)[c]};
     }
-    static __device__ __forceinline__ unsigned long long key(const Params& p, const Row&, const Tile& t, float score,
-                                                            int e, int h, int64_t y) {
-        if ((t.ew >> mf_acc_row(e, h)) & 1u) return 0ull;
-        return y < p.nY ? mf_key_retrieval(score, (unsigned)y) : 0ull;
+    static __device__ __forceinline__ bool key(const Params& p, const Row&, const Tile& t, float score, int e, int h,
+                                               unsigned y, unsigned& hi, unsigned& lo) {
+        hi = mf_key_retrieval_hi(score);
+        lo = mf_key_retrieval_lo(y);
+        return !((t.ew >> mf_acc_row(e, h)) & 1u) && y < (unsigned)p.nY;
     }
 };
 
