@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
             // stash layout is (lane = user, register = item row): transpose to (lane = item, register = user row)
             float* tr = reinterpret_cast<float*>(smem + L::TR) + wave * (33 * 32);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mf_lds_store_b32(tr + mf_acc_row(e, h) * 33 + c, Lv[e]);   // asm: no DMA drain
+            for (int e = 0; e < 16; ++e) tr[mf_acc_row(e, h) * 33 + c] = Lv[e];
 #pragma unroll
             for (int e = 0; e < 16; ++e) Lv[e] = tr[c * 33 + mf_acc_row(e, h)];
 #pragma unroll
