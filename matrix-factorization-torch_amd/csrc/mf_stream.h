@@ -137,12 +137,15 @@ __device__ __forceinline__ f32x16 mf_tile_scores_interleaved(const char* lds_til
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    // fragments are read two groups (8 MFMAs) ahead of their use
     f32x4 a_next = *reinterpret_cast<const f32x4*>(rowp + ((h ^ sw) << 4));
+    f32x4 a_next2 = *reinterpret_cast<const f32x4*>(rowp + (((NG > 1 ? 2 : 0) + h) ^ sw) * 16);
     int s_done = 0;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const f32x4 a = a_next;
-        if (g + 1 < NG) a_next = *reinterpret_cast<const f32x4*>(rowp + (((2 * (g + 1) + h) ^ sw) << 4));
+        a_next = a_next2;
+        if (g + 2 < NG) a_next2 = *reinterpret_cast<const f32x4*>(rowp + (((2 * (g + 2) + h) ^ sw) << 4));
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], x.v[g][t], acc, 0, 0, 0);
         const int s_end = (g + 1) * NSLICE / NG;
