@@ -173,15 +173,15 @@ __device__ __forceinline__ void mf_lds_cols(float (&v)[D / 32], const char* lds_
     using G = TileGeom<D>;
     const char* rowp = lds_tile + row * G::ROWB;
     const int sw = G::swz(row);
-    if (D == 128) {
+    if constexpr (D == 128) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(rowp + ((c ^ sw) << 4));
         v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-    } else if (D == 256) {
+    } else if constexpr (D == 256) {
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(rowp + (((2 * c) ^ sw) << 4));
         const f32x4 t1 = *reinterpret_cast<const f32x4*>(rowp + (((2 * c + 1) ^ sw) << 4));
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] = t0[j]; v[4 + j] = t1[j]; }
-    } else if (D == 64) {
+    } else if constexpr (D == 64) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 t = *reinterpret_cast<const f32x2*>(rowp + ((((c >> 1) ^ sw) << 4) | ((c & 1) << 3)));
         v[0] = t[0]; v[1] = t[1];
