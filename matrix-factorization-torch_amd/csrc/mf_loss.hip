@@ -50,7 +50,7 @@ struct LossWs {
     int M;
     int32_t* colslot;
     uint32_t* ubits;
-    uint32_t *maskW, *maskTW;
+    uint32_t* maskW;
     float *part, *stats, *rowloss, *rowc, *dpart, *stash;
     unsigned long long* cand;
     int32_t *cand_cnt, *sel, *sel_cnt;
@@ -91,7 +91,6 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.colslot = a.take<int32_t>((size_t)w.Np);
     w.ubits = a.take<uint32_t>((size_t)(w.M / 32) * w.Bp);
     w.maskW = a.take<uint32_t>((size_t)w.NT * w.Bp);
-    w.maskTW = a.take<uint32_t>((size_t)w.BT * w.Np);
     w.part = a.take<float>((size_t)w.nsplit_f * NSTAT * w.Bp);
     w.stats = a.take<float>((size_t)NSTAT * w.Bp);
     w.rowloss = a.take<float>((size_t)MF_NUM_KINDS * w.Bp);
@@ -142,7 +141,6 @@ __global__ __launch_bounds__(256) void diag_kernel(const float* __restrict__ u, 
 
 // ------------------------------------------------------------------ hit masks --
 // maskW [tj][i]  bit c : item column 32 tj + c is NOT a valid negative of user i
-// maskTW[ti][j]  bit r : user 32 ti + r  x  item j   (same bit, transposed words)
 //
 // The reference compares every (user, column, positive) triple (B x N x P bools,
 // losses.py:108).  Here:
@@ -153,8 +151,7 @@ __global__ __launch_bounds__(256) void diag_kernel(const float* __restrict__ u, 
 //      ubits[slot / 32][user] -- positives absent from the batch cost nothing more;
 //   3. the B x N membership tests are then a branch-free sweep: one coalesced word
 //      load and a shift per (user, column).  A half-wave holds 32 users on its lanes
-//      and walks column tiles; each lane ORs its own maskW word and the ballot of a
-//      column over the 32 lanes IS that column's maskTW word.
+//      and walks column tiles; each lane ORs its own maskW word.
 static constexpr long long HT_EMPTY = (long long)0x8080808080808080ull;   // memset(0x80)
 
 __device__ __forceinline__ unsigned ht_hash(long long id, unsigned slots_mask) {
@@ -199,29 +196,23 @@ __global__ __launch_bounds__(256) void ubits_kernel(const int64_t* __restrict__ 
 
 __global__ __launch_bounds__(256) void mask_sweep_kernel(const int32_t* __restrict__ colslot,
                                                          const uint32_t* __restrict__ ubits, int64_t B, int64_t N,
-                                                         int64_t Bp, int64_t Np, int NT,
-                                                         uint32_t* __restrict__ maskW, uint32_t* __restrict__ maskTW) {
+                                                         int64_t Bp, int NT, uint32_t* __restrict__ maskW) {
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
-    const int ti = blockIdx.x;
-    const int64_t i = (int64_t)ti * 32 + c;
+    const int64_t i = (int64_t)blockIdx.x * 32 + c;
     const bool user_ok = i < B;
     const int hw = (threadIdx.x >> 6) * 2 + h;            // half-wave id inside the block: 0..7
     for (int tj = blockIdx.y * 8 + hw; tj < NT; tj += 8 * gridDim.y) {
         const int64_t j0 = (int64_t)tj * 32;
         const int myslot = j0 + c < N ? colslot[j0 + c] : -1;
-        uint32_t word = 0u, tword = 0u;
+        uint32_t word = 0u;
 #pragma unroll 8
         for (int c2 = 0; c2 < 32; ++c2) {
             const int slot = __shfl(myslot, c2 + 32 * h, 64);
-            bool hit = true;                                // padding column / padding user: never a negative
+            uint32_t hit = 1u;                              // padding column / padding user: never a negative
             if (slot >= 0 && user_ok) hit = (ubits[(int64_t)(slot >> 5) * Bp + i] >> (slot & 31)) & 1u;
-            word |= (hit ? 1u : 0u) << c2;
-            const unsigned long long bal = __ballot(hit);
-            const uint32_t mine = h ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-            if (c == c2) tword = mine;
+            word |= hit << c2;
         }
         maskW[(int64_t)tj * Bp + i] = word;
-        maskTW[(int64_t)ti * Np + j0 + c] = tword;
     }
 }
 
@@ -338,7 +329,7 @@ __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
     // The statistics of one tile, cut in 32 slices so they can be threaded between the MFMAs of
     // the next tile: slices 0..15 turn score e into logit e (and stash it), slices 16..31 fold
     // logit e into the running statistics.
-    float Lg[16];
+    float Lg[16], Ls[4];
     float tmax = -FLT_MAX, nmx = -FLT_MAX;
     uint32_t mw = 0u;
     f32x4 nv4 = {0.f, 0.f, 0.f, 0.f}, lq4 = {0.f, 0.f, 0.f, 0.f};
@@ -359,9 +350,10 @@ __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
             Lg[e] = mf_logit(nu_i, nv4[r], acc[e], s_i, p.sigma, lq4[r]);
             const bool ok = !((mw >> mf_acc_row(e, h)) & 1u);
             tmax = fmaxf(tmax, ok ? Lg[e] : -FLT_MAX);
+            Ls[r] = ok ? Lg[e] : -INFINITY;     // masked logits: every dloss/dL of the backward is then exactly 0 there
             if (r == 3) {   // stash 4 logits of the block for the backward sweeps
                 float* blk = p.stash + ((int64_t)(i0 / 32 + wave) * p.NT + te) * 1024 + lane * 4;
-                *reinterpret_cast<f32x4*>(blk + q * 256) = f32x4{Lg[e - 3], Lg[e - 2], Lg[e - 1], Lg[e]};
+                *reinterpret_cast<f32x4*>(blk + q * 256) = f32x4{Ls[0], Ls[1], Ls[2], Ls[3]};
             }
         } else {
             const int e = sidx - 16;
@@ -668,34 +660,38 @@ __device__ __forceinline__ float g_of(int gmode, float x) {
     return x >= 0.f ? r : e * r;
 }
 
-// The forward stashes the logits of every 32 x 32 (user tile, item tile) block in HBM
-// (B x N fp32: 0.5 GB at B = 8192 -- MI355X has 288 GB) so that the two backward
-// sweeps only contract: they never recompute the score tile.  Block (ti, tj) is 4 KiB:
-// [q = e / 4][lane][e % 4] in the forward's accumulator layout (lane = user), i.e.
-// four whole-KiB coalesced stores per tile and a linear LDS-DMA on the way back.
+// The forward stashes the MASKED logits (-inf where the column is not a valid negative) of every
+// 32 x 32 (user tile, item tile) block in HBM (B x N fp32: 0.5 GB at B = 8192 -- MI355X has
+// 288 GB) so that the two backward sweeps only contract: they never recompute the score tile.
+// Block (ti, tj) is 4 KiB: [q = e / 4][lane][e % 4] in the forward's accumulator layout
+// (lane = user), i.e. four whole-KiB coalesced stores per tile and a linear LDS-DMA on the way
+// back.  The dU sweep turns each block into G' = dloss/dL (one exp / step / sigmoid per element,
+// diagonal patched) and writes it back IN PLACE, so the dV sweep, which runs after it, reads G'
+// and has no per-element arithmetic at all: on gfx950 fp32 MFMA and VALU share the SIMD's FP32
+// lanes (a VALU op costs ~2 cycles of MFMA throughput, a transcendental ~17 -- measured), so
+// every VALU instruction removed from these loops is MFMA time won back.
 struct BwdParams {
-    const float *u, *v, *rowc, *stash;
-    const uint32_t *maskW, *maskTW;
+    const float *u, *v, *rowc;
+    float* stash;
     float* dpart;
     int64_t B, N, Bp, Np;
-    int NT, YT, tps, gmode;
+    int NT, YT, tps;
 };
 
 template <int D, bool XU>
 struct BwdLds {
     using G = TileGeom<D>;
-    static constexpr int LT = G::TILEB;                  // 4 x 4 KiB logits blocks (one per wave)
-    static constexpr int AUX = G::TILEB + 4 * 4096;      // 4 x 128 B mask words, then 4 x 128 B rowc (dV)
-    static constexpr int SLOT = AUX + 1024;
+    static constexpr int LT = G::TILEB;                  // 4 x 4 KiB stash blocks (one per wave)
+    static constexpr int SLOT = G::TILEB + 4 * 4096;
     static constexpr int EXTRA = XU ? 0 : 4 * 33 * 32 * 4;
     static constexpr int NSLOT = (3 * SLOT + EXTRA <= 160 * 1024) ? 3 : 2;   // d = 256: 2-deep ring, 2 barriers
     static constexpr int TR = NSLOT * SLOT;              // dV: per-wave 32 x 33 transpose scratch
     static constexpr int BYTES = TR + EXTRA;
-    static constexpr int NWAIT = G::PPW + 4 + (XU ? 1 : 2);   // DMA instructions per wave per stage
+    static constexpr int NDMA = G::PPW + 4;              // DMA instructions per wave per stage
 };
 
-// XU = true : lanes hold users, item tiles stream, result d loss / d u
-// XU = false: lanes hold items, user tiles stream, result d loss / d v
+// XU = true : lanes hold users, item tiles stream, result d loss / d u   (reads L, writes G' back)
+// XU = false: lanes hold items, user tiles stream, result d loss / d v   (reads G')
 template <int D, bool XU, int GMODE>
 __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -719,67 +715,58 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
         for (int e = 0; e < 16; ++e) dacc[mb][e] = 0.f;
     float rsum = 0.f;
 
+    auto block_of = [&](int t) { return XU ? ((int64_t)xt * p.NT + t) : ((int64_t)t * p.NT + xt); };
     auto stage = [&](int t, int slot_idx) {
         char* slot = smem + slot_idx * L::SLOT;
         mf_stage_tile<D>(slot, Y, (int64_t)t * 32, nY);
-        const int64_t blk = XU ? ((int64_t)xt * p.NT + t) : ((int64_t)t * p.NT + xt);
-        const char* lsrc = reinterpret_cast<const char*>(p.stash + blk * 1024) + lane * 16;
+        const char* lsrc = reinterpret_cast<const char*>(p.stash + block_of(t) * 1024) + lane * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             __builtin_amdgcn_global_load_lds((mf_glb_ptr)(lsrc + q * 1024),
                                              (mf_lds_ptr)(slot + L::LT + wave * 4096 + q * 1024), 16, 0, 0);
-        const uint32_t* mw = XU ? p.maskW + (int64_t)t * p.Bp + x0 : p.maskTW + (int64_t)t * p.Np + x0;
-        mf_stage_small(slot + L::AUX + wave * 128, mw, 128);
-        if (!XU) mf_stage_small(slot + L::AUX + 512 + wave * 128, p.rowc + (int64_t)wave * p.Bp + (int64_t)t * 32, 128);
     };
     if (t0 < t1) stage(t0, 0);
     if (t0 + 1 < t1) stage(t0 + 1, 1);
     int cur = 0;
     for (int ty = t0; ty < t1; ++ty) {
-        if (ty + 1 < t1) mf_wait_vmcnt<L::NWAIT>(); else mf_wait_vmcnt<0>();
+        // queue, oldest first: [DMA(ty)] [G stores(ty-2)] [DMA(ty+1)] [G stores(ty-1)]   (stores: dU only)
+        if (ty + 1 >= t1) mf_wait_vmcnt<0>();
+        else if (!XU || ty == t0) mf_wait_vmcnt<L::NDMA>();
+        else mf_wait_vmcnt<L::NDMA + 4>();
         mf_block_barrier();
         if (L::NSLOT == 3 && ty + 2 < t1) stage(ty + 2, cur >= 1 ? cur - 1 : 2);
         const char* slot = smem + cur * L::SLOT;
         const char* lt = slot + L::LT + wave * 4096;
-        const int64_t y0 = (int64_t)ty * 32;
-        const uint32_t mw = reinterpret_cast<const uint32_t*>(slot + L::AUX + wave * 128)[c];
-        float Lv[16];
+        float Gv[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 t4 = *reinterpret_cast<const f32x4*>(lt + q * 1024 + lane * 16);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) Lv[4 * q + t] = t4[t];
+            for (int t = 0; t < 4; ++t) Gv[4 * q + t] = t4[t];
         }
-        f32x4 ya4[4], yb4[4], yc4[4], yd4[4];
-        if (!XU) {
-            // stash layout is (lane = user, register = item row): transpose to (lane = item, register = user row)
+        if (XU) {
+            // masked logits -> G' (masked entries are -inf: exp / step / sigmoid give exactly 0)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Gv[e] = xc * g_of(GMODE, (Gv[e] - xa) + xb);
+            if (ty == xt) {             // only the diagonal tile holds the user's own positive
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (mf_acc_row(e, h) == c) Gv[e] = xd;
+            }
+            float* blk = p.stash + block_of(ty) * 1024 + lane * 4;      // hand G' to the dV sweep, in place
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(blk + q * 256) = f32x4{Gv[4 * q], Gv[4 * q + 1], Gv[4 * q + 2], Gv[4 * q + 3]};
+        } else {
+            // block layout is (lane = user, register = item row): transpose to (lane = item, register = user row)
             float* tr = reinterpret_cast<float*>(smem + L::TR) + wave * (33 * 32);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) tr[mf_acc_row(e, h) * 33 + c] = Lv[e];
+            for (int e = 0; e < 16; ++e) tr[mf_acc_row(e, h) * 33 + c] = Gv[e];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Lv[e] = tr[c * 33 + mf_acc_row(e, h)];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const char* rc = slot + L::AUX + 512 + (8 * q + 4 * h) * 4;
-                ya4[q] = *reinterpret_cast<const f32x4*>(rc);
-                yb4[q] = *reinterpret_cast<const f32x4*>(rc + 128);
-                yc4[q] = *reinterpret_cast<const f32x4*>(rc + 256);
-                yd4[q] = *reinterpret_cast<const f32x4*>(rc + 384);
-            }
+            for (int e = 0; e < 16; ++e) Gv[e] = tr[c * 33 + mf_acc_row(e, h)];
         }
-        float Gv[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int q = e >> 2, t = e & 3;
-            const int64_t y = y0 + mf_acc_row(e, h);
-            const float a = XU ? xa : ya4[q][t], b = XU ? xb : yb4[q][t];
-            const float cg = XU ? xc : yc4[q][t], gd = XU ? xd : yd4[q][t];
-            float g = cg * g_of(GMODE, (Lv[e] - a) + b);
-            if ((mw >> mf_acc_row(e, h)) & 1u) g = 0.f;
-            if (x == y) g = gd;
-            Gv[e] = g;
-            rsum += g;
-        }
+        for (int e = 0; e < 16; ++e) rsum += Gv[e];
         // dX[m][x] += sum_y Y[y][m] * G[y][x]   (the G tile is already a B operand)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -956,8 +943,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
         if (gy > 16) gy = 16;
         if (gy * w.BT < 1024) gy = (1024 + w.BT - 1) / w.BT;   // enough blocks when B is small
         if (gy > (w.NT + 7) / 8) gy = (w.NT + 7) / 8;
-        mask_sweep_kernel<<<dim3((unsigned)w.BT, (unsigned)gy), 256, 0, s>>>(w.colslot, w.ubits, B, N, w.Bp, w.Np, w.NT,
-                                                                            w.maskW, w.maskTW);
+        mask_sweep_kernel<<<dim3((unsigned)w.BT, (unsigned)gy), 256, 0, s>>>(w.colslot, w.ubits, B, N, w.Bp, w.NT, w.maskW);
     }
     // logq is read by whole float4s up to the padded width: keep a zero-padded copy in ws
     // (all zeros when there is no logQ correction: L - 0 is exact, and the kernels stay branch-free)
@@ -1020,13 +1006,13 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
                                                                                         w.Bp, gmode, du, dv);
         });
     } else {
-        BwdParams bp{u, v, w.rowc, w.stash, w.maskW, w.maskTW, w.dpart, B, N, w.Bp, w.Np, w.NT, 0, 0, gmode};
+        BwdParams bp{u, v, w.rowc, w.stash, w.dpart, B, N, w.Bp, w.Np, w.NT, 0, 0};
         MF_DISPATCH_D(d, {
             bp.YT = w.NT; bp.tps = w.tps_u;
             MF_TIMED("loss_bwd_du", s, (launch_bwd<D, true>(gmode, dim3((unsigned)(w.BT / 4), (unsigned)w.nsplit_u), bp, s)));
             sum_parts_kernel<<<dim3((unsigned)((B * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_u, B, w.Bp, D, du);
             bp.YT = w.BT; bp.tps = w.tps_v;
-            MF_TIMED("loss_bwd_dv", s, (launch_bwd<D, false>(gmode, dim3((unsigned)(w.NT / 4), (unsigned)w.nsplit_v), bp, s)));
+            MF_TIMED("loss_bwd_dv", s, (launch_bwd<D, false>(G_EXP, dim3((unsigned)(w.NT / 4), (unsigned)w.nsplit_v), bp, s)));
             sum_parts_kernel<<<dim3((unsigned)((N * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_v, N, w.Np, D, dv);
         });
     }
