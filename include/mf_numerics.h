@@ -58,13 +58,18 @@ MF_HD float mf_half_sqdist(float nu, float nv, float dot) {
     return 0.5f * sq;
 }
 
-/* logits[i][j] = ((-D) * sign(target_i)) * sigma  (losses.py:181-183), then our
- * optional logQ correction L -= log q_j (no reference counterpart). */
+/* logits[i][j] = -D_ij * sign(target_i) * sigma (losses.py:181-183) [- log q_j: our optional logQ
+ * correction, no reference counterpart; SURVEY 0.3], evaluated as two fused multiply-adds on the
+ * chain products:
+ *     L = fma(sigma*s, dot, fma(-0.5*sigma*s, nu + nv, -logq))
+ * (D = 0.5 (nu + nv - 2 dot) expanded).  Three VALU instructions per element instead of eight:
+ * on gfx950 every VALU instruction in an MFMA loop costs matrix throughput.  cdist's clamp of
+ * tiny negative squared distances is not reproduced here (|effect| <= 1e-7 * sigma); the
+ * AlignmentLoss value uses mf_half_sqdist, which keeps it. */
 MF_HD float mf_logit(float nu, float nv, float dot, float sgn, float sigma, float logq) {
-    float l = -mf_half_sqdist(nu, nv, dot);
-    l = l * sgn;
-    l = l * sigma;
-    return l - logq;
+    const float as = sigma * sgn;
+    const float hs = -0.5f * as;
+    return MF_FMAF(as, dot, MF_FMAF(hs, nu + nv, -logq));
 }
 
 MF_HD float mf_sign(float t) { return (t > 0.0f) ? 1.0f : ((t < 0.0f) ? -1.0f : 0.0f); }
@@ -106,11 +111,11 @@ MF_HD float mf_key_retrieval_score(unsigned long long key) { return mf_unorderab
 
 MF_HD unsigned mf_key_mining_hi(float dm) {
     const unsigned cls = (dm < 0.0f) ? 2u : 1u;
-    const unsigned ord = mf_orderable((dm < 0.0f) ? dm : -dm);
+    const unsigned ord = mf_orderable((dm < 0.0f) ? dm : (0.0f - dm));   /* 0 - dm: -0 and +0 give the same key */
     return (cls << 30) | (ord >> 2);
 }
 MF_HD unsigned mf_key_mining_lo(float dm, unsigned col) {
-    const unsigned ord = mf_orderable((dm < 0.0f) ? dm : -dm);
+    const unsigned ord = mf_orderable((dm < 0.0f) ? dm : (0.0f - dm));
     return (ord << 30) | (0x3FFFFFFFu - col);
 }
 MF_HD unsigned long long mf_key_mining(float dm, unsigned col) {

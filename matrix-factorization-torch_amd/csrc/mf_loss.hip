@@ -281,10 +281,8 @@ struct FwdLds {
 };
 
 template <int NEED>
-__device__ __forceinline__ void stats_add_masked(RowStats& s, float L, bool ok, float sm, float lii, float margin) {
-    // masked elements enter as -FLT_MAX: every term below is then exactly 0
-    const float Lm = ok ? L : -FLT_MAX;
-    s.cnt += ok ? 1.f : 0.f;
+__device__ __forceinline__ void stats_add_masked(RowStats& s, float Lm, float sm, float lii, float margin) {
+    // Lm is -inf for masked elements: every term below is then exactly 0 (the count is kept separately)
     if (NEED & NEED_CONTR) s.A += fmaxf(Lm + sm, 0.f);
     if (NEED & (NEED_HINGE | NEED_LOGI)) {
         const float x = (Lm - lii) + margin;
@@ -329,7 +327,7 @@ __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
     // The statistics of one tile, cut in 32 slices so they can be threaded between the MFMAs of
     // the next tile: slices 0..15 turn score e into logit e (and stash it), slices 16..31 fold
     // logit e into the running statistics.
-    float Lg[16], Ls[4];
+    float Lg[16];
     float tmax = -FLT_MAX, nmx = -FLT_MAX;
     uint32_t mw = 0u;
     f32x4 nv4 = {0.f, 0.f, 0.f, 0.f}, lq4 = {0.f, 0.f, 0.f, 0.f};
@@ -342,18 +340,21 @@ __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
             if (e == 0) {
                 mw = reinterpret_cast<const uint32_t*>(aux)[wave * 32 + c];
                 tmax = -FLT_MAX;
+                // valid negatives among this lane's 16 rows of the tile (rows (e&3) + 8 (e>>2) + 4 h)
+                st.cnt += (float)(16 - __builtin_popcount(mw & (h ? 0xF0F0F0F0u : 0x0F0F0F0Fu)));
             }
             if (r == 0) {
                 nv4 = *reinterpret_cast<const f32x4*>(aux + L::AUX_NV + (8 * q + 4 * h) * 4);
                 lq4 = *reinterpret_cast<const f32x4*>(aux + L::AUX_LQ + (8 * q + 4 * h) * 4);
             }
-            Lg[e] = mf_logit(nu_i, nv4[r], acc[e], s_i, p.sigma, lq4[r]);
-            const bool ok = !((mw >> mf_acc_row(e, h)) & 1u);
-            tmax = fmaxf(tmax, ok ? Lg[e] : -FLT_MAX);
-            Ls[r] = ok ? Lg[e] : -INFINITY;     // masked logits: every dloss/dL of the backward is then exactly 0 there
-            if (r == 3) {   // stash 4 logits of the block for the backward sweeps
+            // masked logit: -inf where the column is not a valid negative -> every statistic below and
+            // every dloss/dL of the backward is exactly 0 there, with no further mask test
+            const float Lraw = mf_logit(nu_i, nv4[r], acc[e], s_i, p.sigma, lq4[r]);
+            Lg[e] = ((mw >> mf_acc_row(e, h)) & 1u) ? -INFINITY : Lraw;
+            tmax = fmaxf(tmax, Lg[e]);
+            if (r == 3) {   // stash 4 masked logits of the block for the backward sweeps
                 float* blk = p.stash + ((int64_t)(i0 / 32 + wave) * p.NT + te) * 1024 + lane * 4;
-                *reinterpret_cast<f32x4*>(blk + q * 256) = f32x4{Ls[0], Ls[1], Ls[2], Ls[3]};
+                *reinterpret_cast<f32x4*>(blk + q * 256) = f32x4{Lg[e - 3], Lg[e - 2], Lg[e - 1], Lg[e]};
             }
         } else {
             const int e = sidx - 16;
@@ -362,9 +363,8 @@ __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
                 if (NEED & NEED_LSE) st.se *= __expf(st.mx - nmx);
                 st.mx = nmx;
             }
-            const bool ok = !((mw >> mf_acc_row(e, h)) & 1u);
-            stats_add_masked<NEED>(st, Lg[e], ok, sm, lii, p.margin);
-            if (NEED & NEED_LSE) st.se += __expf((ok ? Lg[e] : -FLT_MAX) - nmx);
+            stats_add_masked<NEED>(st, Lg[e], sm, lii, p.margin);
+            if (NEED & NEED_LSE) st.se += __expf(Lg[e] - nmx);
         }
     };
 
@@ -708,6 +708,7 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
     const int t0 = blockIdx.y * p.tps, t1 = min(p.YT, t0 + p.tps);
     float xa = 0.f, xb = 0.f, xc = 0.f, xd = 0.f;
     if (XU) { xa = p.rowc[x]; xb = p.rowc[p.Bp + x]; xc = p.rowc[2 * p.Bp + x]; xd = p.rowc[3 * p.Bp + x]; }
+    const float xa2 = -xa * 1.44269504088896341f;      // exp(L - a) = exp2(L log2e - a log2e)
     f32x16 dacc[D / 32];
 #pragma unroll
     for (int mb = 0; mb < D / 32; ++mb)
@@ -747,7 +748,10 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
         if (XU) {
             // masked logits -> G' (masked entries are -inf: exp / step / sigmoid give exactly 0)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Gv[e] = xc * g_of(GMODE, (Gv[e] - xa) + xb);
+            for (int e = 0; e < 16; ++e) {
+                if (GMODE == G_EXP) Gv[e] = xc * __builtin_amdgcn_exp2f(__builtin_fmaf(Gv[e], 1.44269504088896341f, xa2));   // xb = 0
+                else Gv[e] = xc * g_of(GMODE, (Gv[e] - xa) + xb);
+            }
             if (ty == xt) {             // only the diagonal tile holds the user's own positive
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
