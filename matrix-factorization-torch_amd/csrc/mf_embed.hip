@@ -114,7 +114,7 @@ extern "C" int mf_scores(const float* u, int64_t B, const float* v, int64_t N, i
 // all-pairs count spread over the whole chip.  n is a batch (<= a few 10^4 ids)
 // and the count is integer-exact and order-free, so the result is deterministic;
 // it costs 1/(6 d) of the score contraction of the same batch.
-static constexpr int SORT_TILE = 2048;
+static constexpr int SORT_TILE = 512;
 
 __global__ __launch_bounds__(256) void rank_count_kernel(const int64_t* __restrict__ keys, int n,
                                                          int32_t* __restrict__ rank) {
