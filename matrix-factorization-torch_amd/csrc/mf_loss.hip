@@ -328,9 +328,11 @@ __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
     using L = FwdLds<D>;
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int wave = mf_wave_id();
-    const int64_t i0 = (int64_t)blockIdx.x * 128;
+    // grid = (item-range split, user block): consecutive workgroup ids -- dealt round-robin to the 8 XCDs --
+    // differ in the SPLIT, so the workgroups of one XCD stream the same 1/nsplit of V through its L2
+    const int64_t i0 = (int64_t)blockIdx.y * 128;
     const int64_t i = i0 + wave * 32 + c;
-    const int t0 = blockIdx.y * p.tps, t1 = min(p.NT, t0 + p.tps);
+    const int t0 = blockIdx.x * p.tps, t1 = min(p.NT, t0 + p.tps);
     RowFrag<D> xf;
     mf_load_frag<D>(xf, p.u, i, i < p.B);
     const float nu_i = p.nu[i], s_i = p.sgn[i], lii = p.lii[i];
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
         st.Lg += mf_shfl_xor32(st.Lg); st.Ls += mf_shfl_xor32(st.Ls);
     }
     if (h == 0) {
-        float* o = p.part + (int64_t)blockIdx.y * NSTAT * p.Bp + i;
+        float* o = p.part + (int64_t)blockIdx.x * NSTAT * p.Bp + i;
         o[ST_CNT * p.Bp] = st.cnt; o[ST_A * p.Bp] = st.A; o[ST_MX * p.Bp] = st.mx; o[ST_SE * p.Bp] = st.se;
         o[ST_H * p.Bp] = st.H; o[ST_HC * p.Bp] = st.Hc; o[ST_LG * p.Bp] = st.Lg; o[ST_LS * p.Bp] = st.Ls;
     }
@@ -720,14 +722,14 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
     using L = BwdLds<D, XU>;
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int wave = mf_wave_id();
-    const int64_t x0 = (int64_t)blockIdx.x * 128 + wave * 32;     // this wave's X tile
+    const int64_t x0 = (int64_t)blockIdx.y * 128 + wave * 32;     // this wave's X tile (grid = (Y split, X block))
     const int64_t x = x0 + c;
     const int xt = (int)(x0 >> 5);
     const int64_t nX = XU ? p.B : p.N, nY = XU ? p.N : p.B;
     const int64_t Xp = XU ? p.Bp : p.Np;
     const float* X = XU ? p.u : p.v;
     const float* Y = XU ? p.v : p.u;
-    const int t0 = blockIdx.y * p.tps, t1 = min(p.YT, t0 + p.tps);
+    const int t0 = blockIdx.x * p.tps, t1 = min(p.YT, t0 + p.tps);
     float xa = 0.f, xb = 0.f, xc = 0.f, xd = 0.f;
     if (XU) { xa = p.rowc[x]; xb = p.rowc[p.Bp + x]; xc = p.rowc[2 * p.Bp + x]; xd = p.rowc[3 * p.Bp + x]; }
     const float xa2 = -xa * 1.44269504088896341f;      // exp(L - a) = exp2(L log2e - a log2e)
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
     // dX[x][m] = dacc - rsum * X[x][m];  register e of block j is feature m = NB * row(e, h) + j
     if (x < nX) {
         constexpr int NB = D / 32;
-        float* o = p.dpart + ((int64_t)blockIdx.y * Xp + x) * D;
+        float* o = p.dpart + ((int64_t)blockIdx.x * Xp + x) * D;
         const float* xr = X + x * D;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -924,7 +926,7 @@ static void launch_mining_select_t(const LossWs& w, const MiningPolicy::Params& 
     auto fn = select_kernel<D, T, MiningPolicy>;
     const int bytes = SelectLds<D>::bytes(sc.capl);
     (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    fn<<<dim3((unsigned)w.plan.gx, (unsigned)w.plan.nchunk), 256, bytes, s>>>(mp, sc);
+    fn<<<dim3((unsigned)w.plan.nchunk, (unsigned)w.plan.gx), 256, bytes, s>>>(mp, sc);
 }
 template <int D>
 static void launch_mining_select(const LossWs& w, const MiningPolicy::Params& mp, const SelectCommon& sc,
@@ -981,7 +983,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     if (scores_needed && !w.mined) {
         FwdParams fp{u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.part, w.stash, B, N, w.Bp, w.NT, w.tps_f, need, sigma, margin};
         MF_DISPATCH_D(d, {
-            dim3 grid((unsigned)(w.BT / 4), (unsigned)w.nsplit_f);
+            dim3 grid((unsigned)w.nsplit_f, (unsigned)(w.BT / 4));
             MF_TIMED("loss_fwd_dense", s, (launch_fwd<D>(need, grid, fp, s)));
         });
         stats_merge_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(w.part, w.nsplit_f, w.Bp, w.stats);
@@ -1037,10 +1039,10 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
         BwdParams bp{u, v, w.rowc, w.stash, w.dpart, B, N, w.Bp, w.Np, w.NT, 0, 0};
         MF_DISPATCH_D(d, {
             bp.YT = w.NT; bp.tps = w.tps_u;
-            MF_TIMED("loss_bwd_du", s, (launch_bwd<D, true>(gmode, dim3((unsigned)(w.BT / 4), (unsigned)w.nsplit_u), bp, s)));
+            MF_TIMED("loss_bwd_du", s, (launch_bwd<D, true>(gmode, dim3((unsigned)w.nsplit_u, (unsigned)(w.BT / 4)), bp, s)));
             sum_parts_kernel<<<dim3((unsigned)((B * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_u, B, w.Bp, D, du);
             bp.YT = w.BT; bp.tps = w.tps_v;
-            MF_TIMED("loss_bwd_dv", s, (launch_bwd<D, false>(G_EXP, dim3((unsigned)(w.NT / 4), (unsigned)w.nsplit_v), bp, s)));
+            MF_TIMED("loss_bwd_dv", s, (launch_bwd<D, false>(G_EXP, dim3((unsigned)w.nsplit_v, (unsigned)(w.NT / 4)), bp, s)));
             sum_parts_kernel<<<dim3((unsigned)((N * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_v, N, w.Np, D, dv);
         });
     }

@@ -102,9 +102,11 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
     const int wave = mf_wave_id();
     const int nsub = 4 / sc.xw;
     const int sub = wave / sc.xw;
-    const int64_t x0 = ((int64_t)blockIdx.x * sc.xw + (wave % sc.xw)) * 32;
+    // grid = (Y chunk, X block): the workgroups of one XCD (ids 8 apart) share chunks -> the catalog
+    // slice they stream stays in that XCD's L2
+    const int64_t x0 = ((int64_t)blockIdx.y * sc.xw + (wave % sc.xw)) * 32;
     const int64_t x = x0 + c;
-    const int chunk = blockIdx.y;
+    const int chunk = blockIdx.x;
     const int t0 = chunk * sc.tiles_per_chunk;
     const int t1 = min(sc.YT, t0 + sc.tiles_per_chunk);
 

@@ -133,7 +133,7 @@ static void launch_topk_select_t(const TopkWs& w, const RetrievalPolicy::Params&
     auto fn = select_kernel<D, T, RetrievalPolicy>;
     const int bytes = SelectLds<D>::bytes(sc.capl);
     (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    fn<<<dim3((unsigned)w.plan.gx, (unsigned)w.plan.nchunk), 256, bytes, s>>>(rp, sc);
+    fn<<<dim3((unsigned)w.plan.nchunk, (unsigned)w.plan.gx), 256, bytes, s>>>(rp, sc);
 }
 template <int D>
 static void launch_topk_select(const TopkWs& w, const RetrievalPolicy::Params& rp, const SelectCommon& sc, hipStream_t s) {
