@@ -51,7 +51,7 @@ struct LossWs {
     int32_t *colslot, *gfirst, *colfirst;
     uint32_t *ubits, *dupmask;
     uint32_t* maskW;
-    float *part, *stats, *rowloss, *rowc, *dpart, *stash;
+    float *part, *stats, *rowloss, *rowc, *dpart, *stash, *gstash;
     unsigned long long* cand;
     int32_t *cand_cnt, *sel, *sel_cnt;
     float* sel_L;
@@ -111,6 +111,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
         if (rows_v > rows) rows = rows_v;
         w.dpart = a.take<float>(rows * d);
         w.stash = a.take<float>((size_t)w.Bp * w.Np);
+        w.gstash = a.take<float>((size_t)w.Bp * w.Np);
     }
     w.total = a.used();
     return w;
@@ -690,13 +691,14 @@ __device__ __forceinline__ float g_of(int gmode, float x) {
 // Block (ti, tj) is 4 KiB: [q = e / 4][lane][e % 4] in the forward's accumulator layout
 // (lane = user), i.e. four whole-KiB coalesced stores per tile and a linear LDS-DMA on the way
 // back.  The dU sweep turns each block into G' = dloss/dL (one exp / step / sigmoid per element,
-// diagonal patched) and writes it back IN PLACE, so the dV sweep, which runs after it, reads G'
+// diagonal patched) and writes it to a second stash, so the dV sweep, which runs after it, reads G'
 // and has no per-element arithmetic at all: on gfx950 fp32 MFMA and VALU share the SIMD's FP32
 // lanes (a VALU op costs ~2 cycles of MFMA throughput, a transcendental ~17 -- measured), so
 // every VALU instruction removed from these loops is MFMA time won back.
 struct BwdParams {
     const float *u, *v, *rowc;
-    float* stash;
+    const float* stash;      // masked logits (forward); stays intact so that a backward can be repeated
+    float* gstash;           // G' = dloss/dL blocks: written by the dU sweep, read by the dV sweep
     float* dpart;
     int64_t B, N, Bp, Np;
     int NT, YT, tps;
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
     auto stage = [&](int t, int slot_idx) {
         char* slot = smem + slot_idx * L::SLOT;
         mf_stage_tile<D>(slot, Y, (int64_t)t * 32, nY);
-        const char* lsrc = reinterpret_cast<const char*>(p.stash + block_of(t) * 1024) + lane * 16;
+        const char* lsrc = reinterpret_cast<const char*>((XU ? p.stash : p.gstash) + block_of(t) * 1024) + lane * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             __builtin_amdgcn_global_load_lds((mf_glb_ptr)(lsrc + q * 1024),
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
                 for (int e = 0; e < 16; ++e)
                     if (mf_acc_row(e, h) == c) Gv[e] = xd;
             }
-            float* blk = p.stash + block_of(ty) * 1024 + lane * 4;      // hand G' to the dV sweep, in place
+            float* blk = p.gstash + block_of(ty) * 1024 + lane * 4;     // hand G' to the dV sweep
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *reinterpret_cast<f32x4*>(blk + q * 256) = f32x4{Gv[4 * q], Gv[4 * q + 1], Gv[4 * q + 2], Gv[4 * q + 3]};
@@ -1036,7 +1038,7 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
                                                                                         w.Bp, gmode, du, dv);
         });
     } else {
-        BwdParams bp{u, v, w.rowc, w.stash, w.dpart, B, N, w.Bp, w.Np, w.NT, 0, 0};
+        BwdParams bp{u, v, w.rowc, w.stash, w.gstash, w.dpart, B, N, w.Bp, w.Np, w.NT, 0, 0};
         MF_DISPATCH_D(d, {
             bp.YT = w.NT; bp.tps = w.tps_u;
             MF_TIMED("loss_bwd_du", s, (launch_bwd<D, true>(gmode, dim3((unsigned)w.nsplit_u, (unsigned)(w.BT / 4)), bp, s)));

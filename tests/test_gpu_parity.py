@@ -277,3 +277,28 @@ def test_item_processor_search_surface(mf):
     assert df["score"].is_monotonic_decreasing and not set(df["movie_id"]) & {1000, 1001}
     with pytest.raises(ValueError, match="must be intialised first"):
         mf.retrieval.ItemProcessor().search(emb)
+
+
+def test_backward_can_be_repeated_and_fused_losses_backprop_together(mf):
+    """Two losses of one fused forward receive gradient (two HIP backwards on the same workspace),
+    and retain_graph backward twice gives identical gradients: the stashed logits stay intact."""
+    t = _random_case(96, 192, 64, 8, seed=9)
+    dev = {k: x.to(DEV) for k, x in t.items()}
+    u = dev["u"].clone().requires_grad_()
+    v = dev["v"].clone().requires_grad_()
+    out = mf.losses.fused_losses(u, v, dev["target"], item_idx=dev["item_idx"], pos_idx=dev["pos_idx"])
+    (out["InfomationNoiseContrastiveEstimationLoss"] + 0.5 * out["PairwiseLogisticLoss"]).backward()
+    uo = t["u"].clone().requires_grad_()
+    vo = t["v"].clone().requires_grad_()
+    a = ol.loss("InfomationNoiseContrastiveEstimationLoss", uo, vo, t["target"], item_idx=t["item_idx"], pos_idx=t["pos_idx"])
+    b = ol.loss("PairwiseLogisticLoss", uo, vo, t["target"], item_idx=t["item_idx"], pos_idx=t["pos_idx"])
+    (a + 0.5 * b).backward()
+    np.testing.assert_allclose(u.grad.cpu().numpy(), uo.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(v.grad.cpu().numpy(), vo.grad.numpy(), rtol=2e-4, atol=2e-5)
+    u2 = dev["u"].clone().requires_grad_()
+    loss = mf.losses.PairwiseHingeLoss()(u2, dev["v"], dev["target"], item_idx=dev["item_idx"], pos_idx=dev["pos_idx"])
+    loss.backward(retain_graph=True)
+    g1 = u2.grad.clone()
+    u2.grad = None
+    loss.backward()
+    assert torch.equal(g1, u2.grad)
