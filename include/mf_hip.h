@@ -121,6 +121,17 @@ int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sig
                 void* ws, size_t ws_bytes, const float* grad_out, float* du, float* dv,
                 mf_stream_t stream);
 
+/* API parity with the public helper methods of EmbeddingLoss, on caller-provided tensors (not the
+ * hot path): negative_masks (losses.py:92-110) -> out_mask[B,N] bytes, 1 = valid negative;
+ * hard_mining (losses.py:112-132, semi_hard = 0: keep the k highest logits among the valid
+ * negatives) and semi_hard_mining (losses.py:134-162, semi_hard = 1) on a MATERIALISED logits[B,N]
+ * matrix, mask[B,N] bytes updated in place; k <= 0 or k >= N leaves it unchanged.  Any k. */
+size_t mf_negative_masks_ws_bytes(int64_t B, int64_t N, int P);
+int mf_negative_masks(int64_t B, int64_t N, int P, const int64_t* item_idx, const int64_t* pos_idx, void* ws,
+                      size_t ws_bytes, uint8_t* out_mask, mf_stream_t stream);
+int mf_mine_logits(const float* logits, int64_t B, int64_t N, int k, int semi_hard, uint8_t* mask,
+                   mf_stream_t stream);
+
 /* --------------------------------------------------------------- optimiser ---
  * Replaces `configure_optimizers` (xfmr_rec/lightning.py:238-239, dense AdamW) by
  * sparse row updates of an embedding table (north-star; our spec):

@@ -54,6 +54,7 @@ struct LossWs {
     float *part, *stats, *rowloss, *rowc, *dpart, *stash, *gstash;
     unsigned long long* cand;
     int32_t *cand_cnt, *sel, *sel_cnt;
+    unsigned* gtau;
     float* sel_L;
     size_t total;
 };
@@ -104,6 +105,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
         w.sel = a.take<int32_t>((size_t)w.Bp * KSEL_MAX);
         w.sel_cnt = a.take<int32_t>(w.Bp);
         w.sel_L = a.take<float>((size_t)w.Bp * KSEL_MAX);
+        w.gtau = a.take<unsigned>((size_t)w.Bp);
         w.dpart = nullptr;
     } else {
         size_t rows = (size_t)w.nsplit_u * w.Bp;
@@ -538,6 +540,7 @@ struct MiningPolicy {
         f32x4 nv4[4], lq4[4];
     };
     static constexpr int AUX_DMA = 2;
+    static constexpr bool PREFILTER = false;     // the mining rank is not monotone in the raw dot product
     static __device__ __forceinline__ void stage_aux(const Params& p, char* aux, int wave, int t, int64_t x0) {
         mf_stage_small(aux + wave * 128, p.maskW + (int64_t)t * p.Bp + x0, 128);
         const float* src = (wave == 1 && p.logq) ? p.logq : p.nv;
@@ -891,6 +894,23 @@ __global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ C ABI ------
+// negative_masks of the reference (losses.py:92-110) into w.maskW
+static void build_masks(const LossWs& w, const int64_t* item_idx, const int64_t* pos_idx, int64_t B, int64_t N, int P,
+                        hipStream_t s) {
+    (void)hipMemsetAsync(w.gtab, 0x80, (size_t)w.M * 8, s);
+    (void)hipMemsetAsync(w.gfirst, 0x7f, (size_t)w.M * 4, s);
+    (void)hipMemsetAsync(w.ubits, 0, (size_t)w.NT * w.Bp * 4, s);
+    gt_insert_kernel<<<dim3((unsigned)((N + 255) / 256)), 256, 0, s>>>(item_idx, N, w.M, w.gtab, w.gfirst, w.colslot);
+    colfirst_kernel<<<dim3((unsigned)((w.Np + 255) / 256)), 256, 0, s>>>(w.colslot, w.gfirst, N, w.Np, w.colfirst, w.dupmask);
+    const int64_t nthreads = B * (P + 1);
+    ubits_kernel<<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(item_idx, pos_idx, B, P, w.M, w.gtab, w.gfirst, w.Bp, w.ubits);
+    int gy = (w.NT + 7) / 8;
+    if (gy > 16) gy = 16;
+    if (gy * w.BT < 1024) gy = (1024 + w.BT - 1) / w.BT;   // enough blocks when B is small
+    if (gy > (w.NT + 7) / 8) gy = (w.NT + 7) / 8;
+    mask_sweep_kernel<<<dim3((unsigned)w.BT, (unsigned)gy), 256, 0, s>>>(w.colfirst, w.dupmask, w.ubits, B, N, w.Bp, w.NT, w.maskW);
+}
+
 template <int D, bool XU>
 static void launch_bwd(int gmode, dim3 grid, const BwdParams& bp, hipStream_t s);
 
@@ -964,18 +984,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     diag_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(u, v, target, logq, w.nu, w.nv, B, w.Bp, d, sigma,
                                                                      w.lii, w.dii, w.sgn);
     if (scores_needed) {
-        (void)hipMemsetAsync(w.gtab, 0x80, (size_t)w.M * 8, s);
-        (void)hipMemsetAsync(w.gfirst, 0x7f, (size_t)w.M * 4, s);
-        (void)hipMemsetAsync(w.ubits, 0, (size_t)w.NT * w.Bp * 4, s);
-        gt_insert_kernel<<<dim3((unsigned)((N + 255) / 256)), 256, 0, s>>>(item_idx, N, w.M, w.gtab, w.gfirst, w.colslot);
-        colfirst_kernel<<<dim3((unsigned)((w.Np + 255) / 256)), 256, 0, s>>>(w.colslot, w.gfirst, N, w.Np, w.colfirst, w.dupmask);
-        const int64_t nthreads = B * (P + 1);
-        ubits_kernel<<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(item_idx, pos_idx, B, P, w.M, w.gtab, w.gfirst, w.Bp, w.ubits);
-        int gy = (w.NT + 7) / 8;
-        if (gy > 16) gy = 16;
-        if (gy * w.BT < 1024) gy = (1024 + w.BT - 1) / w.BT;   // enough blocks when B is small
-        if (gy > (w.NT + 7) / 8) gy = (w.NT + 7) / 8;
-        mask_sweep_kernel<<<dim3((unsigned)w.BT, (unsigned)gy), 256, 0, s>>>(w.colfirst, w.dupmask, w.ubits, B, N, w.Bp, w.NT, w.maskW);
+        build_masks(w, item_idx, pos_idx, B, N, P, s);
     }
     // logq is read by whole float4s up to the padded width: keep a zero-padded copy in ws
     // (all zeros when there is no logQ correction: L - 0 is exact, and the kernels stay branch-free)
@@ -993,7 +1002,8 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
             mask_export_dense_kernel<<<dim3((unsigned)((B * ((N + 31) / 32) + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, (int)((N + 31) / 32), out_mask_bits);
     } else if (scores_needed) {
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
-        SelectCommon sc{u, B, v, N, (int)((N + 31) / 32), w.tpc, w.Bp, num_negatives, w.plan.xw, w.plan.CAPL, w.cand, w.cand_cnt};
+        SelectCommon sc{u, B, v, N, (int)((N + 31) / 32), w.tpc, w.Bp, num_negatives, w.plan.xw, w.plan.CAPL, w.gtau, w.cand, w.cand_cnt};
+        (void)hipMemsetAsync(w.gtau, 0, (size_t)w.Bp * 4, s);
         MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, launch_mining_select<D>(w, mp, sc, s)); });
         mined_merge_kernel<<<dim3((unsigned)B), 64, (size_t)w.nchunk * w.CAP * 8, s>>>(w.cand, w.cand_cnt, w.nchunk, w.Bp, w.CAP,
                                                                                       num_negatives, w.sel, w.sel_cnt);
@@ -1049,4 +1059,70 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
         });
     }
     return mf_check_launch("mf_loss_bwd");
+}
+
+// ------------------------------------------------- public mask / mining helpers ----
+// API parity with the reference's EmbeddingLoss methods on caller-provided tensors:
+// negative_masks (losses.py:92-110), hard_mining (:112-132, never called upstream) and
+// semi_hard_mining (:134-162) on a MATERIALISED logits matrix.  Not the hot path.
+__global__ __launch_bounds__(256) void mask_export_bool_kernel(const uint32_t* __restrict__ maskW, int64_t B, int64_t N,
+                                                               int64_t Bp, uint8_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * N) return;
+    const int64_t i = t / N, j = t % N;
+    out[t] = ((maskW[(j >> 5) * Bp + i] >> (j & 31)) & 1u) ? 0 : 1;
+}
+
+extern "C" size_t mf_negative_masks_ws_bytes(int64_t B, int64_t N, int P) { return mf_loss_ws_bytes(B, N, 32, P, 1); }
+
+extern "C" int mf_negative_masks(int64_t B, int64_t N, int P, const int64_t* item_idx, const int64_t* pos_idx, void* ws,
+                                 size_t ws_bytes, uint8_t* out_mask, mf_stream_t stream) {
+    if (B <= 0 || N < B || P < 0 || !item_idx || !ws || !out_mask || (P > 0 && !pos_idx))
+        return mf_set_error(MF_EINVAL, "mf_negative_masks: bad argument");
+    if (N >= (1 << 24)) return mf_set_error(MF_ENOTSUP, "mf_negative_masks: N >= 2^24");
+    if (ws_bytes < mf_negative_masks_ws_bytes(B, N, P)) return mf_set_error(MF_ENOSPC, "mf_negative_masks: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LossWs w = loss_ws(ws, B, N, 32, P, 1);
+    build_masks(w, item_idx, pos_idx, B, N, P, s);
+    mask_export_bool_kernel<<<dim3((unsigned)((B * N + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, out_mask);
+    return mf_check_launch("mf_negative_masks");
+}
+
+// one wave per row: k rounds, each extracting the best remaining valid key (exact, any k)
+__global__ __launch_bounds__(64) void mine_logits_kernel(const float* __restrict__ logits, int64_t N, int k, int semi_hard,
+                                                         uint8_t* __restrict__ mask) {
+    const int64_t i = blockIdx.x;
+    const int lane = mf_lane();
+    const float* row = logits + i * N;
+    uint8_t* mrow = mask + i * N;
+    const float lii = row[i];
+    unsigned long long prev = ~0ull;
+    int taken = 0;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long best = 0ull;
+        for (int64_t j = lane; j < N; j += 64) {
+            if (!(mrow[j] & 1)) continue;
+            const unsigned long long key = semi_hard ? mf_key_mining(row[j] - lii, (unsigned)j)
+                                                     : (((unsigned long long)mf_orderable(row[j]) << 30) | (0x3FFFFFFFu - (unsigned)j));
+            if (key < prev && key > best) best = key;
+        }
+        best = mf_wave_max_u64(best);
+        if (best == 0ull) break;
+        prev = best;
+        ++taken;
+        const unsigned col = 0x3FFFFFFFu - (unsigned)(best & 0x3FFFFFFFull);
+        if (lane == 0) mrow[col] |= 2;
+    }
+    __syncthreads();
+    (void)taken;
+    for (int64_t j = lane; j < N; j += 64) mrow[j] = (mrow[j] & 2) ? 1 : 0;
+}
+
+extern "C" int mf_mine_logits(const float* logits, int64_t B, int64_t N, int k, int semi_hard, uint8_t* mask,
+                              mf_stream_t stream) {
+    if (!logits || !mask || B <= 0 || N < B) return mf_set_error(MF_EINVAL, "mf_mine_logits: bad argument");
+    if (N >= (1ll << 30)) return mf_set_error(MF_ENOTSUP, "mf_mine_logits: N >= 2^30");
+    if (k <= 0 || k >= N) return MF_OK;       // losses.py:115-119 / :137-141: mining disabled, mask unchanged
+    mine_logits_kernel<<<dim3((unsigned)B), 64, 0, static_cast<hipStream_t>(stream)>>>(logits, N, k, semi_hard, mask);
+    return mf_check_launch("mf_mine_logits");
 }

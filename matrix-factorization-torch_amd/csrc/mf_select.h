@@ -32,7 +32,7 @@
 static inline int mf_select_T(int k) { return k <= 4 ? 2 : k <= 8 ? 4 : k <= 16 ? 8 : k <= 20 ? 10 : k <= 24 ? 12 : k <= 32 ? 16 : 32; }
 static inline int mf_select_nslot(int d) { return d == 256 ? 2 : 3; }
 static inline int mf_select_capl(int d) {
-    const int ring = mf_select_nslot(d) * (32 * d * 4) + 4 * 1024;
+    const int ring = mf_select_nslot(d) * (32 * d * 4) + 4 * 1536;
     int capl = (160 * 1024 - ring - 1024) / (4 * 64 * 8) - 1;
     capl = capl > 64 ? 64 : capl;
     return capl & ~1;        // even capacity -> odd segment stride: lanes of a half hit distinct banks
@@ -54,6 +54,8 @@ struct SelectCommon {
     int xw;              // X tiles per workgroup (1, 2 or 4); the 4 / xw waves that share an X tile
                          // deal the chunk's Y tiles round-robin and emit separate candidate sets
     int capl;            // per-lane LDS segment capacity
+    unsigned* gtau;      // [Xp], zeroed by the host: best known lower bound (rank) of every X row's k-th best key,
+                         // shared by all chunks of the launch (max-published, so always a valid bound)
     unsigned long long* cand;   // [nchunk * 4 / xw][Xp][2 capl]
     int32_t* cand_cnt;          // [nchunk * 4 / xw][Xp]
 };
@@ -75,7 +77,8 @@ __device__ __forceinline__ void mf_wave_sync() { asm volatile("s_waitcnt lgkmcnt
 template <int D>
 struct SelectLds {
     using G = TileGeom<D>;
-    static constexpr int AUXB = 1024;                    // [4 x 128 B per-wave words][nv 128][logq 128][pad]
+    static constexpr int AUXB = 1536;                    // [4 x 128 B per-wave words][nv 128][logq 128][pad][4 x 128 B gtau]
+    static constexpr int GT0 = 1024;                     // per-wave copies of gtau[x0 .. x0 + 31]
     static constexpr int NSLOT = D == 256 ? 2 : 3;       // d = 256: 2-deep tile ring, 2 barriers per tile
     static constexpr int AUX0 = NSLOT * G::TILEB;        // 4 side-input slots after the tile slots
     static constexpr int RING = AUX0 + 4 * AUXB;
@@ -90,12 +93,13 @@ struct SelectLds {
 //   static Row  row_init(P, x, valid)
 //   static Tile tile_init(P, row, aux, wave, c, h)  read the staged side inputs
 //   static bool key(P, row, tile, score, e, h, y, hi&, lo&)   false = never a candidate; (hi, lo) = key halves
+//   static constexpr bool PREFILTER                 true: hi is mf_orderable(score), so `score < bound` may skip key()
 template <int D, int T, class Policy>
 __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp, SelectCommon sc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = TileGeom<D>;
     using L = SelectLds<D>;
-    constexpr int NWAIT = G::PPW + Policy::AUX_DMA;
+    constexpr int NWAIT = G::PPW + Policy::AUX_DMA + 1;
     const int CAPL = sc.capl;
 
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
         const int kk = t - t0;
         mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, sc.Y, (int64_t)t * 32, sc.nY);
         Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t, x0);
+        mf_stage_small<17>(smem + L::AUX0 + (kk & 3) * L::AUXB + L::GT0 + wave * 128, sc.gtau + x0, 128);
     };
     auto mine = [&](int t) { return (t - t0) % nsub == sub; };   // else another wave of this X tile takes tile t
 
@@ -142,7 +147,15 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
     unsigned y0 = 0u;                            // first Y row of the current tile (rows < 2^32)
     // 32-bit-only fast path: rank (= high key word) against the row bound; the exact 64-bit floor of
     // the degenerate path is checked by halves as well
+    float thr_f = __builtin_bit_cast(float, 0xFFFFFFFFu);   // NaN: everything passes until a bound exists
+    unsigned pub = 0u;                                       // last bound this lane published
     auto slice = [&](int e) {
+        // one compare per element on the raw score where the policy's rank is monotone in it
+        // (conservative: NaN and signed zeros pass), everything exact happens behind the branch
+#ifdef MF_ABL_NOSLICE
+        return;
+#endif
+        if (Policy::PREFILTER && (acc[e] < thr_f)) return;
         unsigned hi, lo;
         const bool ok = Policy::key(pp, row, tile, acc[e], e, h, y0 + (unsigned)mf_acc_row(e, h), hi, lo);
         const unsigned fhi = (unsigned)(fl >> 32), flo = (unsigned)fl;
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
     // accepted elements (one per tile), so tl[T-1] stays a valid -- and, with the row's best spread
     // over many tiles, nearly tight -- lower bound, at the cost of one branch-free insertion per tile.
     // While the lists fill (the first T tiles of the chunk) every accepted key is inserted instead.
-    auto settle = [&](int cnt0, bool warm) {
+    auto settle = [&](int cnt0, bool warm, const char* aux) {
         if (warm) {
             for (int i = cnt0; __any(i < cnt); ++i) {
                 if (i < cnt) {
@@ -186,7 +199,20 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
         tmaxr = 0u;
         {
             const unsigned own = tl[T - 1];
-            tau_row = min(own, mf_shfl_xor32u(own));
+            const unsigned mine_ = min(own, mf_shfl_xor32u(own));
+            // every chunk's bound is a valid bound of the row: take the best one published so far
+            // (the copy staged with this tile; a stale value only prunes less) and publish ours
+#ifdef MF_ABL_NOGTAU
+            const unsigned g = 0u * reinterpret_cast<const unsigned*>(aux + L::GT0 + wave * 128)[c] + 0xFFFFFFFFu * 0u;
+            pub = 0xFFFFFFFFu;
+#else
+            const unsigned g = reinterpret_cast<const unsigned*>(aux + L::GT0 + wave * 128)[c];
+#endif
+            if (h == 0 && mine_ > g && mine_ > pub) {
+                mf_global_umax(sc.gtau + x, mine_);
+                pub = mine_;
+            }
+            tau_row = max(mine_, g);
         }
         if (__any(cnt > CAPL - 16)) {
             filter_segment();   // drop, in place, what has fallen below the row's current bound
@@ -225,6 +251,13 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
             }
             fl = floor64[c];
         }
+        {
+            const unsigned t = max(tau_row, (unsigned)(fl >> 32));
+            thr_f = row_ok ? mf_unorderable(t) : __builtin_inff();
+#ifdef MF_ABL_NOPASS
+            thr_f = __builtin_inff();
+#endif
+        }
     };
 
     if (t0 < t1) {
@@ -260,7 +293,7 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
             } else if (nxt) {
                 acc = mf_tile_scores_interleaved<D, 16, (48 * 32 / D)>(next_tile, xf, [](int) {});
             }
-            if (cur) settle(cnt0, (ty - t0) < (T + 1) * nsub);
+            if (cur) settle(cnt0, (ty - t0) < (T + 1) * nsub, smem + L::AUX0 + ((ty - t0) & 3) * L::AUXB);
         }
     }
 

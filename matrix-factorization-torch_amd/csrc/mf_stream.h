@@ -74,11 +74,17 @@ __device__ __forceinline__ void mf_stage_tile(char* lds_tile, const float* __res
 }
 
 // DMA `nbytes` (multiple of 16, <= 1024) from src to lds_dst by the calling wave.
+// CPOL: cache-policy bits of the load (0 = default; 17 = sc0 sc1: read at L2, past a possibly stale L1 line)
+template <int CPOL = 0>
 __device__ __forceinline__ void mf_stage_small(char* lds_dst, const void* src, int nbytes) {
     const int lane = mf_lane();
     if (lane * 16 < nbytes)
         __builtin_amdgcn_global_load_lds((mf_glb_ptr)(reinterpret_cast<const char*>(src) + lane * 16),
-                                         (mf_lds_ptr)lds_dst, 16, 0, 0);
+                                         (mf_lds_ptr)lds_dst, 16, 0, CPOL);
+}
+// fire-and-forget device-scope max (no return value, so no wait is ever attached to it)
+__device__ __forceinline__ void mf_global_umax(unsigned* p, unsigned v) {
+    asm volatile("global_atomic_umax %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
 // LDS stores that must not drain the DMA queue: while a global_load_lds is in flight, hipcc puts

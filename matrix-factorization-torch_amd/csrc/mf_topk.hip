@@ -9,6 +9,8 @@
 #include <cmath>
 
 #include "mf_common.h"
+#include <vector>
+
 #include "mf_select.h"
 
 // Exclusion prefilter as a bitmask: exclW[tile][query] holds the 32 "excluded" bits of
@@ -24,6 +26,7 @@ struct RetrievalPolicy {
         uint32_t ew;
     };
     static constexpr int AUX_DMA = 1;
+    static constexpr bool PREFILTER = true;      // hi = mf_orderable(score)
     static __device__ __forceinline__ void stage_aux(const Params& p, char* aux, int wave, int t, int64_t x0) {
         mf_stage_small(aux + wave * 128, p.exclW + (int64_t)t * p.Qp + x0, 128);
     }
@@ -55,6 +58,7 @@ struct TopkWs {
     unsigned long long* cand;
     int32_t* cand_cnt;
     uint32_t* exclW;
+    unsigned* gtau;      // right behind exclW: one memset clears both
     size_t total;
 };
 
@@ -66,6 +70,7 @@ static TopkWs topk_ws(void* base, int64_t Q, int64_t N, int d, int k) {
     w.cand = a.take<unsigned long long>((size_t)w.plan.nsets * w.plan.Xp * w.plan.CAP);
     w.cand_cnt = a.take<int32_t>((size_t)w.plan.nsets * w.plan.Xp);
     w.exclW = a.take<uint32_t>((size_t)w.NT * w.plan.Xp);
+    w.gtau = a.take<unsigned>((size_t)w.plan.Xp);
     w.total = a.used();
     return w;
 }
@@ -148,6 +153,19 @@ static void launch_topk_select(const TopkWs& w, const RetrievalPolicy::Params& r
     }
 }
 
+#ifdef MF_PROBE
+static TopkWs g_probe_ws;
+extern "C" long long mf_probe_topk_cand() {       // tools/topk_probe.py: candidate keys kept by the last mf_topk
+    (void)hipDeviceSynchronize();
+    const size_t n = (size_t)g_probe_ws.plan.nsets * g_probe_ws.plan.Xp;
+    std::vector<int32_t> h(n);
+    (void)hipMemcpy(h.data(), g_probe_ws.cand_cnt, n * 4, hipMemcpyDeviceToHost);
+    long long t = 0;
+    for (int32_t c : h) t += c;
+    return t;
+}
+#endif
+
 extern "C" int mf_topk(const float* q, int64_t Q, const float* items, int64_t N, int d, int k,
                        const int64_t* excl_off, const int64_t* excl_idx, int64_t idx_base, void* ws,
                        size_t ws_bytes, float* out_scores, int64_t* out_idx, mf_stream_t stream) {
@@ -162,10 +180,13 @@ extern "C" int mf_topk(const float* q, int64_t Q, const float* items, int64_t N,
     hipStream_t s = static_cast<hipStream_t>(stream);
     TopkWs w = topk_ws(ws, Q, N, d, k);
     if (!w.plan.ok) return mf_set_error(MF_ENOTSUP, "mf_topk: k = %d too large at d = %d", k, d);
-    (void)hipMemsetAsync(w.exclW, 0, (size_t)w.NT * w.plan.Xp * 4, s);
+#ifdef MF_PROBE
+    g_probe_ws = w;
+#endif
+    (void)hipMemsetAsync(w.exclW, 0, (size_t)((char*)(w.gtau + w.plan.Xp) - (char*)w.exclW), s);
     if (excl_off) excl_scatter_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.plan.Xp, w.exclW);
     RetrievalPolicy::Params rp{w.exclW, w.plan.Xp, N};
-    SelectCommon sc{q, Q, items, N, w.NT, w.plan.tpc, w.plan.Xp, k, w.plan.xw, w.plan.CAPL, w.cand, w.cand_cnt};
+    SelectCommon sc{q, Q, items, N, w.NT, w.plan.tpc, w.plan.Xp, k, w.plan.xw, w.plan.CAPL, w.gtau, w.cand, w.cand_cnt};
     MF_DISPATCH_D(d, { MF_TIMED("topk_select", s, launch_topk_select<D>(w, rp, sc, s)); });
     topk_merge_cand_kernel<<<dim3((unsigned)Q), 64, (size_t)w.plan.nsets * w.plan.CAP * 8, s>>>(w.cand, w.cand_cnt, w.plan.nsets, w.plan.Xp, w.plan.CAP, k,
                                                                                       idx_base, out_scores, out_idx);

@@ -158,6 +158,38 @@ class EmbeddingLoss(torch.nn.Module, abc.ABC):
         self.check_inputs(user_embed, item_embed, target)
         return self.loss(user_embed, item_embed, target, item_idx=item_idx, pos_idx=pos_idx, logq=logq)
 
+    # ---- the reference's public helper methods, on caller-provided tensors (API parity; not the hot path)
+    @torch.no_grad()
+    def negative_masks(self, logits: torch.Tensor, *, item_idx: torch.Tensor,
+                       pos_idx: torch.Tensor | None = None) -> torch.Tensor:
+        """``~accidental_hits`` of losses.py:92-110: bool ``[B, N]``, True = valid negative."""
+        b, n = logits.size(0), item_idx.numel()
+        ii = _lib.dev_i64(item_idx, "item_idx")
+        pi = None if pos_idx is None or pos_idx.shape[1] == 0 else _lib.dev_i64(pos_idx, "pos_idx")
+        p = 0 if pi is None else pi.shape[1]
+        lib = _lib.lib()
+        ws = _lib.workspace(lib.mf_negative_masks_ws_bytes(b, n, p), ii.device)
+        out = torch.empty(b, n, dtype=torch.uint8, device=ii.device)
+        _lib.check(lib.mf_negative_masks(b, n, p, _lib.ptr(ii), _lib.ptr(pi), _lib.ptr(ws), ws.numel(), _lib.ptr(out),
+                                         _lib.stream_ptr()))
+        return out.bool()
+
+    @torch.no_grad()
+    def _mine(self, logits: torch.Tensor, negative_masks: torch.Tensor, semi_hard: bool) -> torch.Tensor:
+        lg = _lib.dev_f32(logits, "logits")
+        m = negative_masks.to(device=lg.device, dtype=torch.uint8).contiguous().clone()
+        _lib.check(_lib.lib().mf_mine_logits(_lib.ptr(lg), lg.shape[0], lg.shape[1], int(self.num_negatives),
+                                             int(semi_hard), _lib.ptr(m), _lib.stream_ptr()))
+        return m.bool()
+
+    def hard_mining(self, logits: torch.Tensor, negative_masks: torch.Tensor) -> torch.Tensor:
+        """losses.py:112-132 (defined upstream, never called): keep the ``num_negatives`` highest logits."""
+        return self._mine(logits, negative_masks, semi_hard=False)
+
+    def semi_hard_mining(self, logits: torch.Tensor, negative_masks: torch.Tensor) -> torch.Tensor:
+        """losses.py:134-162 on a materialised logits matrix (the losses themselves mine on the fly)."""
+        return self._mine(logits, negative_masks, semi_hard=True)
+
     def loss(self, user_embed, item_embed, target, *, item_idx, pos_idx, logq=None) -> torch.Tensor:
         k = int(self.num_negatives)
         if 0 < k < item_embed.size(0) and k > MAX_MINED_NEGATIVES and self.kind != 0:

@@ -302,3 +302,25 @@ def test_backward_can_be_repeated_and_fused_losses_backprop_together(mf):
     u2.grad = None
     loss.backward()
     assert torch.equal(g1, u2.grad)
+
+
+@pytest.mark.parametrize("path", golden_files()[:3], ids=lambda p: p.stem)
+def test_public_mask_and_mining_helpers_match_reference(mf, path):
+    """negative_masks / semi_hard_mining / hard_mining as methods, against the reference's own masks
+    (golden) and the oracle, on the reference's own logits."""
+    z = np.load(path)
+    t = {k: torch.from_numpy(z[k]) for k in ("u", "v", "target", "item_idx", "pos_idx")}
+    b, n = t["u"].shape[0], t["v"].shape[0]
+    lg = torch.from_numpy(z["logits_0"])
+    fn0 = mf.losses.PairwiseHingeLoss(num_negatives=0)
+    base = fn0.negative_masks(lg.to(DEV), item_idx=t["item_idx"].to(DEV), pos_idx=t["pos_idx"].to(DEV)).cpu()
+    want0 = np.unpackbits(z["mask_0_0"])[: b * n].reshape(b, n).astype(bool)
+    assert np.array_equal(base.numpy(), want0)
+    fn4 = mf.losses.PairwiseHingeLoss(num_negatives=4)
+    semi = fn4.semi_hard_mining(lg.to(DEV), base.to(DEV)).cpu()
+    assert torch.equal(semi, ol.semi_hard_mining(lg, base.clone(), 4))
+    hard = fn4.hard_mining(lg.to(DEV), base.to(DEV)).cpu()
+    key = torch.where(base, lg, torch.full_like(lg, -float("inf")))
+    top = torch.argsort(key, dim=1, descending=True, stable=True)[:, :4]
+    want_h = torch.zeros_like(base).scatter_(1, top, True) & base
+    assert torch.equal(hard, want_h)
