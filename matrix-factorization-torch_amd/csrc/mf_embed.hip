@@ -145,6 +145,64 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const int64_t* __rest
     if (sorted_keys) sorted_keys[p] = keys[r];
 }
 
+// Packed variant used by the sparse updates: when bits(id_limit + 1) + bits(n) <= 32 the pair
+// (id, position) is ONE 32-bit word -- four keys per ds_read_b128, two VALU instructions per
+// comparison -- and out-of-range ids (skipped by the update anyway) share the bucket id_limit.
+// Every (row block, tile stripe) writes its own partial count: no atomics, no memset.
+static constexpr int SORT_TILE32 = 1024;
+static constexpr int SORT_MAX_STRIPES = 32;
+
+__device__ __forceinline__ unsigned sort_pack(long long id, unsigned q, long long id_limit, int posbits) {
+    const unsigned b = (id >= 0 && id < id_limit) ? (unsigned)id : (unsigned)id_limit;
+    return (b << posbits) | q;
+}
+
+__global__ __launch_bounds__(256) void rank_count32_kernel(const int64_t* __restrict__ keys, int n, long long id_limit,
+                                                           int posbits, int32_t* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) unsigned tile[SORT_TILE32];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const unsigned mine = r < n ? sort_pack(keys[r], (unsigned)r, id_limit, posbits) : 0u;
+    int cnt = 0;
+    for (int base = blockIdx.y * SORT_TILE32; base < n; base += gridDim.y * SORT_TILE32) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < SORT_TILE32; t += 256) {
+            const int q = base + t;
+            tile[t] = q < n ? sort_pack(keys[q], (unsigned)q, id_limit, posbits) : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int t = 0; t < SORT_TILE32; t += 4) {
+            const uint4 k = *reinterpret_cast<const uint4*>(&tile[t]);   // same address in every lane: LDS broadcast
+            cnt += (k.x < mine ? 1 : 0) + (k.y < mine ? 1 : 0) + (k.z < mine ? 1 : 0) + (k.w < mine ? 1 : 0);
+        }
+    }
+    if (r < n) part[(int64_t)blockIdx.y * n + r] = cnt;
+}
+
+__global__ __launch_bounds__(256) void rank_scatter32_kernel(const int64_t* __restrict__ keys, int n, int stripes,
+                                                             const int32_t* __restrict__ part,
+                                                             int32_t* __restrict__ perm,
+                                                             int64_t* __restrict__ sorted_keys) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    int p = 0;
+    for (int y = 0; y < stripes; ++y) p += part[(int64_t)y * n + r];
+    perm[p] = r;
+    sorted_keys[p] = keys[r];
+}
+
+static int sort_stripes(int64_t n) {
+    const int ny = (int)((n + SORT_TILE32 - 1) / SORT_TILE32);
+    return ny < SORT_MAX_STRIPES ? ny : SORT_MAX_STRIPES;
+}
+// posbits if the packed sort applies to (n keys, ids below id_limit), else -1
+static int sort_packed_posbits(int64_t n, int64_t id_limit) {
+    if (n <= 0 || n > (1 << 20) || id_limit <= 0) return -1;
+    int posbits = 0;
+    while ((1ll << posbits) < n) ++posbits;
+    return (((unsigned long long)(id_limit + 1)) << posbits) <= (1ull << 32) ? posbits : -1;
+}
+
 extern "C" size_t mf_sort_ws_bytes(int64_t n) { return mf_align_up((size_t)(n > 0 ? n : 1) * 4, 256); }
 
 extern "C" int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64_t* sorted_keys,
@@ -169,9 +227,11 @@ struct AdamHyper {
 
 // One d/4-lane group per sorted position.  Runs of equal ids are summed in two
 // deterministic levels so that a very popular row (Zipf: hundreds of duplicates in
-// one batch) does not serialise on one group: every 32nd position of a run sums up
-// to 32 gradient rows (batch order); a run longer than 32 parks these partial sums
-// and its first position adds them up in order in a second launch.
+// one batch) does not serialise on one group.  A CHUNK starts at a run's first position
+// and at every position that is a multiple of 32; its owner sums the chunk's <= 32 gradient
+// rows in sorted (= batch) order.  A run that is one chunk is applied at once; otherwise the
+// chunk sums are parked and the run's first position adds them up, in order, in a second
+// launch.  Chunk boundaries depend on sorted positions only: deterministic.
 template <int D, bool ADAM>
 __device__ __forceinline__ void apply_row_update(bool active, int64_t row, int c, f32x4 acc,
                                                  float* __restrict__ table, float* __restrict__ exp_avg,
@@ -225,33 +285,39 @@ __global__ __launch_bounds__(256) void update_rows_kernel(float* __restrict__ ta
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t p = wave * RPW + lane / LPR;
     const int c = lane % LPR;
-    int64_t row = 0, start = 0;
-    bool in_range = false;
+    int64_t row = 0;
+    bool head = false, owner = false;
     if (p < n) {
         row = skeys[p];
-        in_range = row >= 0 && row < n_rows;
-        int64_t lo = 0, hi = p;                       // first position of this id
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (skeys[mid] < row) lo = mid + 1; else hi = mid;
-        }
-        start = lo;
+        const bool in_range = row >= 0 && row < n_rows;
+        head = in_range && (p == 0 || skeys[p - 1] != row);
+        owner = in_range && (head || (p % RUN_CHUNK) == 0);
     }
-    const bool is_start = p < n && p == start;
-    const bool long_run = p < n && start + RUN_CHUNK < n && skeys[start + RUN_CHUNK] == row;
+    const int64_t chunk_end = (p / RUN_CHUNK + 1) * RUN_CHUNK;         // next chunk boundary after p
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     bool apply = false;
     if (PHASE == 1) {
-        const bool subhead = p < n && in_range && ((p - start) % RUN_CHUNK) == 0;
-        if (subhead) {
-            for (int64_t q = p; q < n && q < p + RUN_CHUNK && skeys[q] == row; ++q)
-                acc += reinterpret_cast<const f32x4*>(grad + (int64_t)perm[q] * D)[c];
-            if (long_run) reinterpret_cast<f32x4*>(partial + p * D)[c] = acc;
-            else apply = true;                        // short run: p is its start, acc is complete
+        if (owner) {
+            int64_t e = p + 1;                                          // end of this chunk inside the run
+            while (e < n && e < chunk_end && skeys[e] == row) ++e;
+            int64_t q = p;
+            for (; q + 4 <= e; q += 4) {                                // four rows in flight, added in order
+                f32x4 g[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = reinterpret_cast<const f32x4*>(grad + (int64_t)perm[q + j] * D)[c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += g[j];
+            }
+            for (; q < e; ++q) acc += reinterpret_cast<const f32x4*>(grad + (int64_t)perm[q] * D)[c];
+            const bool whole = head && (e >= n || skeys[e] != row);     // the run is this one chunk
+            if (whole) apply = true;
+            else reinterpret_cast<f32x4*>(partial + p * D)[c] = acc;
         }
     } else {
-        if (is_start && in_range && long_run) {
-            for (int64_t q = p; q < n && skeys[q] == row; q += RUN_CHUNK)
+        const bool multi = head && chunk_end < n && skeys[chunk_end] == row;   // run continues into the next chunk
+        if (multi) {
+            acc = reinterpret_cast<const f32x4*>(partial + p * D)[c];
+            for (int64_t q = chunk_end; q < n && skeys[q] == row; q += RUN_CHUNK)
                 acc += reinterpret_cast<const f32x4*>(partial + q * D)[c];
             apply = true;
         }
@@ -271,7 +337,8 @@ static UpdateWs update_ws(void* ws, int64_t n, int d) {
     UpdateWs w;
     w.perm = a.take<int32_t>((size_t)n);
     w.skeys = a.take<int64_t>((size_t)n);
-    w.sort_ws = a.take<char>(mf_sort_ws_bytes(n));
+    const size_t packed = (size_t)n * 4 * sort_stripes(n);       // partial counts of the packed sort
+    w.sort_ws = a.take<char>(packed > mf_sort_ws_bytes(n) ? packed : mf_sort_ws_bytes(n));
     w.partial = a.take<float>((size_t)n * d);
     w.total = a.used();
     return w;
@@ -290,9 +357,17 @@ static int update_common(float* table, float* m, float* v, int64_t n_rows, int d
     if (ws_bytes < mf_update_ws_bytes(n, d)) return mf_set_error(MF_ENOSPC, "%s: workspace too small", what);
     if (n == 0) return MF_OK;
     UpdateWs w = update_ws(ws, n, d);
-    int rc = mf_sort_keys(idx, n, w.perm, w.skeys, w.sort_ws, mf_sort_ws_bytes(n), stream);
-    if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const int posbits = sort_packed_posbits(n, n_rows);
+    if (posbits >= 0) {
+        const int stripes = sort_stripes(n);
+        int32_t* part = reinterpret_cast<int32_t*>(w.sort_ws);
+        rank_count32_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)stripes), 256, 0, s>>>(idx, (int)n, n_rows, posbits, part);
+        rank_scatter32_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, s>>>(idx, (int)n, stripes, part, w.perm, w.skeys);
+    } else {
+        int rc = mf_sort_keys(idx, n, w.perm, w.skeys, w.sort_ws, mf_sort_ws_bytes(n), stream);
+        if (rc) return rc;
+    }
     MF_DISPATCH_D(d, {
         constexpr int RPB = (64 / (D / 4)) * 4;
         dim3 grid((unsigned)((n + RPB - 1) / RPB));

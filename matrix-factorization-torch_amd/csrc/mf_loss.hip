@@ -51,7 +51,8 @@ struct LossWs {
     int32_t *colslot, *gfirst, *colfirst;
     uint32_t *ubits, *dupmask;
     uint32_t* maskW;
-    float *part, *stats, *rowloss, *rowc, *dpart, *stash, *gstash;
+    float *part, *stats, *rowloss, *rowc, *dpart, *stash, *gstash, *blockpart;
+    unsigned* ticket;
     unsigned long long* cand;
     int32_t *cand_cnt, *sel, *sel_cnt;
     unsigned* gtau;
@@ -99,6 +100,8 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.stats = a.take<float>((size_t)NSTAT * w.Bp);
     w.rowloss = a.take<float>((size_t)MF_NUM_KINDS * w.Bp);
     w.rowc = a.take<float>((size_t)4 * w.Bp);
+    w.blockpart = a.take<float>((size_t)MF_NUM_KINDS * (w.Bp / 256 + 1));
+    w.ticket = a.take<unsigned>(4);
     if (w.mined) {
         w.cand = a.take<unsigned long long>((size_t)w.nchunk * w.Bp * w.CAP);
         w.cand_cnt = a.take<int32_t>((size_t)w.nchunk * w.Bp);
@@ -124,25 +127,65 @@ extern "C" size_t mf_loss_ws_bytes(int64_t B, int64_t N, int d, int P, int num_n
     return loss_ws(nullptr, B, N, d, P, num_negatives).total;
 }
 
-// ------------------------------------------------------------------ diagonal ---
-__global__ __launch_bounds__(256) void diag_kernel(const float* __restrict__ u, const float* __restrict__ v,
-                                                   const float* __restrict__ target,
-                                                   const float* __restrict__ logq,
-                                                   const float* __restrict__ nu, const float* __restrict__ nv,
-                                                   int64_t B, int64_t Bp, int d, float sigma,
-                                                   float* __restrict__ lii, float* __restrict__ dii,
-                                                   float* __restrict__ sgn) {
+// ------------------------------------------------------------- per-call setup ---
+// ONE launch for everything the sweeps need that is O(B + N): chain norms of both operands, the
+// diagonal (L_ii, D_ii, sign), the zero-padded logQ copy, and the clearing of the hash table, the
+// per-user bit rows and the reduction ticket.  (Each of these used to be its own ~5 us launch.)
+struct PrepParams {
+    const float *u, *v, *target, *logq;
+    int64_t B, N, Bp, Np;
+    int d;
+    float sigma;
+    float *nu, *nv, *lii, *dii, *sgn, *wlogq;
+    uint4* gtab; int64_t gtab16;        // fills, in 16-byte units (0 = skip)
+    uint4* gfirst; int64_t gfirst16;
+    uint4* ubits; int64_t ubits16;
+    unsigned* ticket;
+};
+
+__device__ __forceinline__ void fill16(uint4* dst, int64_t n16, unsigned pat, int64_t tid, int64_t nthreads) {
+    const uint4 v = {pat, pat, pat, pat};
+    for (int64_t q = tid; q < n16; q += nthreads) dst[q] = v;
+}
+
+__global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= Bp) return;
-    if (i >= B) {
-        lii[i] = 0.f; dii[i] = 0.f; sgn[i] = 0.f;
-        return;
+    if (i < p.Np) {
+        const bool hv = i < p.N, hu = i < p.B;                  // B <= N: a user row always has its item row
+        float nvv = 0.f, nuu = 0.f, dot = 0.f;
+        if (hv) {
+            const f32x4* pv = reinterpret_cast<const f32x4*>(p.v + i * p.d);
+            const f32x4* pu = reinterpret_cast<const f32x4*>(p.u + (hu ? i : 0) * p.d);
+            for (int g = 0; g < p.d / 8; ++g) {                 // k order of mf_dot_chain
+                const f32x4 a = pv[2 * g], b = pv[2 * g + 1];
+                f32x4 ua = {0.f, 0.f, 0.f, 0.f}, ub = ua;
+                if (hu) { ua = pu[2 * g]; ub = pu[2 * g + 1]; }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    nvv = __builtin_fmaf(a[t], a[t], nvv);  nvv = __builtin_fmaf(b[t], b[t], nvv);
+                    nuu = __builtin_fmaf(ua[t], ua[t], nuu); nuu = __builtin_fmaf(ub[t], ub[t], nuu);
+                    dot = __builtin_fmaf(ua[t], a[t], dot);  dot = __builtin_fmaf(ub[t], b[t], dot);
+                }
+            }
+        }
+        p.nv[i] = nvv;
+        const float lq = (p.logq && hv) ? p.logq[i] : 0.f;
+        p.wlogq[i] = lq;
+        if (i < p.Bp) {
+            float l = 0.f, dd = 0.f, sg = 0.f;
+            if (hu) {
+                sg = mf_sign(p.target[i]);
+                dd = mf_half_sqdist(nuu, nvv, dot);
+                l = mf_logit(nuu, nvv, dot, sg, p.sigma, lq);
+            }
+            p.nu[i] = nuu; p.lii[i] = l; p.dii[i] = dd; p.sgn[i] = sg;
+        }
     }
-    const float dot = mf_dot_chain(u + i * d, v + i * d, d);
-    const float s = mf_sign(target[i]);
-    dii[i] = mf_half_sqdist(nu[i], nv[i], dot);
-    lii[i] = mf_logit(nu[i], nv[i], dot, s, sigma, logq ? logq[i] : 0.f);
-    sgn[i] = s;
+    if (i == 0) *p.ticket = 0u;
+    const int64_t nthreads = (int64_t)gridDim.x * 256;
+    fill16(p.gtab, p.gtab16, 0x80808080u, i, nthreads);
+    fill16(p.gfirst, p.gfirst16, 0x7f7f7f7fu, i, nthreads);
+    fill16(p.ubits, p.ubits16, 0u, i, nthreads);
 }
 
 // ------------------------------------------------------------------ hit masks --
@@ -182,25 +225,22 @@ __global__ __launch_bounds__(256) void gt_insert_kernel(const int64_t* __restric
 }
 
 // colfirst[j] = first column with column j's item; dupmask[t] bit c = column 32 t + c is not that first column
-__global__ __launch_bounds__(256) void colfirst_kernel(const int32_t* __restrict__ colslot,
-                                                       const int32_t* __restrict__ gfirst, int64_t N, int64_t Np,
-                                                       int32_t* __restrict__ colfirst, uint32_t* __restrict__ dupmask) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= Np) return;
+__device__ __forceinline__ void colfirst_body(int64_t j, const int32_t* __restrict__ colslot,
+                                              const int32_t* __restrict__ gfirst, int64_t N, int64_t Np,
+                                              int32_t* __restrict__ colfirst, uint32_t* __restrict__ dupmask) {
     int32_t f = -1;
     if (j < N) f = gfirst[colslot[j]];
-    colfirst[j] = f;
+    if (j < Np) colfirst[j] = f;
     const unsigned long long bal = __ballot(j < N && f != (int32_t)j);
     const int lane = mf_lane();
-    if (lane == 0) dupmask[j >> 5] = (uint32_t)bal;
-    if (lane == 32) dupmask[j >> 5] = (uint32_t)(bal >> 32);
+    if (j < Np && lane == 0) dupmask[j >> 5] = (uint32_t)bal;
+    if (j < Np && lane == 32) dupmask[j >> 5] = (uint32_t)(bal >> 32);
 }
 
-__global__ __launch_bounds__(256) void ubits_kernel(const int64_t* __restrict__ item_idx,
-                                                    const int64_t* __restrict__ pos_idx, int64_t B, int P, int M,
-                                                    const long long* __restrict__ gtab, const int32_t* __restrict__ gfirst,
-                                                    int64_t Bp, uint32_t* __restrict__ ubits) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ubits_body(int64_t t, const int64_t* __restrict__ item_idx,
+                                           const int64_t* __restrict__ pos_idx, int64_t B, int P, int M,
+                                           const long long* __restrict__ gtab, const int32_t* __restrict__ gfirst,
+                                           int64_t Bp, uint32_t* __restrict__ ubits) {
     const int64_t i = t / (P + 1);
     const int p = (int)(t % (P + 1));
     if (i >= B) return;
@@ -218,22 +258,47 @@ __global__ __launch_bounds__(256) void ubits_kernel(const int64_t* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void mask_sweep_kernel(const int32_t* __restrict__ colfirst,
-                                                         const uint32_t* __restrict__ dupmask,
-                                                         const uint32_t* __restrict__ ubits, int64_t B, int64_t N,
-                                                         int64_t Bp, int NT, uint32_t* __restrict__ maskW) {
+// both only need the finished hash table: blocks [0, nb_col) do the columns, the rest the users' positives
+__global__ __launch_bounds__(256) void hits_kernel(const int64_t* __restrict__ item_idx, const int64_t* __restrict__ pos_idx,
+                                                   int64_t B, int64_t N, int64_t Bp, int64_t Np, int P, int M, int nb_col,
+                                                   const long long* __restrict__ gtab, const int32_t* __restrict__ gfirst,
+                                                   const int32_t* __restrict__ colslot, int32_t* __restrict__ colfirst,
+                                                   uint32_t* __restrict__ dupmask, uint32_t* __restrict__ ubits) {
+    if ((int)blockIdx.x < nb_col)
+        colfirst_body((int64_t)blockIdx.x * 256 + threadIdx.x, colslot, gfirst, N, Np, colfirst, dupmask);
+    else
+        ubits_body((int64_t)(blockIdx.x - nb_col) * 256 + threadIdx.x, item_idx, pos_idx, B, P, M, gtab, gfirst, Bp, ubits);
+}
+
+// mask word of (user, column tile): the tile's first-occurrence columns at once, plus one probe per
+// DUPLICATE column at its item's first column.  One workgroup owns 32 users and keeps their whole
+// bit-row slab [NT][32 users] in LDS (LDS = true), so the probes -- ~10 per word under a Zipf batch --
+// are LDS reads; 16 waves per workgroup hide their latency.  Larger N: probes go to L2 (LDS = false).
+template <bool LDS>
+__global__ __launch_bounds__(1024) void mask_sweep_kernel(const int32_t* __restrict__ colfirst,
+                                                          const uint32_t* __restrict__ dupmask,
+                                                          const uint32_t* __restrict__ ubits, int64_t B, int64_t N,
+                                                          int64_t Bp, int NT, uint32_t* __restrict__ maskW) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t slab[];      // [NT][32]
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int64_t i = (int64_t)blockIdx.x * 32 + c;
     const bool user_ok = i < B;
-    const int hw = (threadIdx.x >> 6) * 2 + h;            // half-wave id inside the block: 0..7
-    for (int tj = blockIdx.y * 8 + hw; tj < NT; tj += 8 * gridDim.y) {
-        uint32_t word = ubits[(int64_t)tj * Bp + i];       // the tile's first-occurrence columns, all at once
+    const int nhw = (int)(blockDim.x >> 5);
+    const int hw = (int)(threadIdx.x >> 6) * 2 + h;                       // half-wave id inside the block
+    if (LDS) {
+        for (int tj = hw; tj < NT; tj += nhw) slab[tj * 32 + c] = ubits[(int64_t)tj * Bp + i];
+        __syncthreads();
+    }
+    for (int tj = blockIdx.y * nhw + hw; tj < NT; tj += nhw * gridDim.y) {
+        uint32_t word = LDS ? slab[tj * 32 + c] : ubits[(int64_t)tj * Bp + i];
         uint32_t dm = dupmask[tj];
-        while (dm) {                                        // duplicate columns: look at their item's first column
+        const int32_t cf = colfirst[tj * 32 + c];                          // lane c: first column of column c's item
+        while (dm) {                                                       // duplicate columns of this tile
             const int c2 = __builtin_ctz(dm);
             dm &= dm - 1;
-            const int f = colfirst[tj * 32 + c2];
-            word |= ((ubits[(int64_t)(f >> 5) * Bp + i] >> (f & 31)) & 1u) << c2;
+            const int f = __shfl(cf, c2 + 32 * h, 64);
+            const uint32_t src = LDS ? slab[(f >> 5) * 32 + c] : ubits[(int64_t)(f >> 5) * Bp + i];
+            word |= ((src >> (f & 31)) & 1u) << c2;
         }
         const int64_t left = N - (int64_t)tj * 32;          // padding columns / padding users: never a negative
         if (left < 32) word |= ~0u << (left > 0 ? (int)left : 0);
@@ -450,65 +515,75 @@ static void launch_fwd(int need, dim3 grid, const FwdParams& fp, hipStream_t s) 
     }
 }
 
-// merge the item-range splits in split order (deterministic)
-__global__ __launch_bounds__(256) void stats_merge_kernel(const float* __restrict__ part, int nsplit,
-                                                          int64_t Bp, float* __restrict__ stats) {
+// The tail of the forward in ONE launch: merge the item-range splits of the row statistics in split
+// order (nsplit = 0: `stats` is already final), evaluate the seven per-row losses, and sum them over
+// the batch in a fixed order: in-block tree, then the last workgroup to finish (ticket) adds the
+// block sums in block order -- deterministic, no second launch.
+__global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ part, int nsplit, int64_t B, int64_t Bp,
+                                                     const float* __restrict__ target, const float* __restrict__ lii,
+                                                     const float* __restrict__ dii, float sigma, int kind_mask,
+                                                     float* __restrict__ stats, float* __restrict__ rowloss,
+                                                     float* __restrict__ blockpart, unsigned* __restrict__ ticket,
+                                                     float* __restrict__ out) {
+    __shared__ float sh[MF_NUM_KINDS][256];
+    __shared__ bool last;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= Bp) return;
     float acc[NSTAT];
-    for (int s = 0; s < NSTAT; ++s) acc[s] = part[(int64_t)s * Bp + i];
-    for (int sp = 1; sp < nsplit; ++sp) {
-        const float* q = part + (int64_t)sp * NSTAT * Bp + i;
-        lse_merge(acc[ST_MX], acc[ST_SE], q[ST_MX * Bp], q[ST_SE * Bp]);
-        acc[ST_CNT] += q[ST_CNT * Bp]; acc[ST_A] += q[ST_A * Bp]; acc[ST_H] += q[ST_H * Bp];
-        acc[ST_HC] += q[ST_HC * Bp]; acc[ST_LG] += q[ST_LG * Bp]; acc[ST_LS] += q[ST_LS * Bp];
+    if (i < Bp) {
+        if (nsplit > 0) {
+            for (int s = 0; s < NSTAT; ++s) acc[s] = part[(int64_t)s * Bp + i];
+            for (int sp = 1; sp < nsplit; ++sp) {
+                const float* q = part + (int64_t)sp * NSTAT * Bp + i;
+                lse_merge(acc[ST_MX], acc[ST_SE], q[ST_MX * Bp], q[ST_SE * Bp]);
+                acc[ST_CNT] += q[ST_CNT * Bp]; acc[ST_A] += q[ST_A * Bp]; acc[ST_H] += q[ST_H * Bp];
+                acc[ST_HC] += q[ST_HC * Bp]; acc[ST_LG] += q[ST_LG * Bp]; acc[ST_LS] += q[ST_LS * Bp];
+            }
+            for (int s = 0; s < NSTAT; ++s) stats[(int64_t)s * Bp + i] = acc[s];
+        } else {
+            for (int s = 0; s < NSTAT; ++s) acc[s] = stats[(int64_t)s * Bp + i];
+        }
     }
-    for (int s = 0; s < NSTAT; ++s) stats[(int64_t)s * Bp + i] = acc[s];
-}
-
-// per-row losses of all seven classes from the row statistics
-__global__ __launch_bounds__(256) void rowloss_kernel(const float* __restrict__ stats, const float* __restrict__ target,
-                                                      const float* __restrict__ lii, const float* __restrict__ dii,
-                                                      int64_t B, int64_t Bp, float sigma, float* __restrict__ rowloss) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= Bp) return;
-    float out[MF_NUM_KINDS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float o[MF_NUM_KINDS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < B) {
         const float t = target[i], w = fabsf(t), l = lii[i];
-        const float cnt = stats[ST_CNT * Bp + i], mx = stats[ST_MX * Bp + i], se = stats[ST_SE * Bp + i];
+        const float cnt = acc[ST_CNT], mx = acc[ST_MX], se = acc[ST_SE];
         const float den = cnt + 1e-10f;
         const float align = dii[i] * t * sigma;                       // losses.py:164-170
-        const float contr = (stats[ST_A * Bp + i] / den) * w;         // losses.py:172-193
+        const float contr = (acc[ST_A] / den) * w;                    // losses.py:172-193
         const float m2 = fmaxf(mx, l);
         const float se2 = se * __expf(mx - m2) + __expf(l - m2);
         const float lse_all = m2 + __logf(se2);                       // diagonal forced in, :213-215
         const float lse_neg = cnt > 0.f ? mx + __logf(se) : -INFINITY;  // :242 (no valid negative: -inf)
-        out[MF_ALIGNMENT] = align;
-        out[MF_CONTRASTIVE] = contr;
-        out[MF_ALIGNMENT_CONTRASTIVE] = align + contr;
-        out[MF_INFONCE] = (lse_all - l) * w;
-        out[MF_MINE] = (-l + lse_neg) * w;
-        out[MF_PAIRWISE_HINGE] = (stats[ST_H * Bp + i] / den) * w;
-        out[MF_PAIRWISE_LOGISTIC] = (stats[ST_LG * Bp + i] / den) * w;
+        o[MF_ALIGNMENT] = align;
+        o[MF_CONTRASTIVE] = contr;
+        o[MF_ALIGNMENT_CONTRASTIVE] = align + contr;
+        o[MF_INFONCE] = (lse_all - l) * w;
+        o[MF_MINE] = (-l + lse_neg) * w;
+        o[MF_PAIRWISE_HINGE] = (acc[ST_H] / den) * w;
+        o[MF_PAIRWISE_LOGISTIC] = (acc[ST_LG] / den) * w;
     }
-    for (int k = 0; k < MF_NUM_KINDS; ++k) rowloss[(int64_t)k * Bp + i] = out[k];
-}
-
-// fixed-order sum over the batch: one block per loss kind
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ rowloss, int64_t B, int64_t Bp,
-                                                          int kind_mask, float* __restrict__ out) {
-    __shared__ float sh[256];
-    const int k = blockIdx.x;
-    if (!((kind_mask >> k) & 1)) return;
-    float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < B; i += 256) acc += rowloss[(int64_t)k * Bp + i];
-    sh[threadIdx.x] = acc;
+    for (int k = 0; k < MF_NUM_KINDS; ++k) {
+        if (i < Bp) rowloss[(int64_t)k * Bp + i] = o[k];
+        sh[k][threadIdx.x] = o[k];
+    }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+            for (int k = 0; k < MF_NUM_KINDS; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[k] = sh[0];
+    if (threadIdx.x < MF_NUM_KINDS) blockpart[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = sh[threadIdx.x][0];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (last && threadIdx.x < MF_NUM_KINDS && ((kind_mask >> threadIdx.x) & 1)) {
+        __threadfence();
+        float tot = 0.f;
+        const volatile float* bp = blockpart + (int64_t)threadIdx.x * gridDim.x;
+        for (unsigned b = 0; b < gridDim.x; ++b) tot += bp[b];
+        out[threadIdx.x] = tot;
+    }
 }
 
 __global__ __launch_bounds__(256) void mask_export_dense_kernel(const uint32_t* __restrict__ maskW, int64_t B,
@@ -895,20 +970,32 @@ __global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------ C ABI ------
 // negative_masks of the reference (losses.py:92-110) into w.maskW
-static void build_masks(const LossWs& w, const int64_t* item_idx, const int64_t* pos_idx, int64_t B, int64_t N, int P,
-                        hipStream_t s) {
+static void clear_mask_tables(const LossWs& w, hipStream_t s) {     // mf_loss_fwd does this inside prep_kernel
     (void)hipMemsetAsync(w.gtab, 0x80, (size_t)w.M * 8, s);
     (void)hipMemsetAsync(w.gfirst, 0x7f, (size_t)w.M * 4, s);
     (void)hipMemsetAsync(w.ubits, 0, (size_t)w.NT * w.Bp * 4, s);
+}
+
+// expects gtab / gfirst / ubits cleared
+static void build_masks(const LossWs& w, const int64_t* item_idx, const int64_t* pos_idx, int64_t B, int64_t N, int P,
+                        hipStream_t s) {
     gt_insert_kernel<<<dim3((unsigned)((N + 255) / 256)), 256, 0, s>>>(item_idx, N, w.M, w.gtab, w.gfirst, w.colslot);
-    colfirst_kernel<<<dim3((unsigned)((w.Np + 255) / 256)), 256, 0, s>>>(w.colslot, w.gfirst, N, w.Np, w.colfirst, w.dupmask);
-    const int64_t nthreads = B * (P + 1);
-    ubits_kernel<<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(item_idx, pos_idx, B, P, w.M, w.gtab, w.gfirst, w.Bp, w.ubits);
-    int gy = (w.NT + 7) / 8;
-    if (gy > 16) gy = 16;
-    if (gy * w.BT < 1024) gy = (1024 + w.BT - 1) / w.BT;   // enough blocks when B is small
-    if (gy > (w.NT + 7) / 8) gy = (w.NT + 7) / 8;
-    mask_sweep_kernel<<<dim3((unsigned)w.BT, (unsigned)gy), 256, 0, s>>>(w.colfirst, w.dupmask, w.ubits, B, N, w.Bp, w.NT, w.maskW);
+    const int nb_col = (int)((w.Np + 255) / 256);
+    const int nb_u = (int)((B * (P + 1) + 255) / 256);
+    hits_kernel<<<dim3((unsigned)(nb_col + nb_u)), 256, 0, s>>>(item_idx, pos_idx, B, N, w.Bp, w.Np, P, w.M, nb_col, w.gtab,
+                                                                  w.gfirst, w.colslot, w.colfirst, w.dupmask, w.ubits);
+    int gy = 256 / w.BT;                                     // enough workgroups when B is small
+    if (gy > (w.NT + 31) / 32) gy = (w.NT + 31) / 32;
+    if (gy < 1) gy = 1;
+    const size_t slab = (size_t)w.NT * 128;
+    if (slab <= 128 * 1024) {
+        auto fn = mask_sweep_kernel<true>;
+        if (slab > 64 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slab);
+        fn<<<dim3((unsigned)w.BT, (unsigned)gy), 1024, slab, s>>>(w.colfirst, w.dupmask, w.ubits, B, N, w.Bp, w.NT, w.maskW);
+    } else {
+        gy = (w.NT + 31) / 32 < 16 ? (w.NT + 31) / 32 : 16;
+        mask_sweep_kernel<false><<<dim3((unsigned)w.BT, (unsigned)gy), 1024, 0, s>>>(w.colfirst, w.dupmask, w.ubits, B, N, w.Bp, w.NT, w.maskW);
+    }
 }
 
 template <int D, bool XU>
@@ -977,27 +1064,31 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     const int need = need_flags(kind_mask);
     const bool scores_needed = (kind_mask & ~(1 << MF_ALIGNMENT)) != 0 || out_mask_bits;
 
-    (void)hipMemsetAsync(w.nu, 0, (size_t)w.Bp * 4, s);
-    (void)hipMemsetAsync(w.nv, 0, (size_t)w.Np * 4, s);
-    if ((rc = mf_row_sqnorm(u, B, d, w.nu, stream))) return rc;
-    if ((rc = mf_row_sqnorm(v, N, d, w.nv, stream))) return rc;
-    diag_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(u, v, target, logq, w.nu, w.nv, B, w.Bp, d, sigma,
-                                                                     w.lii, w.dii, w.sgn);
-    if (scores_needed) {
-        build_masks(w, item_idx, pos_idx, B, N, P, s);
+    {
+        PrepParams pp{u, v, target, logq, B, N, w.Bp, w.Np, d, sigma, w.nu, w.nv, w.lii, w.dii, w.sgn, w.logq,
+                      nullptr, 0, nullptr, 0, nullptr, 0, w.ticket};
+        int nb = (int)((w.Np + 255) / 256);
+        if (scores_needed) {
+            pp.gtab = reinterpret_cast<uint4*>(w.gtab); pp.gtab16 = (int64_t)w.M * 8 / 16;
+            pp.gfirst = reinterpret_cast<uint4*>(w.gfirst); pp.gfirst16 = (int64_t)w.M * 4 / 16;
+            pp.ubits = reinterpret_cast<uint4*>(w.ubits); pp.ubits16 = (int64_t)w.NT * w.Bp * 4 / 16;
+            const int64_t want = (pp.ubits16 + 256 * 8 - 1) / (256 * 8);     // ~8 stores per thread
+            if (want > nb) nb = (int)(want < 2048 ? want : 2048);
+        }
+        prep_kernel<<<dim3((unsigned)nb), 256, 0, s>>>(pp);
     }
-    // logq is read by whole float4s up to the padded width: keep a zero-padded copy in ws
+    if (scores_needed) build_masks(w, item_idx, pos_idx, B, N, P, s);
+    // logq is read by whole float4s up to the padded width: prep_kernel keeps a zero-padded copy in ws
     // (all zeros when there is no logQ correction: L - 0 is exact, and the kernels stay branch-free)
-    (void)hipMemsetAsync(w.logq, 0, (size_t)w.Np * 4, s);
-    if (logq) (void)hipMemcpyAsync(w.logq, logq, (size_t)N * 4, hipMemcpyDeviceToDevice, s);
     const float* logq_p = w.logq;
+    int merge_splits = 0;
     if (scores_needed && !w.mined) {
         FwdParams fp{u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.part, w.stash, B, N, w.Bp, w.NT, w.tps_f, need, sigma, margin};
         MF_DISPATCH_D(d, {
             dim3 grid((unsigned)w.nsplit_f, (unsigned)(w.BT / 4));
             MF_TIMED("loss_fwd_dense", s, (launch_fwd<D>(need, grid, fp, s)));
         });
-        stats_merge_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(w.part, w.nsplit_f, w.Bp, w.stats);
+        merge_splits = w.nsplit_f;
         if (out_mask_bits)
             mask_export_dense_kernel<<<dim3((unsigned)((B * ((N + 31) / 32) + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, (int)((N + 31) / 32), out_mask_bits);
     } else if (scores_needed) {
@@ -1017,8 +1108,9 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     } else {
         (void)hipMemsetAsync(w.stats, 0, (size_t)NSTAT * w.Bp * 4, s);
     }
-    rowloss_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(w.stats, target, w.lii, w.dii, B, w.Bp, sigma, w.rowloss);
-    loss_reduce_kernel<<<dim3(MF_NUM_KINDS), 256, 0, s>>>(w.rowloss, B, w.Bp, kind_mask, out_losses);
+    finish_kernel<<<dim3((unsigned)(w.Bp / 256 + (w.Bp % 256 ? 1 : 0))), 256, 0, s>>>(w.part, merge_splits, B, w.Bp, target, w.lii, w.dii,
+                                                                                       sigma, kind_mask, w.stats, w.rowloss,
+                                                                                       w.blockpart, w.ticket, out_losses);
     return mf_check_launch("mf_loss_fwd");
 }
 
@@ -1083,6 +1175,7 @@ extern "C" int mf_negative_masks(int64_t B, int64_t N, int P, const int64_t* ite
     if (ws_bytes < mf_negative_masks_ws_bytes(B, N, P)) return mf_set_error(MF_ENOSPC, "mf_negative_masks: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     LossWs w = loss_ws(ws, B, N, 32, P, 1);
+    clear_mask_tables(w, s);
     build_masks(w, item_idx, pos_idx, B, N, P, s);
     mask_export_bool_kernel<<<dim3((unsigned)((B * N + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, out_mask);
     return mf_check_launch("mf_negative_masks");

@@ -60,6 +60,18 @@ struct SelectCommon {
     int32_t* cand_cnt;          // [nchunk * 4 / xw][Xp]
 };
 
+#ifdef MF_PROBE
+// tools/topk_probe.py: wave-summed cycle / event counters of the last launches
+// 0 total cycles, 1 settle cycles, 2 warm-loop cycles, 3 filter+slow-path cycles, 4 accepted keys,
+// 5 slices whose body ran (any lane passed the prefilter), 6 filter calls, 7 slow-path rows, 8 waves
+static __device__ unsigned long long mf_sel_dbg[16];
+#define MF_PROBE_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define MF_PROBE_ADD(i, x) dbg[i] += (x)
+#else
+#define MF_PROBE_T(v)
+#define MF_PROBE_ADD(i, x)
+#endif
+
 template <int T>
 __device__ __forceinline__ void mf_tlist_insert(unsigned (&tl)[T], unsigned rank) {
     tl[T - 1] = rank;
@@ -122,6 +134,10 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
     mf_load_frag<D>(xf, sc.X, x, x < sc.nX);
     typename Policy::Row row = Policy::row_init(pp, x, x < sc.nX);
 
+#ifdef MF_PROBE
+    unsigned long long dbg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    MF_PROBE_T(pt_begin);
     unsigned tl[T];
 #pragma unroll
     for (int i = 0; i < T; ++i) tl[i] = 0u;
@@ -156,6 +172,9 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
         return;
 #endif
         if (Policy::PREFILTER && (acc[e] < thr_f)) return;
+#ifdef MF_PROBE
+        if (lane == (int)__builtin_ctzll(__ballot(1))) dbg[5] += 1;
+#endif
         unsigned hi, lo;
         const bool ok = Policy::key(pp, row, tile, acc[e], e, h, y0 + (unsigned)mf_acc_row(e, h), hi, lo);
         const unsigned fhi = (unsigned)(fl >> 32), flo = (unsigned)fl;
@@ -163,6 +182,7 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
         if (ok && row_ok && hi >= tau_row && above_floor) {
             mf_lds_store_b64(buf + lane * (CAPL + 1) + cnt, lo, hi);     // asm store: must not drain the DMA queue
             ++cnt;
+            MF_PROBE_ADD(4, 1);
             tmaxr = max(tmaxr, hi);
         }
     };
@@ -186,6 +206,7 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
     // over many tiles, nearly tight -- lower bound, at the cost of one branch-free insertion per tile.
     // While the lists fill (the first T tiles of the chunk) every accepted key is inserted instead.
     auto settle = [&](int cnt0, bool warm, const char* aux) {
+        MF_PROBE_T(ps0);
         if (warm) {
             for (int i = cnt0; __any(i < cnt); ++i) {
                 if (i < cnt) {
@@ -197,6 +218,8 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
             mf_tlist_insert<T>(tl, tmaxr);
         }
         tmaxr = 0u;
+        MF_PROBE_T(ps1);
+        MF_PROBE_ADD(2, ps1 - ps0);
         {
             const unsigned own = tl[T - 1];
             const unsigned mine_ = min(own, mf_shfl_xor32u(own));
@@ -214,7 +237,9 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
             }
             tau_row = max(mine_, g);
         }
+        MF_PROBE_T(ps2);
         if (__any(cnt > CAPL - 16)) {
+            MF_PROBE_ADD(6, lane == 0 ? 1 : 0);
             filter_segment();   // drop, in place, what has fallen below the row's current bound
             // rare: a row still too full -> exact selection of its k best keys (wave-local)
             const unsigned long long ovb = __ballot(cnt > CAPL - 16);
@@ -222,6 +247,7 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
             while (rows) {
                 const int r = __builtin_ctz(rows);
                 rows &= rows - 1;
+                MF_PROBE_ADD(7, lane == 0 ? 1 : 0);
                 const int n0 = __shfl(cnt, r, 64), n1 = __shfl(cnt, r + 32, 64);
                 const int m = n0 + n1;                       // <= 2 CAPL <= 160
                 mf_wave_sync();
@@ -254,6 +280,9 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
         {
             const unsigned t = max(tau_row, (unsigned)(fl >> 32));
             thr_f = row_ok ? mf_unorderable(t) : __builtin_inff();
+            MF_PROBE_T(ps3);
+            MF_PROBE_ADD(3, ps3 - ps2);
+            MF_PROBE_ADD(1, ps3 - ps0);
 #ifdef MF_ABL_NOPASS
             thr_f = __builtin_inff();
 #endif
@@ -304,6 +333,18 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
     unsigned long long* dst = sc.cand + (set * sc.Xp + x) * (2 * CAPL) + (h ? n_other : 0);
     for (int t = 0; t < cnt; ++t) dst[t] = MF_BUF(lane, t);
     if (h == 0) sc.cand_cnt[set * sc.Xp + x] = cnt + n_other;
+#ifdef MF_PROBE
+    {
+        MF_PROBE_T(pt_end);
+        dbg[0] = pt_end - pt_begin;
+        dbg[8] = 1;
+        for (int i = 0; i < 9; ++i) {
+            unsigned long long v = (i == 4 || i == 5) ? dbg[i] : (lane == 0 ? dbg[i] : 0ull);
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) atomicAdd(&mf_sel_dbg[i], v);
+        }
+    }
+#endif
 #undef MF_BUF
 }
 

@@ -164,6 +164,14 @@ extern "C" long long mf_probe_topk_cand() {       // tools/topk_probe.py: candid
     for (int32_t c : h) t += c;
     return t;
 }
+extern "C" void mf_probe_sel_counters(unsigned long long* out16, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(mf_sel_dbg), 16 * 8);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(mf_sel_dbg), z, 16 * 8);
+    }
+}
 #endif
 
 extern "C" int mf_topk(const float* q, int64_t Q, const float* items, int64_t N, int d, int k,

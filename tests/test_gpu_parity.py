@@ -324,3 +324,30 @@ def test_public_mask_and_mining_helpers_match_reference(mf, path):
     top = torch.argsort(key, dim=1, descending=True, stable=True)[:, :4]
     want_h = torch.zeros_like(base).scatter_(1, top, True) & base
     assert torch.equal(hard, want_h)
+
+
+def test_sparse_update_generic_sort_path_and_out_of_range_ids(mf):
+    """A table too tall for the packed (id, position) sort word takes the 64-bit rank sort; ids outside
+    the table are skipped (never written), the rest matches the oracle's coalesced update."""
+    lib = mf._lib.lib()
+    rows, d, n = 5_000_000, 32, 700                      # (rows + 1) << 10 > 2^32
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, rows, (n,), generator=g)
+    idx[100:180] = idx[7]                                # a run longer than two 32-row chunks
+    idx[3], idx[4] = -1, rows + 9                        # out of range: ignored
+    grad = torch.randn(n, d, generator=g)
+    table = torch.zeros(rows, d, device=DEV)
+    valid = (idx >= 0) & (idx < rows)
+    touched = torch.unique(idx[valid])
+    init = torch.randn(touched.numel(), d, generator=g)
+    table[touched.to(DEV)] = init.to(DEV)
+    ws = mf._lib.workspace(lib.mf_update_ws_bytes(n, d), DEV)
+    gi, gg = idx.to(DEV), grad.to(DEV)
+    mf._lib.check(lib.mf_update_sgd(table.data_ptr(), rows, d, gi.data_ptr(), n, gg.data_ptr(), 0, 0.1, 0.0,
+                                    ws.data_ptr(), ws.numel(), None))
+    small = torch.zeros(touched.numel(), d)
+    small.copy_(init)
+    remap = torch.searchsorted(touched, idx[valid])
+    oembed.sgd_update(small, remap, grad[valid], 0.1, 0.0)
+    torch.testing.assert_close(table[touched.to(DEV)].cpu(), small, rtol=2e-5, atol=2e-6)
+    assert int(torch.count_nonzero(table.abs().sum(dim=1))) == touched.numel()   # nothing else was written

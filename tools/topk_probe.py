@@ -37,6 +37,14 @@ line = f"lib={mf._lib.LIB_PATH.name} Q={Q} N={N} d={d} k={k} select_ms={ms:.4f} 
 if hasattr(lib, "mf_probe_topk_cand"):
     lib.mf_probe_topk_cand.restype = ctypes.c_longlong
     line += f" candidates_per_query={lib.mf_probe_topk_cand() / Q:.1f}"
+if hasattr(lib, "mf_probe_sel_counters"):
+    buf = (ctypes.c_ulonglong * 16)()
+    lib.mf_probe_sel_counters(buf, 1)
+    index.search(q, k)
+    lib.mf_probe_sel_counters(buf, 1)
+    w = max(buf[8], 1)
+    names = ["cycles", "settle", "warm", "filter_slow", "accepted", "body_slices", "filter_calls", "slow_rows"]
+    line += " per_wave{" + ", ".join(f"{nm}={buf[j] / w:.0f}" for j, nm in enumerate(names)) + f"}} waves={buf[8]}"
 ref = torch.topk(q @ items.T, k, dim=1)
 line += f" idx_equal_torch={bool((ref.indices == i).float().mean() > 0.999)}"
 print(line)
