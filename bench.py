@@ -38,6 +38,8 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 NUM_USERS, NUM_ITEMS, DIM = 162_541, 62_423, 128       # ML-25M shape
+TIME_EVERY = 4      # HIP-event pairs around every 4th launch of each timed kernel, inside the timed region
+                    # (an event pair costs ~6 us of stream time around the kernel it brackets)
 PEAK_F32_MFMA_TFLOPS = 157.3                            # MI355X_MICROARCH.md, fp32 matrix
 PEAK_HBM_GBS = 8000.0
 TOP_K, POS_PAD = 20, 64
@@ -209,7 +211,7 @@ def main() -> None:
     for i in range(W):
         trainer.step(batches[i % n_batches])
     lib.mf_timing_reset()
-    lib.mf_timing_enable(1)
+    lib.mf_timing_enable(TIME_EVERY)
     dt_train = timed(lambda i: trainer.step(batches[(W + i) % n_batches]), K, dist_on)
     lib.mf_timing_enable(0)
     pairs_per_s = world * B * K / dt_train
@@ -249,7 +251,7 @@ def main() -> None:
     for i in range(W):
         run_topk(i)
     lib.mf_timing_reset()
-    lib.mf_timing_enable(1)
+    lib.mf_timing_enable(TIME_EVERY)
     dt_topk = timed(run_topk, K, dist_on)
     lib.mf_timing_enable(0)
     qps = world * Q * K / dt_topk

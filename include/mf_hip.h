@@ -57,9 +57,10 @@ int mf_version(void);
 
 /* Optional HIP-event timing of the dominant kernels ("loss_fwd_dense",
  * "loss_bwd_du", "loss_bwd_dv", "mining_select", "topk_select", "gather_rows",
- * "update_rows"), recorded on the launch stream.  mf_timing_get blocks until the
- * recorded spans finished and returns their count (total_ms = summed duration). */
-void mf_timing_enable(int on);
+ * "update_rows"), recorded on the launch stream.  mf_timing_enable(k): 0 = off, k >= 1 = time every
+ * k-th launch of each name (an event pair costs a few us of stream time).  mf_timing_get blocks until
+ * the recorded spans finished and returns their count (total_ms = summed duration). */
+void mf_timing_enable(int every);
 void mf_timing_reset(void);
 int64_t mf_timing_get(const char* name, double* total_ms);
 
@@ -99,7 +100,7 @@ int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64_t* sorted_
  *   (0-padded, nullable with P = 0), logq[N] (nullable; our logQ correction
  *   L_ij -= logq[j]).
  * kind_mask selects which losses to evaluate in the one pass (bit k = kind k);
- * out_losses[7] receives them (others are left untouched).  The workspace keeps
+ * out_losses[7] receives them (the entries of the other kinds are set to 0).  The workspace keeps
  * the per-row statistics / mined negatives for mf_loss_bwd and must stay intact
  * between the two calls.  out_mask_bits (nullable, B x ceil(N/32) uint32, bit c of
  * word [i][w] = column 32w+c) receives the post-mining negative mask

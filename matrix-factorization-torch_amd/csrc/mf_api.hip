@@ -26,7 +26,8 @@ extern "C" int mf_version(void) { return 100; }
 // ---------------------------------------------------------------- kernel timing --
 // Optional HIP-event timing of the dominant kernels, recorded on the stream the
 // kernel is launched on (bench.py's roofline leg).  Off by default: no event is
-// created or recorded unless mf_timing_enable(1) was called.
+// created or recorded unless mf_timing_enable(k >= 1) was called (k: time every k-th launch of each
+// name -- an event pair costs a few microseconds of stream time around the kernel it brackets).
 #include <map>
 #include <string>
 #include <vector>
@@ -34,29 +35,41 @@ extern "C" int mf_version(void) { return 100; }
 struct TimedSpan {
     hipEvent_t start, stop;
 };
-static bool g_timing = false;
-static std::map<std::string, std::vector<TimedSpan>> g_spans;
+struct TimedName {
+    std::vector<TimedSpan> spans;
+    long long calls = 0;
+    bool open = false;             // the current launch is being timed
+};
+static int g_every = 0;            // 0: off; k: every k-th launch of each name is timed
+static std::map<std::string, TimedName> g_spans;
 
-bool mf_timing_on() { return g_timing; }
+bool mf_timing_on() { return g_every > 0; }
 
 void mf_timing_begin(const char* name, hipStream_t s) {
+    TimedName& tn = g_spans[name];
+    tn.open = (tn.calls++ % g_every) == 0;
+    if (!tn.open) return;
     TimedSpan sp;
-    if (hipEventCreate(&sp.start) != hipSuccess || hipEventCreate(&sp.stop) != hipSuccess) return;
+    if (hipEventCreate(&sp.start) != hipSuccess || hipEventCreate(&sp.stop) != hipSuccess) {
+        tn.open = false;
+        return;
+    }
     (void)hipEventRecord(sp.start, s);
-    g_spans[name].push_back(sp);
+    tn.spans.push_back(sp);
 }
 
 void mf_timing_end(const char* name, hipStream_t s) {
     auto it = g_spans.find(name);
-    if (it == g_spans.end() || it->second.empty()) return;
-    (void)hipEventRecord(it->second.back().stop, s);
+    if (it == g_spans.end() || !it->second.open) return;
+    (void)hipEventRecord(it->second.spans.back().stop, s);
+    it->second.open = false;
 }
 
-extern "C" void mf_timing_enable(int on) { g_timing = on != 0; }
+extern "C" void mf_timing_enable(int every) { g_every = every > 0 ? every : 0; }
 
 extern "C" void mf_timing_reset(void) {
     for (auto& kv : g_spans)
-        for (auto& sp : kv.second) {
+        for (auto& sp : kv.second.spans) {
             (void)hipEventDestroy(sp.start);
             (void)hipEventDestroy(sp.stop);
         }
@@ -69,7 +82,7 @@ extern "C" int64_t mf_timing_get(const char* name, double* total_ms) {
     int64_t n = 0;
     auto it = g_spans.find(name);
     if (it != g_spans.end())
-        for (auto& sp : it->second) {
+        for (auto& sp : it->second.spans) {
             float ms = 0.f;
             if (hipEventSynchronize(sp.stop) == hipSuccess && hipEventElapsedTime(&ms, sp.start, sp.stop) == hipSuccess) {
                 tot += ms;

@@ -49,7 +49,7 @@ struct LossWs {
     long long* gtab;
     int M;
     int32_t *colslot, *gfirst, *colfirst;
-    uint32_t *ubits, *dupmask;
+    uint32_t* ubits;
     uint32_t* maskW;
     float *part, *stats, *rowloss, *rowc, *dpart, *stash, *gstash, *blockpart;
     unsigned* ticket;
@@ -77,8 +77,13 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.BT = (int)(w.Bp / 32); w.NT = (int)(w.Np / 32);
     w.mined = mining_on(num_negatives, N);
     split_geometry(w.BT / 4, w.NT, &w.nsplit_f, &w.tps_f, 512);
+#ifdef MF_ABL_BWD2
+    split_geometry(w.BT / 4, w.NT, &w.nsplit_u, &w.tps_u, 512);
+    split_geometry(w.NT / 4, w.BT, &w.nsplit_v, &w.tps_v, 256);
+#else
     split_geometry(w.BT / 4, w.NT, &w.nsplit_u, &w.tps_u, 256);
     split_geometry(w.NT / 4, w.BT, &w.nsplit_v, &w.tps_v, 256);
+#endif
     const int k = num_negatives;
     w.plan = mf_select_plan(B, N, d, k);
     w.T = w.plan.T; w.CAP = w.plan.CAP; w.nchunk = w.plan.nsets; w.tpc = w.plan.tpc;
@@ -93,8 +98,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.gfirst = a.take<int32_t>((size_t)w.M);
     w.colslot = a.take<int32_t>((size_t)w.Np);
     w.colfirst = a.take<int32_t>((size_t)w.Np);
-    w.dupmask = a.take<uint32_t>((size_t)w.NT);
-    w.ubits = a.take<uint32_t>((size_t)w.NT * w.Bp);
+    w.ubits = a.take<uint32_t>((size_t)w.Np * (w.Bp / 32));      // ubitsT [column][user / 32]
     w.maskW = a.take<uint32_t>((size_t)w.NT * w.Bp);
     w.part = a.take<float>((size_t)w.nsplit_f * NSTAT * w.Bp);
     w.stats = a.take<float>((size_t)NSTAT * w.Bp);
@@ -104,11 +108,11 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.ticket = a.take<unsigned>(4);
     if (w.mined) {
         w.cand = a.take<unsigned long long>((size_t)w.nchunk * w.Bp * w.CAP);
-        w.cand_cnt = a.take<int32_t>((size_t)w.nchunk * w.Bp);
         w.sel = a.take<int32_t>((size_t)w.Bp * KSEL_MAX);
         w.sel_cnt = a.take<int32_t>(w.Bp);
         w.sel_L = a.take<float>((size_t)w.Bp * KSEL_MAX);
         w.gtau = a.take<unsigned>((size_t)w.Bp);
+        w.cand_cnt = a.take<int32_t>((size_t)w.Bp);      // right behind gtau: one memset clears both
         w.dpart = nullptr;
     } else {
         size_t rows = (size_t)w.nsplit_u * w.Bp;
@@ -196,11 +200,12 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
 //   1. the batch's item ids go into ONE open-addressing table (M >= 2N slots); every column
 //      learns the FIRST column that carries the same item id (duplicates are common: Zipf);
 //   2. each user's positives (plus its own item: the accidental-hit term, losses.py:103) are
-//      looked up there and set ONE bit of that user's row, at the item's first column:
-//      ubits[first / 32][user] -- positives absent from the batch cost nothing more;
-//   3. the mask word of (user, column tile t) is then ubits[t][user] itself (all the tile's
-//      first-occurrence columns in one coalesced load) plus one probe per DUPLICATE column of the
-//      tile (dupmask[t]); no atomics, no B x N x P temp, ~1/3 of the loads of a per-column sweep.
+//      looked up there and set ONE bit, in the bit-vector over users of that first column:
+//      ubitsT[first][user / 32] -- positives absent from the batch cost nothing more;
+//   3. the 32 columns of a tile then each fetch the user bit-vector of THEIR first column (a
+//      duplicate column simply reads another row: no per-duplicate probing) and a 32 x 32 bit
+//      transpose across the half-wave turns (lane = column, bit = user) into the mask words
+//      (lane = user, bit = column).  No atomics in the sweep, no B x N x P temp.
 static constexpr long long HT_EMPTY = (long long)0x8080808080808080ull;   // memset(0x80)
 
 __device__ __forceinline__ unsigned ht_hash(long long id, unsigned slots_mask) {
@@ -215,94 +220,120 @@ __global__ __launch_bounds__(256) void gt_insert_kernel(const int64_t* __restric
     const long long key = item_idx[j];
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(gtab);
     unsigned hpos = ht_hash(key, M - 1);
+    // a Zipf batch repeats its popular items hundreds of times: look before the atomic (a stale read
+    // only costs the atomic it would have saved; slots never change once taken, gfirst only decreases)
+    const volatile unsigned long long* vtab = tab;
     for (int probe = 0; probe < M; ++probe) {
-        const unsigned long long old = atomicCAS(&tab[hpos], (unsigned long long)HT_EMPTY, (unsigned long long)key);
+        unsigned long long old = vtab[hpos];
+        if (old == (unsigned long long)HT_EMPTY)
+            old = atomicCAS(&tab[hpos], (unsigned long long)HT_EMPTY, (unsigned long long)key);
         if (old == (unsigned long long)HT_EMPTY || old == (unsigned long long)key) break;
         hpos = (hpos + 1) & (M - 1);
     }
-    atomicMin(&gfirst[hpos], (int32_t)j);       // gfirst was memset to 0x7f7f7f7f
+    if (*(const volatile int32_t*)&gfirst[hpos] > (int32_t)j) atomicMin(&gfirst[hpos], (int32_t)j);   // cleared to 0x7f7f7f7f
     colslot[j] = (int32_t)hpos;
 }
 
-// colfirst[j] = first column with column j's item; dupmask[t] bit c = column 32 t + c is not that first column
+// colfirst[j] = first column with column j's item (-1: padding column)
 __device__ __forceinline__ void colfirst_body(int64_t j, const int32_t* __restrict__ colslot,
                                               const int32_t* __restrict__ gfirst, int64_t N, int64_t Np,
-                                              int32_t* __restrict__ colfirst, uint32_t* __restrict__ dupmask) {
+                                              int32_t* __restrict__ colfirst) {
     int32_t f = -1;
     if (j < N) f = gfirst[colslot[j]];
     if (j < Np) colfirst[j] = f;
-    const unsigned long long bal = __ballot(j < N && f != (int32_t)j);
-    const int lane = mf_lane();
-    if (j < Np && lane == 0) dupmask[j >> 5] = (uint32_t)bal;
-    if (j < Np && lane == 32) dupmask[j >> 5] = (uint32_t)(bal >> 32);
 }
 
-__device__ __forceinline__ void ubits_body(int64_t t, const int64_t* __restrict__ item_idx,
-                                           const int64_t* __restrict__ pos_idx, int64_t B, int P, int M,
-                                           const long long* __restrict__ gtab, const int32_t* __restrict__ gfirst,
-                                           int64_t Bp, uint32_t* __restrict__ ubits) {
-    const int64_t i = t / (P + 1);
-    const int p = (int)(t % (P + 1));
-    if (i >= B) return;
-    const long long key = (p == P) ? item_idx[i] : pos_idx[i * P + p];
+// gtab lookup: first column of `key` in the batch, or -1
+__device__ __forceinline__ int32_t ht_find(long long key, int M, const long long* __restrict__ gtab,
+                                           const int32_t* __restrict__ gfirst) {
     unsigned hpos = ht_hash(key, M - 1);
     for (int probe = 0; probe < M; ++probe) {
         const long long sv = gtab[hpos];
-        if (sv == key) {
-            const int32_t f = gfirst[hpos];
-            atomicOr(&ubits[(int64_t)(f >> 5) * Bp + i], 1u << (f & 31));
-            return;
-        }
-        if (sv == HT_EMPTY) return;           // this positive is not in the batch
+        if (sv == key) return gfirst[hpos];
+        if (sv == HT_EMPTY) return -1;        // this positive is not in the batch
         hpos = (hpos + 1) & (M - 1);
     }
+    return -1;
 }
 
-// both only need the finished hash table: blocks [0, nb_col) do the columns, the rest the users' positives
-__global__ __launch_bounds__(256) void hits_kernel(const int64_t* __restrict__ item_idx, const int64_t* __restrict__ pos_idx,
+// One launch for both consumers of the finished hash table.  Blocks [0, nb_col): colfirst.  The rest:
+// one block per group of 32 users -- it OWNS word `group` of every column's user bit-vector, so its
+// hits are combined in an LDS table keyed by the first column (LDS atomics; a popular item is the
+// positive of thousands of users) and written out with plain stores: no global atomics.  `cap` = LDS
+// table entries (power of two >= 2 * 32 * (P + 1)), or 0: fall back to global atomicOr.
+__global__ __launch_bounds__(1024) void hits_kernel(const int64_t* __restrict__ item_idx, const int64_t* __restrict__ pos_idx,
                                                    int64_t B, int64_t N, int64_t Bp, int64_t Np, int P, int M, int nb_col,
-                                                   const long long* __restrict__ gtab, const int32_t* __restrict__ gfirst,
-                                                   const int32_t* __restrict__ colslot, int32_t* __restrict__ colfirst,
-                                                   uint32_t* __restrict__ dupmask, uint32_t* __restrict__ ubits) {
-    if ((int)blockIdx.x < nb_col)
-        colfirst_body((int64_t)blockIdx.x * 256 + threadIdx.x, colslot, gfirst, N, Np, colfirst, dupmask);
-    else
-        ubits_body((int64_t)(blockIdx.x - nb_col) * 256 + threadIdx.x, item_idx, pos_idx, B, P, M, gtab, gfirst, Bp, ubits);
+                                                   int cap, const long long* __restrict__ gtab,
+                                                   const int32_t* __restrict__ gfirst, const int32_t* __restrict__ colslot,
+                                                   int32_t* __restrict__ colfirst, uint32_t* __restrict__ ubitsT) {
+    extern __shared__ __attribute__((aligned(16))) int32_t hl[];           // [cap] keys, [cap] bit words
+    if ((int)blockIdx.x < nb_col) {
+        colfirst_body((int64_t)blockIdx.x * 1024 + threadIdx.x, colslot, gfirst, N, Np, colfirst);
+        return;
+    }
+    const int grp = blockIdx.x - nb_col;
+    const int64_t wpr = Bp >> 5;                                           // words per column row
+    int32_t* keys = hl;
+    uint32_t* bits = reinterpret_cast<uint32_t*>(hl + cap);
+    for (int e = threadIdx.x; e < cap; e += 1024) { keys[e] = -1; bits[e] = 0u; }
+    __syncthreads();
+    const int per_user = P + 1;
+    for (int t = threadIdx.x; t < 32 * per_user; t += 1024) {
+        const int ul = t / per_user, p = t % per_user;
+        const int64_t i = (int64_t)grp * 32 + ul;
+        if (i >= B) continue;
+        const long long key = (p == P) ? item_idx[i] : pos_idx[i * P + p];
+        const int32_t f = ht_find(key, M, gtab, gfirst);
+        if (f < 0) continue;
+        if (cap == 0) {
+            atomicOr(&ubitsT[(int64_t)f * wpr + grp], 1u << ul);
+            continue;
+        }
+        unsigned h = ((unsigned)f * 2654435761u >> 7) & (cap - 1);
+        for (;;) {
+            const int32_t old = atomicCAS(&keys[h], -1, f);
+            if (old == -1 || old == f) { atomicOr(&bits[h], 1u << ul); break; }
+            h = (h + 1) & (cap - 1);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cap; e += 1024)
+        if (keys[e] >= 0) ubitsT[(int64_t)keys[e] * wpr + grp] = bits[e];
 }
 
-// mask word of (user, column tile): the tile's first-occurrence columns at once, plus one probe per
-// DUPLICATE column at its item's first column.  One workgroup owns 32 users and keeps their whole
-// bit-row slab [NT][32 users] in LDS (LDS = true), so the probes -- ~10 per word under a Zipf batch --
-// are LDS reads; 16 waves per workgroup hide their latency.  Larger N: probes go to L2 (LDS = false).
-template <bool LDS>
-__global__ __launch_bounds__(1024) void mask_sweep_kernel(const int32_t* __restrict__ colfirst,
-                                                          const uint32_t* __restrict__ dupmask,
-                                                          const uint32_t* __restrict__ ubits, int64_t B, int64_t N,
-                                                          int64_t Bp, int NT, uint32_t* __restrict__ maskW) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t slab[];      // [NT][32]
+// 32 x 32 bit transpose across the 32 lanes of a half-wave: lane i holds row i; five block-swap steps
+template <int J, uint32_t M0>
+__device__ __forceinline__ uint32_t bit_transpose_step(uint32_t w, int lane) {
+    const uint32_t p = (uint32_t)__shfl_xor((int)w, J, 64);
+    return (lane & J) ? ((w & ~M0) | ((p & ~M0) >> J)) : ((w & M0) | ((p & M0) << J));
+}
+__device__ __forceinline__ uint32_t bit_transpose32(uint32_t w, int lane) {
+    w = bit_transpose_step<16, 0x0000FFFFu>(w, lane);
+    w = bit_transpose_step<8, 0x00FF00FFu>(w, lane);
+    w = bit_transpose_step<4, 0x0F0F0F0Fu>(w, lane);
+    w = bit_transpose_step<2, 0x33333333u>(w, lane);
+    return bit_transpose_step<1, 0x55555555u>(w, lane);
+}
+
+// one half-wave per (column tile, group of 128 users): lane = column fetches 16 bytes of its first
+// column's user bit-vector, four transposes give the mask words of 4 x 32 users
+__global__ __launch_bounds__(256) void mask_sweep_kernel(const int32_t* __restrict__ colfirst,
+                                                         const uint32_t* __restrict__ ubitsT, int64_t B, int64_t Bp,
+                                                         int NT, uint32_t* __restrict__ maskW) {
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
-    const int64_t i = (int64_t)blockIdx.x * 32 + c;
-    const bool user_ok = i < B;
-    const int nhw = (int)(blockDim.x >> 5);
-    const int hw = (int)(threadIdx.x >> 6) * 2 + h;                       // half-wave id inside the block
-    if (LDS) {
-        for (int tj = hw; tj < NT; tj += nhw) slab[tj * 32 + c] = ubits[(int64_t)tj * Bp + i];
-        __syncthreads();
-    }
-    for (int tj = blockIdx.y * nhw + hw; tj < NT; tj += nhw * gridDim.y) {
-        uint32_t word = LDS ? slab[tj * 32 + c] : ubits[(int64_t)tj * Bp + i];
-        uint32_t dm = dupmask[tj];
-        const int32_t cf = colfirst[tj * 32 + c];                          // lane c: first column of column c's item
-        while (dm) {                                                       // duplicate columns of this tile
-            const int c2 = __builtin_ctz(dm);
-            dm &= dm - 1;
-            const int f = __shfl(cf, c2 + 32 * h, 64);
-            const uint32_t src = LDS ? slab[(f >> 5) * 32 + c] : ubits[(int64_t)(f >> 5) * Bp + i];
-            word |= ((src >> (f & 31)) & 1u) << c2;
-        }
-        const int64_t left = N - (int64_t)tj * 32;          // padding columns / padding users: never a negative
-        if (left < 32) word |= ~0u << (left > 0 ? (int)left : 0);
-        maskW[(int64_t)tj * Bp + i] = user_ok ? word : ~0u;
+    const int ngrp = (int)(Bp >> 7);
+    const int64_t unit = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + h;
+    if (unit >= (int64_t)NT * ngrp) return;
+    const int tj = (int)(unit / ngrp), g = (int)(unit % ngrp);
+    const int32_t f = colfirst[tj * 32 + c];                 // -1: padding column, never a negative
+    uint4 w = {~0u, ~0u, ~0u, ~0u};
+    if (f >= 0) w = *reinterpret_cast<const uint4*>(ubitsT + (int64_t)f * (Bp >> 5) + 4 * g);
+    const uint32_t in[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t word = bit_transpose32(in[q], c);
+        const int64_t i = ((int64_t)4 * g + q) * 32 + c;
+        maskW[(int64_t)tj * Bp + i] = i < B ? word : ~0u;    // padding users: no negatives at all
     }
 }
 
@@ -532,11 +563,20 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
     if (i < Bp) {
         if (nsplit > 0) {
             for (int s = 0; s < NSTAT; ++s) acc[s] = part[(int64_t)s * Bp + i];
-            for (int sp = 1; sp < nsplit; ++sp) {
-                const float* q = part + (int64_t)sp * NSTAT * Bp + i;
-                lse_merge(acc[ST_MX], acc[ST_SE], q[ST_MX * Bp], q[ST_SE * Bp]);
-                acc[ST_CNT] += q[ST_CNT * Bp]; acc[ST_A] += q[ST_A * Bp]; acc[ST_H] += q[ST_H * Bp];
-                acc[ST_HC] += q[ST_HC * Bp]; acc[ST_LG] += q[ST_LG * Bp]; acc[ST_LS] += q[ST_LS * Bp];
+            for (int sp0 = 1; sp0 < nsplit; sp0 += 4) {             // four splits' loads in flight, merged in order
+                float q[4][NSTAT];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int s = 0; s < NSTAT; ++s)
+                        q[j][s] = sp0 + j < nsplit ? part[((int64_t)(sp0 + j) * NSTAT + s) * Bp + i] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (sp0 + j >= nsplit) break;
+                    lse_merge(acc[ST_MX], acc[ST_SE], q[j][ST_MX], q[j][ST_SE]);
+                    acc[ST_CNT] += q[j][ST_CNT]; acc[ST_A] += q[j][ST_A]; acc[ST_H] += q[j][ST_H];
+                    acc[ST_HC] += q[j][ST_HC]; acc[ST_LG] += q[j][ST_LG]; acc[ST_LS] += q[j][ST_LS];
+                }
             }
             for (int s = 0; s < NSTAT; ++s) stats[(int64_t)s * Bp + i] = acc[s];
         } else {
@@ -577,12 +617,18 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
     __syncthreads();
     if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     __syncthreads();
-    if (last && threadIdx.x < MF_NUM_KINDS && ((kind_mask >> threadIdx.x) & 1)) {
+    if (last) {
+        // wave k (two passes for 7 kinds on 4 waves) adds the block sums of loss kind k: lane-strided
+        // partial sums, then a fixed xor tree -- the same order on every run
         __threadfence();
-        float tot = 0.f;
-        const volatile float* bp = blockpart + (int64_t)threadIdx.x * gridDim.x;
-        for (unsigned b = 0; b < gridDim.x; ++b) tot += bp[b];
-        out[threadIdx.x] = tot;
+        const int lane = mf_lane();
+        for (int k = (int)(threadIdx.x >> 6); k < MF_NUM_KINDS; k += 4) {
+            float tot = 0.f;
+            const volatile float* bp = blockpart + (int64_t)k * gridDim.x;
+            for (unsigned b = lane; b < gridDim.x; b += 64) tot += bp[b];
+            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+            if (lane == 0) out[k] = ((kind_mask >> k) & 1) ? tot : 0.f;   // every entry is written
+        }
     }
 }
 
@@ -653,13 +699,9 @@ __global__ __launch_bounds__(64) void mined_merge_kernel(const unsigned long lon
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
     const int64_t i = blockIdx.x;
     const int lane = mf_lane();
-    int total = 0;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int n = cand_cnt[(int64_t)ch * Bp + i];
-        const unsigned long long* src = cand + ((int64_t)ch * Bp + i) * CAP;
-        for (int t = lane; t < n; t += 64) s_keys[total + t] = src[t];
-        total += n;
-    }
+    const int total = cand_cnt[i];
+    const unsigned long long* src = cand + i * (int64_t)nchunk * CAP;
+    for (int t = lane; t < total; t += 64) s_keys[t] = src[t];
     __syncthreads();
     int32_t* out = sel + i * KSEL_MAX;
     int found = 0;
@@ -788,7 +830,11 @@ struct BwdLds {
     static constexpr int LT = G::TILEB;                  // 4 x 4 KiB stash blocks (one per wave)
     static constexpr int SLOT = G::TILEB + 4 * 4096;
     static constexpr int EXTRA = XU ? 0 : 4 * 33 * 32 * 4;
+#ifdef MF_ABL_BWD2
+    static constexpr int NSLOT = 2;
+#else
     static constexpr int NSLOT = (3 * SLOT + EXTRA <= 160 * 1024) ? 3 : 2;   // d = 256: 2-deep ring, 2 barriers
+#endif
     static constexpr int TR = NSLOT * SLOT;              // dV: per-wave 32 x 33 transpose scratch
     static constexpr int BYTES = TR + EXTRA;
     static constexpr int NDMA = G::PPW + 4;              // DMA instructions per wave per stage
@@ -980,22 +1026,15 @@ static void clear_mask_tables(const LossWs& w, hipStream_t s) {     // mf_loss_f
 static void build_masks(const LossWs& w, const int64_t* item_idx, const int64_t* pos_idx, int64_t B, int64_t N, int P,
                         hipStream_t s) {
     gt_insert_kernel<<<dim3((unsigned)((N + 255) / 256)), 256, 0, s>>>(item_idx, N, w.M, w.gtab, w.gfirst, w.colslot);
-    const int nb_col = (int)((w.Np + 255) / 256);
-    const int nb_u = (int)((B * (P + 1) + 255) / 256);
-    hits_kernel<<<dim3((unsigned)(nb_col + nb_u)), 256, 0, s>>>(item_idx, pos_idx, B, N, w.Bp, w.Np, P, w.M, nb_col, w.gtab,
-                                                                  w.gfirst, w.colslot, w.colfirst, w.dupmask, w.ubits);
-    int gy = 256 / w.BT;                                     // enough workgroups when B is small
-    if (gy > (w.NT + 31) / 32) gy = (w.NT + 31) / 32;
-    if (gy < 1) gy = 1;
-    const size_t slab = (size_t)w.NT * 128;
-    if (slab <= 128 * 1024) {
-        auto fn = mask_sweep_kernel<true>;
-        if (slab > 64 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slab);
-        fn<<<dim3((unsigned)w.BT, (unsigned)gy), 1024, slab, s>>>(w.colfirst, w.dupmask, w.ubits, B, N, w.Bp, w.NT, w.maskW);
-    } else {
-        gy = (w.NT + 31) / 32 < 16 ? (w.NT + 31) / 32 : 16;
-        mask_sweep_kernel<false><<<dim3((unsigned)w.BT, (unsigned)gy), 1024, 0, s>>>(w.colfirst, w.dupmask, w.ubits, B, N, w.Bp, w.NT, w.maskW);
-    }
+    const int nb_col = (int)((w.Np + 1023) / 1024);
+    const int nb_u = (int)((B + 31) / 32);
+    int cap = 64;
+    while (cap < 2 * 32 * (P + 1)) cap *= 2;
+    if (cap > 8192) cap = 0;                                 // very long positive lists: global atomics
+    hits_kernel<<<dim3((unsigned)(nb_col + nb_u)), 1024, (size_t)cap * 8, s>>>(item_idx, pos_idx, B, N, w.Bp, w.Np, P, w.M, nb_col, cap,
+                                                                              w.gtab, w.gfirst, w.colslot, w.colfirst, w.ubits);
+    const int64_t units = (int64_t)w.NT * (w.Bp >> 7);
+    mask_sweep_kernel<<<dim3((unsigned)((units + 7) / 8)), 256, 0, s>>>(w.colfirst, w.ubits, B, w.Bp, w.NT, w.maskW);
 }
 
 template <int D, bool XU>
@@ -1093,8 +1132,8 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
             mask_export_dense_kernel<<<dim3((unsigned)((B * ((N + 31) / 32) + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, (int)((N + 31) / 32), out_mask_bits);
     } else if (scores_needed) {
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
-        SelectCommon sc{u, B, v, N, (int)((N + 31) / 32), w.tpc, w.Bp, num_negatives, w.plan.xw, w.plan.CAPL, w.gtau, w.cand, w.cand_cnt};
-        (void)hipMemsetAsync(w.gtau, 0, (size_t)w.Bp * 4, s);
+        SelectCommon sc{u, B, v, N, (int)((N + 31) / 32), w.tpc, w.Bp, num_negatives, w.plan.xw, w.plan.CAPL, w.gtau, w.cand, w.cand_cnt, w.nchunk * w.CAP};
+        (void)hipMemsetAsync(w.gtau, 0, (size_t)((char*)(w.cand_cnt + w.Bp) - (char*)w.gtau), s);
         MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, launch_mining_select<D>(w, mp, sc, s)); });
         mined_merge_kernel<<<dim3((unsigned)B), 64, (size_t)w.nchunk * w.CAP * 8, s>>>(w.cand, w.cand_cnt, w.nchunk, w.Bp, w.CAP,
                                                                                       num_negatives, w.sel, w.sel_cnt);

@@ -21,7 +21,7 @@
 //      that row's k best keys exactly and installs a full 64-bit floor.
 //
 // The surviving candidates of every (row, column-chunk) go to HBM (<= 2 CAPL keys
-// each); the exact ordered top-k is produced by a merge kernel (one wave per row).
+// each, appended to the row's list); the exact ordered top-k is produced by a merge kernel (one wave per row).
 #pragma once
 
 #include "mf_common.h"
@@ -56,8 +56,9 @@ struct SelectCommon {
     int capl;            // per-lane LDS segment capacity
     unsigned* gtau;      // [Xp], zeroed by the host: best known lower bound (rank) of every X row's k-th best key,
                          // shared by all chunks of the launch (max-published, so always a valid bound)
-    unsigned long long* cand;   // [nchunk * 4 / xw][Xp][2 capl]
-    int32_t* cand_cnt;          // [nchunk * 4 / xw][Xp]
+    unsigned long long* cand;   // [Xp][rowcap]: every X row's surviving keys of ALL chunks, contiguous
+    int32_t* cand_cnt;          // [Xp], zeroed by the host: fill count of the row's list (atomic cursor)
+    int rowcap;                 // nsets * 2 capl
 };
 
 #ifdef MF_PROBE
@@ -328,11 +329,14 @@ __global__ __launch_bounds__(256) void select_kernel(typename Policy::Params pp,
 
     // final filter with the final bound, then ship every row's survivors
     filter_segment();
+    // a row's two lanes reserve one contiguous piece of the row's list (order of the pieces varies from
+    // run to run; the exact selection that follows does not depend on it: keys are unique)
     const int n_other = __shfl_xor(cnt, 32, 64);
-    const int64_t set = (int64_t)chunk * nsub + sub;
-    unsigned long long* dst = sc.cand + (set * sc.Xp + x) * (2 * CAPL) + (h ? n_other : 0);
+    int base = 0;
+    if (h == 0 && cnt + n_other > 0) base = atomicAdd(&sc.cand_cnt[x], cnt + n_other);
+    base = __shfl(base, c, 64);
+    unsigned long long* dst = sc.cand + x * (int64_t)sc.rowcap + base + (h ? n_other : 0);
     for (int t = 0; t < cnt; ++t) dst[t] = MF_BUF(lane, t);
-    if (h == 0) sc.cand_cnt[set * sc.Xp + x] = cnt + n_other;
 #ifdef MF_PROBE
     {
         MF_PROBE_T(pt_end);

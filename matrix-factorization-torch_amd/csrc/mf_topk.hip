@@ -58,7 +58,7 @@ struct TopkWs {
     unsigned long long* cand;
     int32_t* cand_cnt;
     uint32_t* exclW;
-    unsigned* gtau;      // right behind exclW: one memset clears both
+    unsigned* gtau;      // gtau and cand_cnt sit right behind exclW: one memset clears all three
     size_t total;
 };
 
@@ -68,9 +68,9 @@ static TopkWs topk_ws(void* base, int64_t Q, int64_t N, int d, int k) {
     w.NT = (int)((N + 31) / 32);
     MfArena a(base);
     w.cand = a.take<unsigned long long>((size_t)w.plan.nsets * w.plan.Xp * w.plan.CAP);
-    w.cand_cnt = a.take<int32_t>((size_t)w.plan.nsets * w.plan.Xp);
     w.exclW = a.take<uint32_t>((size_t)w.NT * w.plan.Xp);
     w.gtau = a.take<unsigned>((size_t)w.plan.Xp);
+    w.cand_cnt = a.take<int32_t>((size_t)w.plan.Xp);
     w.total = a.used();
     return w;
 }
@@ -89,13 +89,9 @@ __global__ __launch_bounds__(64) void topk_merge_cand_kernel(const unsigned long
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
     const int64_t r = blockIdx.x;
     const int lane = mf_lane();
-    int total = 0;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int n = cand_cnt[(int64_t)ch * Qp + r];
-        const unsigned long long* src = cand + ((int64_t)ch * Qp + r) * CAP;
-        for (int t = lane; t < n; t += 64) s_keys[total + t] = src[t];
-        total += n;
-    }
+    const int total = cand_cnt[r];
+    const unsigned long long* src = cand + r * (int64_t)nchunk * CAP;
+    for (int t = lane; t < total; t += 64) s_keys[t] = src[t];
     __syncthreads();
     mf_wave_select(s_keys, total, k, [&](int t, unsigned long long key) {
         if (key != 0ull) {
@@ -157,7 +153,7 @@ static void launch_topk_select(const TopkWs& w, const RetrievalPolicy::Params& r
 static TopkWs g_probe_ws;
 extern "C" long long mf_probe_topk_cand() {       // tools/topk_probe.py: candidate keys kept by the last mf_topk
     (void)hipDeviceSynchronize();
-    const size_t n = (size_t)g_probe_ws.plan.nsets * g_probe_ws.plan.Xp;
+    const size_t n = (size_t)g_probe_ws.plan.Xp;
     std::vector<int32_t> h(n);
     (void)hipMemcpy(h.data(), g_probe_ws.cand_cnt, n * 4, hipMemcpyDeviceToHost);
     long long t = 0;
@@ -191,10 +187,10 @@ extern "C" int mf_topk(const float* q, int64_t Q, const float* items, int64_t N,
 #ifdef MF_PROBE
     g_probe_ws = w;
 #endif
-    (void)hipMemsetAsync(w.exclW, 0, (size_t)((char*)(w.gtau + w.plan.Xp) - (char*)w.exclW), s);
+    (void)hipMemsetAsync(w.exclW, 0, (size_t)((char*)(w.cand_cnt + w.plan.Xp) - (char*)w.exclW), s);
     if (excl_off) excl_scatter_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.plan.Xp, w.exclW);
     RetrievalPolicy::Params rp{w.exclW, w.plan.Xp, N};
-    SelectCommon sc{q, Q, items, N, w.NT, w.plan.tpc, w.plan.Xp, k, w.plan.xw, w.plan.CAPL, w.gtau, w.cand, w.cand_cnt};
+    SelectCommon sc{q, Q, items, N, w.NT, w.plan.tpc, w.plan.Xp, k, w.plan.xw, w.plan.CAPL, w.gtau, w.cand, w.cand_cnt, w.plan.nsets * w.plan.CAP};
     MF_DISPATCH_D(d, { MF_TIMED("topk_select", s, launch_topk_select<D>(w, rp, sc, s)); });
     topk_merge_cand_kernel<<<dim3((unsigned)Q), 64, (size_t)w.plan.nsets * w.plan.CAP * 8, s>>>(w.cand, w.cand_cnt, w.plan.nsets, w.plan.Xp, w.plan.CAP, k,
                                                                                       idx_base, out_scores, out_idx);

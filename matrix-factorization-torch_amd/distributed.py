@@ -164,8 +164,17 @@ class ShardedTrainer:
         loss, du, dv = self.ops.loss_and_grads(self.kind, u, v, b["target"], b["item"], b["pos"], logq,
                                                self.num_negatives, 1.0, 1.0)
         dv_owned = ex.push(dv)
-        self.ops.update(self.optimizer, self.item_table, self.state["item"], ex.local_ids, dv_owned, True, self.steps, self.lr)
-        self.ops.update(self.optimizer, self.user_table, self.state["user"], user_local, du, True, self.steps, self.lr)
+        jobs = [lambda: self.ops.update(self.optimizer, self.item_table, self.state["item"], ex.local_ids, dv_owned, True,
+                                        self.steps, self.lr),
+                lambda: self.ops.update(self.optimizer, self.user_table, self.state["user"], user_local, du, True,
+                                        self.steps, self.lr)]
+        if self.item_table.is_cuda:
+            from .optim import run_table_jobs
+
+            run_table_jobs(jobs)                      # the two tables update side by side (two streams)
+        else:
+            for job in jobs:
+                job()
         return loss
 
 

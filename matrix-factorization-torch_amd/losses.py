@@ -75,13 +75,15 @@ class _LossFunction(torch.autograd.Function):
         lib = _lib.lib()
         nbytes = lib.mf_loss_ws_bytes(b, n, dp, p, num_negatives)
         ws = _lib.workspace(nbytes, u.device)
-        out = torch.zeros(len(KINDS), dtype=torch.float32, device=u.device)
+        out = torch.empty(len(KINDS), dtype=torch.float32, device=u.device)      # mf_loss_fwd writes all 7 entries
         _lib.check(lib.mf_loss_fwd(b, n, dp, p, num_negatives, sigma, margin, kind_mask, _lib.ptr(u), _lib.ptr(v),
                                    _lib.ptr(t), _lib.ptr(ii), _lib.ptr(pi), _lib.ptr(lq), _lib.ptr(ws), ws.numel(),
                                    _lib.ptr(out), None, _lib.stream_ptr()))
         ctx.save_for_backward(u, v, t, lq, ws)
         ctx.meta = (b, n, d, dp, p, num_negatives, sigma, margin, bwd_kind, user_embed.dtype, item_embed.dtype)
-        return out
+        # one trained loss (``bwd_kind``): hand out the scalar itself, so that autograd needs no
+        # select-backward (two fills and a copy per step) between ``loss.backward()`` and this node
+        return out if bwd_kind is None else out[bwd_kind]
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -91,8 +93,9 @@ class _LossFunction(torch.autograd.Function):
         nz = torch.nonzero(grad_out).flatten().tolist() if bwd_kind is None else [bwd_kind]
         du = dv = None
         lib = _lib.lib()
+        grad_out = grad_out.to(torch.float32).contiguous()          # no-ops for the usual fp32 gradient
         for kind in nz:
-            g = grad_out[kind : kind + 1].to(torch.float32).contiguous()
+            g = grad_out.reshape(1) if bwd_kind is not None else grad_out[kind : kind + 1]   # views: no kernel
             du_k = torch.empty_like(u)
             dv_k = torch.empty_like(v)
             _lib.check(lib.mf_loss_bwd(b, n, dp, p, k, sigma, margin, kind, _lib.ptr(u), _lib.ptr(v), _lib.ptr(t),
@@ -195,9 +198,8 @@ class EmbeddingLoss(torch.nn.Module, abc.ABC):
         if 0 < k < item_embed.size(0) and k > MAX_MINED_NEGATIVES and self.kind != 0:
             msg = f"semi-hard mining supports num_negatives <= {MAX_MINED_NEGATIVES} (or >= num_items): {k = }"
             raise NotImplementedError(msg)
-        out = _LossFunction.apply(user_embed, item_embed, target, item_idx, pos_idx, logq, 1 << self.kind, self.kind,
-                                  k, float(self.sigma), float(self.margin))
-        return out[self.kind]
+        return _LossFunction.apply(user_embed, item_embed, target, item_idx, pos_idx, logq, 1 << self.kind, self.kind,
+                                   k, float(self.sigma), float(self.margin))
 
 
 class AlignmentLoss(EmbeddingLoss):  # losses.py:249-259

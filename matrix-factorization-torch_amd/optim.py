@@ -30,6 +30,39 @@ def _pending(p: torch.Tensor):
     return ids, g, norm
 
 
+_side_streams: dict = {}
+
+
+def run_table_jobs(jobs) -> None:
+    """Run independent per-table update jobs (callables issuing work on the *current* stream) side by
+    side: the first on the caller's stream, the others on cached side streams, forked from and joined
+    back into the caller's stream with events.  The updates of different tables touch disjoint memory,
+    and each is a chain of small latency-bound kernels, so they overlap almost perfectly."""
+    if not jobs:
+        return
+    if len(jobs) == 1:
+        jobs[0]()
+        return
+    cur = torch.cuda.current_stream()
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    joins = []
+    for k, job in enumerate(jobs[1:]):
+        key = (cur.device, k)
+        side = _side_streams.get(key)
+        if side is None:
+            side = _side_streams[key] = torch.cuda.Stream(device=cur.device)
+        side.wait_event(fork)
+        with torch.cuda.stream(side):
+            job()
+            done = torch.cuda.Event()
+            done.record(side)
+        joins.append(done)
+    jobs[0]()
+    for done in joins:
+        cur.wait_event(done)
+
+
 class _SparseRowOptimizer(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = True) -> None:
         super().zero_grad(set_to_none=set_to_none)
@@ -59,19 +92,27 @@ class SparseSGD(_SparseRowOptimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.lib()
+        jobs, done = [], []
         for group in self.param_groups:
             for p in group["params"]:
                 self._check(p)
                 pend = _pending(p)
                 if pend is None:
                     continue
-                ids, g, norm = pend
-                n, d = ids.numel(), p.shape[1]
-                ws = _lib.workspace(lib.mf_update_ws_bytes(n, d), p.device)
-                _lib.check(lib.mf_update_sgd(p.data_ptr(), p.shape[0], d, ids.data_ptr(), n, g.data_ptr(), int(norm),
-                                             group["lr"], group["weight_decay"], ws.data_ptr(), ws.numel(),
-                                             _lib.stream_ptr()))
-                p._mf_pending.clear()
+
+                def job(p=p, pend=pend, group=group):
+                    ids, g, norm = pend
+                    n, d = ids.numel(), p.shape[1]
+                    ws = _lib.workspace(lib.mf_update_ws_bytes(n, d), p.device)
+                    _lib.check(lib.mf_update_sgd(p.data_ptr(), p.shape[0], d, ids.data_ptr(), n, g.data_ptr(), int(norm),
+                                                 group["lr"], group["weight_decay"], ws.data_ptr(), ws.numel(),
+                                                 _lib.stream_ptr()))
+
+                jobs.append(job)
+                done.append(p)
+        run_table_jobs(jobs)
+        for p in done:
+            p._mf_pending.clear()
         return loss
 
 
@@ -90,6 +131,7 @@ class RowAdam(_SparseRowOptimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.lib()
+        jobs, done = [], []
         for group in self.param_groups:
             for p in group["params"]:
                 self._check(p)
@@ -102,13 +144,20 @@ class RowAdam(_SparseRowOptimizer):
                     state["exp_avg"] = torch.zeros_like(p)
                     state["exp_avg_sq"] = torch.zeros_like(p)
                 state["step"] += 1
-                ids, g, norm = pend
-                n, d = ids.numel(), p.shape[1]
-                ws = _lib.workspace(lib.mf_update_ws_bytes(n, d), p.device)
-                b1, b2 = group["betas"]
-                _lib.check(lib.mf_update_adam(p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
-                                              p.shape[0], d, ids.data_ptr(), n, g.data_ptr(), int(norm), state["step"],
-                                              group["lr"], b1, b2, group["eps"], group["weight_decay"], ws.data_ptr(),
-                                              ws.numel(), _lib.stream_ptr()))
-                p._mf_pending.clear()
+
+                def job(p=p, pend=pend, group=group, state=state):
+                    ids, g, norm = pend
+                    n, d = ids.numel(), p.shape[1]
+                    ws = _lib.workspace(lib.mf_update_ws_bytes(n, d), p.device)
+                    b1, b2 = group["betas"]
+                    _lib.check(lib.mf_update_adam(p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                                                  p.shape[0], d, ids.data_ptr(), n, g.data_ptr(), int(norm), state["step"],
+                                                  group["lr"], b1, b2, group["eps"], group["weight_decay"], ws.data_ptr(),
+                                                  ws.numel(), _lib.stream_ptr()))
+
+                jobs.append(job)
+                done.append(p)
+        run_table_jobs(jobs)
+        for p in done:
+            p._mf_pending.clear()
         return loss

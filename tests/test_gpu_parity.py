@@ -351,3 +351,19 @@ def test_sparse_update_generic_sort_path_and_out_of_range_ids(mf):
     oembed.sgd_update(small, remap, grad[valid], 0.1, 0.0)
     torch.testing.assert_close(table[touched.to(DEV)].cpu(), small, rtol=2e-5, atol=2e-6)
     assert int(torch.count_nonzero(table.abs().sum(dim=1))) == touched.numel()   # nothing else was written
+
+
+@pytest.mark.parametrize("cfg", [(70, 300, 0), (70, 300, 3), (257, 1000, 64), (40, 90, 130), (300, 2100, 17)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_negative_masks_random_ids_bit_exact(mf, cfg):
+    """Hit masks on heavily duplicated random ids (Zipf-like), incl. no positives, ragged sizes, and a
+    positive list too long for the LDS aggregation table (P = 130 -> global atomics path)."""
+    b, n, p = cfg
+    g = torch.Generator().manual_seed(b + n + p)
+    item_idx = torch.randint(0, max(n // 6, 3), (n,), generator=g)         # many duplicate columns, id 0 included
+    pos_idx = torch.randint(0, max(n // 6, 3) + 5, (b, p), generator=g) if p else None
+    fn = mf.losses.PairwiseHingeLoss(num_negatives=0)
+    got = fn.negative_masks(torch.zeros(b, n, device=DEV), item_idx=item_idx.to(DEV),
+                            pos_idx=None if pos_idx is None else pos_idx.to(DEV)).cpu()
+    want = ol.negative_masks(item_idx, pos_idx, b)
+    assert torch.equal(got, want), int((got != want).sum())
