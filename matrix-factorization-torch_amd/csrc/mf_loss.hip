@@ -53,7 +53,7 @@ struct LossWs {
     uint32_t* maskW;
     float *part, *stats, *rowloss, *rowc, *dpart, *stash, *gstash, *blockpart;
     unsigned* ticket;
-    unsigned long long* cand;
+    unsigned long long *cand, *priv, *seeds;
     int32_t *cand_cnt, *sel, *sel_cnt;
     unsigned* gtau;
     float* sel_L;
@@ -107,7 +107,9 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.blockpart = a.take<float>((size_t)MF_NUM_KINDS * (w.Bp / 256 + 1));
     w.ticket = a.take<unsigned>(4);
     if (w.mined) {
-        w.cand = a.take<unsigned long long>((size_t)w.nchunk * w.Bp * w.CAP);
+        w.cand = a.take<unsigned long long>((size_t)w.Bp * w.plan.rowcap);
+        w.priv = a.take<unsigned long long>((size_t)w.plan.nsets * w.Bp * w.plan.CAP);
+        w.seeds = a.take<unsigned long long>((size_t)w.Bp * (w.plan.seeds_per_row > 0 ? w.plan.seeds_per_row : 1));
         w.sel = a.take<int32_t>((size_t)w.Bp * KSEL_MAX);
         w.sel_cnt = a.take<int32_t>(w.Bp);
         w.sel_L = a.take<float>((size_t)w.Bp * KSEL_MAX);
@@ -691,27 +693,16 @@ struct MiningPolicy {
     }
 };
 
-// one wave per user: exact ordered top-k of the chunk candidates -> sel[i][0..cnt)
+// one wave per user: exact ordered top-k of the row's candidate list -> sel[i][0..cnt)
 __global__ __launch_bounds__(64) void mined_merge_kernel(const unsigned long long* __restrict__ cand,
-                                                         const int32_t* __restrict__ cand_cnt, int nchunk,
-                                                         int64_t Bp, int CAP, int k, int32_t* __restrict__ sel,
-                                                         int32_t* __restrict__ sel_cnt) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+                                                         const int32_t* __restrict__ cand_cnt, int rowcap, int k,
+                                                         int32_t* __restrict__ sel, int32_t* __restrict__ sel_cnt) {
+    __shared__ unsigned long long win[64], sorted[64];
     const int64_t i = blockIdx.x;
-    const int lane = mf_lane();
-    const int total = cand_cnt[i];
-    const unsigned long long* src = cand + i * (int64_t)nchunk * CAP;
-    for (int t = lane; t < total; t += 64) s_keys[t] = src[t];
-    __syncthreads();
-    int32_t* out = sel + i * KSEL_MAX;
-    int found = 0;
-    mf_wave_select(s_keys, total, k, [&](int t, unsigned long long key) {
-        if (key != 0ull) {
-            out[t] = (int32_t)mf_key_mining_col(key);
-            found = t + 1;
-        }
-    });
-    if (lane == 0) sel_cnt[i] = found;
+    const int m = mf_row_topk<8>(cand + i * (int64_t)rowcap, cand_cnt[i], k, win, sorted);
+    const int t = mf_lane();
+    if (t < m) sel[i * KSEL_MAX + t] = (int32_t)mf_key_mining_col(sorted[t]);
+    if (t == 0) sel_cnt[i] = m;
 }
 
 // statistics of the mined negatives (thread per user, selection order)
@@ -1069,27 +1060,6 @@ static int check_loss_args(const char* what, int64_t B, int64_t N, int d, int P,
     return MF_OK;
 }
 
-template <int D, int T>
-static void launch_mining_select_t(const LossWs& w, const MiningPolicy::Params& mp, const SelectCommon& sc, hipStream_t s) {
-    auto fn = select_kernel<D, T, MiningPolicy>;
-    const int bytes = SelectLds<D>::bytes(sc.capl);
-    (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    fn<<<dim3((unsigned)w.plan.nchunk, (unsigned)w.plan.gx), 256, bytes, s>>>(mp, sc);
-}
-template <int D>
-static void launch_mining_select(const LossWs& w, const MiningPolicy::Params& mp, const SelectCommon& sc,
-                                 hipStream_t s) {
-    switch (w.T) {
-        case 2: launch_mining_select_t<D, 2>(w, mp, sc, s); break;
-        case 4: launch_mining_select_t<D, 4>(w, mp, sc, s); break;
-        case 8: launch_mining_select_t<D, 8>(w, mp, sc, s); break;
-        case 10: launch_mining_select_t<D, 10>(w, mp, sc, s); break;
-        case 12: launch_mining_select_t<D, 12>(w, mp, sc, s); break;
-        case 16: launch_mining_select_t<D, 16>(w, mp, sc, s); break;
-        default: launch_mining_select_t<D, 32>(w, mp, sc, s); break;
-    }
-}
-
 extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
                            int kind_mask, const float* u, const float* v, const float* target,
                            const int64_t* item_idx, const int64_t* pos_idx, const float* logq, void* ws,
@@ -1132,11 +1102,10 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
             mask_export_dense_kernel<<<dim3((unsigned)((B * ((N + 31) / 32) + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, (int)((N + 31) / 32), out_mask_bits);
     } else if (scores_needed) {
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
-        SelectCommon sc{u, B, v, N, (int)((N + 31) / 32), w.tpc, w.Bp, num_negatives, w.plan.xw, w.plan.CAPL, w.gtau, w.cand, w.cand_cnt, w.nchunk * w.CAP};
+        SelectCommon sc{u, B, v, N, 0, (int)((N + 31) / 32), w.plan.tpc, w.Bp, num_negatives, w.plan.xw, w.gtau, w.priv, w.cand, w.cand_cnt, w.plan.rowcap};
         (void)hipMemsetAsync(w.gtau, 0, (size_t)((char*)(w.cand_cnt + w.Bp) - (char*)w.gtau), s);
-        MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, launch_mining_select<D>(w, mp, sc, s)); });
-        mined_merge_kernel<<<dim3((unsigned)B), 64, (size_t)w.nchunk * w.CAP * 8, s>>>(w.cand, w.cand_cnt, w.nchunk, w.Bp, w.CAP,
-                                                                                      num_negatives, w.sel, w.sel_cnt);
+        MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s))); });
+        mined_merge_kernel<<<dim3((unsigned)B), 64, 0, s>>>(w.cand, w.cand_cnt, w.plan.rowcap, num_negatives, w.sel, w.sel_cnt);
         mined_stats_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.sel,
                                                                                 w.sel_cnt, B, w.Bp, d, sigma, margin, need,
                                                                                 w.sel_L, w.stats);

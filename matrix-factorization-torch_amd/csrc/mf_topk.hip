@@ -56,6 +56,8 @@ struct TopkWs {
     SelectPlan plan;
     int NT;
     unsigned long long* cand;
+    unsigned long long* priv;
+    unsigned long long* seeds;
     int32_t* cand_cnt;
     uint32_t* exclW;
     unsigned* gtau;      // gtau and cand_cnt sit right behind exclW: one memset clears all three
@@ -67,7 +69,9 @@ static TopkWs topk_ws(void* base, int64_t Q, int64_t N, int d, int k) {
     w.plan = mf_select_plan(Q, N, d, k);
     w.NT = (int)((N + 31) / 32);
     MfArena a(base);
-    w.cand = a.take<unsigned long long>((size_t)w.plan.nsets * w.plan.Xp * w.plan.CAP);
+    w.cand = a.take<unsigned long long>((size_t)w.plan.Xp * w.plan.rowcap);
+    w.priv = a.take<unsigned long long>((size_t)w.plan.nsets * w.plan.Xp * w.plan.CAP);
+    w.seeds = a.take<unsigned long long>((size_t)w.plan.Xp * (w.plan.seeds_per_row > 0 ? w.plan.seeds_per_row : 1));
     w.exclW = a.take<uint32_t>((size_t)w.NT * w.plan.Xp);
     w.gtau = a.take<unsigned>((size_t)w.plan.Xp);
     w.cand_cnt = a.take<int32_t>((size_t)w.plan.Xp);
@@ -80,28 +84,24 @@ extern "C" size_t mf_topk_ws_bytes(int64_t Q, int64_t N, int d, int k) {
     return topk_ws(nullptr, Q, N, d, k).total;
 }
 
-// one wave per query: candidates of all chunks -> ordered top-k
+// one wave per query: the row's candidate list -> ordered top-k
 __global__ __launch_bounds__(64) void topk_merge_cand_kernel(const unsigned long long* __restrict__ cand,
-                                                             const int32_t* __restrict__ cand_cnt, int nchunk,
-                                                             int64_t Qp, int CAP, int k, int64_t idx_base,
-                                                             float* __restrict__ out_scores,
+                                                             const int32_t* __restrict__ cand_cnt, int rowcap, int k,
+                                                             int64_t idx_base, float* __restrict__ out_scores,
                                                              int64_t* __restrict__ out_idx) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+    __shared__ unsigned long long win[64], sorted[64];
     const int64_t r = blockIdx.x;
-    const int lane = mf_lane();
-    const int total = cand_cnt[r];
-    const unsigned long long* src = cand + r * (int64_t)nchunk * CAP;
-    for (int t = lane; t < total; t += 64) s_keys[t] = src[t];
-    __syncthreads();
-    mf_wave_select(s_keys, total, k, [&](int t, unsigned long long key) {
-        if (key != 0ull) {
-            out_scores[r * k + t] = mf_key_retrieval_score(key);
-            out_idx[r * k + t] = idx_base + (int64_t)mf_key_retrieval_col(key);
+    const int m = mf_row_topk<8>(cand + r * (int64_t)rowcap, cand_cnt[r], k, win, sorted);
+    const int t = mf_lane();
+    if (t < k) {
+        if (t < m) {
+            out_scores[r * k + t] = mf_key_retrieval_score(sorted[t]);
+            out_idx[r * k + t] = idx_base + (int64_t)mf_key_retrieval_col(sorted[t]);
         } else {
             out_scores[r * k + t] = -INFINITY;
             out_idx[r * k + t] = -1;
         }
-    });
+    }
 }
 
 // merge of G already-ordered partial results with GLOBAL indices (< 2^32)
@@ -127,26 +127,6 @@ __global__ __launch_bounds__(64) void topk_merge_parts_kernel(const float* __res
             out_idx[r * k + t] = -1;
         }
     });
-}
-
-template <int D, int T>
-static void launch_topk_select_t(const TopkWs& w, const RetrievalPolicy::Params& rp, const SelectCommon& sc, hipStream_t s) {
-    auto fn = select_kernel<D, T, RetrievalPolicy>;
-    const int bytes = SelectLds<D>::bytes(sc.capl);
-    (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    fn<<<dim3((unsigned)w.plan.nchunk, (unsigned)w.plan.gx), 256, bytes, s>>>(rp, sc);
-}
-template <int D>
-static void launch_topk_select(const TopkWs& w, const RetrievalPolicy::Params& rp, const SelectCommon& sc, hipStream_t s) {
-    switch (w.plan.T) {
-        case 2: launch_topk_select_t<D, 2>(w, rp, sc, s); break;
-        case 4: launch_topk_select_t<D, 4>(w, rp, sc, s); break;
-        case 8: launch_topk_select_t<D, 8>(w, rp, sc, s); break;
-        case 10: launch_topk_select_t<D, 10>(w, rp, sc, s); break;
-        case 12: launch_topk_select_t<D, 12>(w, rp, sc, s); break;
-        case 16: launch_topk_select_t<D, 16>(w, rp, sc, s); break;
-        default: launch_topk_select_t<D, 32>(w, rp, sc, s); break;
-    }
 }
 
 #ifdef MF_PROBE
@@ -190,10 +170,9 @@ extern "C" int mf_topk(const float* q, int64_t Q, const float* items, int64_t N,
     (void)hipMemsetAsync(w.exclW, 0, (size_t)((char*)(w.cand_cnt + w.plan.Xp) - (char*)w.exclW), s);
     if (excl_off) excl_scatter_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.plan.Xp, w.exclW);
     RetrievalPolicy::Params rp{w.exclW, w.plan.Xp, N};
-    SelectCommon sc{q, Q, items, N, w.NT, w.plan.tpc, w.plan.Xp, k, w.plan.xw, w.plan.CAPL, w.gtau, w.cand, w.cand_cnt, w.plan.nsets * w.plan.CAP};
-    MF_DISPATCH_D(d, { MF_TIMED("topk_select", s, launch_topk_select<D>(w, rp, sc, s)); });
-    topk_merge_cand_kernel<<<dim3((unsigned)Q), 64, (size_t)w.plan.nsets * w.plan.CAP * 8, s>>>(w.cand, w.cand_cnt, w.plan.nsets, w.plan.Xp, w.plan.CAP, k,
-                                                                                      idx_base, out_scores, out_idx);
+    SelectCommon sc{q, Q, items, N, 0, w.NT, w.plan.tpc, w.plan.Xp, k, w.plan.xw, w.gtau, w.priv, w.cand, w.cand_cnt, w.plan.rowcap};
+    MF_DISPATCH_D(d, { MF_TIMED("topk_select", s, (mf_select_run<D, RetrievalPolicy>(w.plan, rp, sc, w.seeds, Q, s))); });
+    topk_merge_cand_kernel<<<dim3((unsigned)Q), 64, 0, s>>>(w.cand, w.cand_cnt, w.plan.rowcap, k, idx_base, out_scores, out_idx);
     return mf_check_launch("mf_topk");
 }
 
