@@ -77,13 +77,8 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.BT = (int)(w.Bp / 32); w.NT = (int)(w.Np / 32);
     w.mined = mining_on(num_negatives, N);
     split_geometry(w.BT / 4, w.NT, &w.nsplit_f, &w.tps_f, 512);
-#ifdef MF_ABL_BWD2
     split_geometry(w.BT / 4, w.NT, &w.nsplit_u, &w.tps_u, 512);
-    split_geometry(w.NT / 4, w.BT, &w.nsplit_v, &w.tps_v, 256);
-#else
-    split_geometry(w.BT / 4, w.NT, &w.nsplit_u, &w.tps_u, 256);
-    split_geometry(w.NT / 4, w.BT, &w.nsplit_v, &w.tps_v, 256);
-#endif
+    split_geometry(w.NT / 4, w.BT, &w.nsplit_v, &w.tps_v, 512);
     const int k = num_negatives;
     w.plan = mf_select_plan(B, N, d, k);
     w.T = w.plan.T; w.CAP = w.plan.CAP; w.nchunk = w.plan.nsets; w.tpc = w.plan.tpc;
@@ -820,13 +815,11 @@ struct BwdLds {
     using G = TileGeom<D>;
     static constexpr int LT = G::TILEB;                  // 4 x 4 KiB stash blocks (one per wave)
     static constexpr int SLOT = G::TILEB + 4 * 4096;
-    static constexpr int EXTRA = XU ? 0 : 4 * 33 * 32 * 4;
-#ifdef MF_ABL_BWD2
-    static constexpr int NSLOT = 2;
-#else
-    static constexpr int NSLOT = (3 * SLOT + EXTRA <= 160 * 1024) ? 3 : 2;   // d = 256: 2-deep ring, 2 barriers
-#endif
-    static constexpr int TR = NSLOT * SLOT;              // dV: per-wave 32 x 33 transpose scratch
+    static constexpr int EXTRA = XU ? 0 : 4 * 32 * 32 * 4;   // dV: per-wave 32 x 32 transpose scratch (XOR-swizzled)
+    // the deepest ring that still lets TWO workgroups share a CU's 160 KiB (a second wave per SIMD hides
+    // the first one's barrier and VALU phases); 2 slots cost a second barrier per tile, measured free
+    static constexpr int NSLOT = (2 * (3 * SLOT + EXTRA) <= 160 * 1024) ? 3 : 2;
+    static constexpr int TR = NSLOT * SLOT;
     static constexpr int BYTES = TR + EXTRA;
     static constexpr int NDMA = G::PPW + 4;              // DMA instructions per wave per stage
 };
@@ -904,11 +897,11 @@ __global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
                 *reinterpret_cast<f32x4*>(blk + q * 256) = f32x4{Gv[4 * q], Gv[4 * q + 1], Gv[4 * q + 2], Gv[4 * q + 3]};
         } else {
             // block layout is (lane = user, register = item row): transpose to (lane = item, register = user row)
-            float* tr = reinterpret_cast<float*>(smem + L::TR) + wave * (33 * 32);
+            float* tr = reinterpret_cast<float*>(smem + L::TR) + wave * (32 * 32);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) tr[mf_acc_row(e, h) * 33 + c] = Gv[e];
+            for (int e = 0; e < 16; ++e) tr[mf_acc_row(e, h) * 32 + (c ^ mf_acc_row(e, h))] = Gv[e];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Gv[e] = tr[c * 33 + mf_acc_row(e, h)];
+            for (int e = 0; e < 16; ++e) Gv[e] = tr[c * 32 + (mf_acc_row(e, h) ^ c)];
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) rsum += Gv[e];
