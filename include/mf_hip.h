@@ -75,6 +75,21 @@ int64_t mf_timing_get(const char* name, double* total_ms);
 int mf_gather_rows(const float* table, int64_t n_rows, int d, const int64_t* idx, int64_t n,
                    int normalize, float* out, float* out_inv_norm, mf_stream_t stream);
 
+/* Hash / bloom embedding tower (BASELINE config 5: catalogs too large for one row per id; our spec,
+ * mf_numerics.h mf_hash_bucket): id -> num_hashes (1..4) bucket rows of a [num_buckets, d] table,
+ *   out[r, :] = sum_j table[bucket_j(idx[r]), :]   (j ascending; then / max(||.||, 1e-12) if normalize)
+ * mf_hash_buckets writes the bucket rows themselves, out_buckets[r * num_hashes + j] -- the row ids
+ * the sparse update of the table is called with.  mf_normalize_backward turns the gradient w.r.t.
+ * the normalised output into the gradient w.r.t. the summed rows (the same for each of the id's
+ * rows): graw = (g - u (u . g)) * inv_norm, u = the normalised output row. */
+int mf_gather_hashed(const float* table, int64_t num_buckets, int d, const int64_t* idx, int64_t n,
+                     int num_hashes, uint64_t seed, int normalize, float* out, float* out_inv_norm,
+                     mf_stream_t stream);
+int mf_hash_buckets(const int64_t* idx, int64_t n, int num_hashes, uint64_t seed, int64_t num_buckets,
+                    int64_t* out_buckets, mf_stream_t stream);
+int mf_normalize_backward(const float* out_unit, const float* inv_norm, const float* grad, int64_t n, int d,
+                          float* grad_raw, mf_stream_t stream);
+
 /* out[r] = chain-ordered ||x_r||^2 (mf_numerics.h); helper of the loss path. */
 int mf_row_sqnorm(const float* x, int64_t n, int d, float* out, mf_stream_t stream);
 
@@ -169,6 +184,18 @@ int mf_topk(const float* q, int64_t Q, const float* items, int64_t N, int d, int
  * catalog) part_*[G,Q,k] into the global top-k with the same order. */
 int mf_topk_merge(const float* part_scores, const int64_t* part_idx, int G, int64_t Q, int k,
                   float* out_scores, int64_t* out_idx, mf_stream_t stream);
+
+/* Retrieval metrics @k on device, straight from the top-k output.  Replaces the
+ * per-example torchmetrics updates of `update_metrics` / `get_metrics` (xfmr_rec/lightning.py:149-187,
+ * :289-306: RetrievalNormalizedDCG / Recall / Precision / MAP / HitRate / MRR, top_k = 20).
+ * topk_idx[Q,k]: retrieved item ids, best first (-1 = none); the targets of query q are
+ * tgt_idx / tgt_rel[tgt_off[q] .. tgt_off[q+1]) (item id, rating); an unretrieved target ranks below
+ * every retrieved item (the reference gives it -U(0,1): the same whenever retrieved scores are
+ * positive).  out[q][6] = {ndcg, recall, precision, map, hit_rate, mrr} of query q with torchmetrics'
+ * definitions: linear gain / log2 discount, binary relevance = rating > 0 for the other five,
+ * precision divided by k, a query without positive target scores 0 everywhere. */
+int mf_retrieval_metrics(const int64_t* topk_idx, int64_t Q, int k, const int64_t* tgt_off,
+                         const int64_t* tgt_idx, const float* tgt_rel, float* out, mf_stream_t stream);
 
 #ifdef __cplusplus
 }

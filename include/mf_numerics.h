@@ -125,4 +125,21 @@ MF_HD unsigned mf_key_mining_col(unsigned long long key) {
     return 0x3FFFFFFFu - (unsigned)(key & 0x3FFFFFFFull);
 }
 
+/*
+ * Hash / bloom embeddings (BASELINE config 5; our spec, no reference counterpart): an id owns
+ * num_hashes rows of a table of num_buckets rows and its embedding is their sum.  Hash j of id x is
+ * the SplitMix64 output function applied to x + seed + (j + 1) * golden-gamma, reduced modulo
+ * num_buckets (for x = seed = 0, j = 0 the mixed word is SplitMix64's first output
+ * 0xE220A8397B1DCDAF -- the known-answer that pins the constants, tests/test_host_cpu.py).
+ */
+MF_HD unsigned long long mf_splitmix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+MF_HD long long mf_hash_bucket(long long id, int j, unsigned long long seed, long long num_buckets) {
+    const unsigned long long z = (unsigned long long)id + seed + (unsigned long long)(j + 1) * 0x9E3779B97F4A7C15ull;
+    return (long long)(mf_splitmix64(z) % (unsigned long long)num_buckets);
+}
+
 #endif /* MF_NUMERICS_H */

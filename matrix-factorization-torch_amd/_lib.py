@@ -25,6 +25,9 @@ SIGNATURES = {
     "mf_timing_reset": (None, []),
     "mf_timing_get": (c_i64, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]),
     "mf_gather_rows": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "mf_gather_hashed": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, ctypes.c_uint64, c_int, c_vp, c_vp, c_vp]),
+    "mf_hash_buckets": (c_int, [c_vp, c_i64, c_int, ctypes.c_uint64, c_i64, c_vp, c_vp]),
+    "mf_normalize_backward": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     "mf_row_sqnorm": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "mf_scores": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp]),
     "mf_sort_ws_bytes": (c_sz, [c_i64]),
@@ -43,6 +46,7 @@ SIGNATURES = {
                                c_f32, c_f32, c_f32, c_vp, c_sz, c_vp]),
     "mf_topk_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int]),
     "mf_topk": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "mf_retrieval_metrics": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mf_topk_merge": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
 }
 

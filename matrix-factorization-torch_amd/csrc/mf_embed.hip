@@ -54,6 +54,105 @@ extern "C" int mf_gather_rows(const float* table, int64_t n_rows, int d, const i
     return mf_check_launch("mf_gather_rows");
 }
 
+// ------------------------------------------------------- hash / bloom towers ----
+template <int D>
+__global__ __launch_bounds__(256) void gather_hashed_kernel(const float* __restrict__ table, int64_t num_buckets,
+                                                            const int64_t* __restrict__ idx, int64_t n, int num_hashes,
+                                                            unsigned long long seed, int normalize,
+                                                            float* __restrict__ out, float* __restrict__ out_inv) {
+    constexpr int LPR = D / 4;
+    constexpr int RPW = 64 / LPR;
+    const int lane = mf_lane();
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t r = wave * RPW + lane / LPR;
+    const int c = lane % LPR;
+    const bool valid = r < n;
+    const long long id = valid ? idx[r] : 0;
+    f32x4 rows[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // all rows in flight, added in hash order
+        rows[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j < num_hashes) rows[j] = reinterpret_cast<const f32x4*>(table + mf_hash_bucket(id, j, seed, num_buckets) * D)[c];
+    }
+    f32x4 x = rows[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (j < num_hashes) x += rows[j];
+    float inv = 1.f;
+    if (normalize) {
+        float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+        ss = mf_group_sum(ss, LPR);
+        inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+        x = x * inv;
+    }
+    if (valid) {
+        reinterpret_cast<f32x4*>(out + r * D)[c] = x;
+        if (out_inv && c == 0) out_inv[r] = inv;
+    }
+}
+
+extern "C" int mf_gather_hashed(const float* table, int64_t num_buckets, int d, const int64_t* idx, int64_t n,
+                                int num_hashes, uint64_t seed, int normalize, float* out, float* out_inv_norm,
+                                mf_stream_t stream) {
+    if (!table || !idx || !out || n < 0 || num_buckets <= 0) return mf_set_error(MF_EINVAL, "mf_gather_hashed: bad argument");
+    if (num_hashes < 1 || num_hashes > 4) return mf_set_error(MF_ENOTSUP, "mf_gather_hashed: num_hashes = %d outside 1..4", num_hashes);
+    if (n == 0) return MF_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MF_DISPATCH_D(d, {
+        constexpr int RPB = (64 / (D / 4)) * 4;
+        dim3 grid((unsigned)((n + RPB - 1) / RPB));
+        MF_TIMED("gather_rows", s, gather_hashed_kernel<D><<<grid, 256, 0, s>>>(table, num_buckets, idx, n, num_hashes, seed, normalize, out, out_inv_norm));
+    });
+    return mf_check_launch("mf_gather_hashed");
+}
+
+__global__ __launch_bounds__(256) void hash_buckets_kernel(const int64_t* __restrict__ idx, int64_t n, int num_hashes,
+                                                           unsigned long long seed, int64_t num_buckets,
+                                                           int64_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * num_hashes) return;
+    out[t] = mf_hash_bucket(idx[t / num_hashes], (int)(t % num_hashes), seed, num_buckets);
+}
+
+extern "C" int mf_hash_buckets(const int64_t* idx, int64_t n, int num_hashes, uint64_t seed, int64_t num_buckets,
+                               int64_t* out_buckets, mf_stream_t stream) {
+    if (!idx || !out_buckets || n < 0 || num_buckets <= 0) return mf_set_error(MF_EINVAL, "mf_hash_buckets: bad argument");
+    if (num_hashes < 1 || num_hashes > 4) return mf_set_error(MF_ENOTSUP, "mf_hash_buckets: num_hashes = %d outside 1..4", num_hashes);
+    if (n == 0) return MF_OK;
+    hash_buckets_kernel<<<dim3((unsigned)((n * num_hashes + 255) / 256)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        idx, n, num_hashes, seed, num_buckets, out_buckets);
+    return mf_check_launch("mf_hash_buckets");
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void normalize_backward_kernel(const float* __restrict__ unit, const float* __restrict__ inv_norm,
+                                                                 const float* __restrict__ grad, int64_t n,
+                                                                 float* __restrict__ graw) {
+    constexpr int LPR = D / 4;
+    constexpr int RPW = 64 / LPR;
+    const int lane = mf_lane();
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t r = wave * RPW + lane / LPR;
+    const int c = lane % LPR;
+    const int64_t rr = r < n ? r : 0;
+    const f32x4 u = reinterpret_cast<const f32x4*>(unit + rr * D)[c];
+    const f32x4 g = reinterpret_cast<const f32x4*>(grad + rr * D)[c];
+    const float pr = mf_group_sum(g[0] * u[0] + g[1] * u[1] + g[2] * u[2] + g[3] * u[3], LPR);
+    if (r < n) reinterpret_cast<f32x4*>(graw + r * D)[c] = (g - u * pr) * inv_norm[r];
+}
+
+extern "C" int mf_normalize_backward(const float* out_unit, const float* inv_norm, const float* grad, int64_t n, int d,
+                                     float* grad_raw, mf_stream_t stream) {
+    if (!out_unit || !inv_norm || !grad || !grad_raw || n < 0) return mf_set_error(MF_EINVAL, "mf_normalize_backward: bad argument");
+    if (n == 0) return MF_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MF_DISPATCH_D(d, {
+        constexpr int RPB = (64 / (D / 4)) * 4;
+        normalize_backward_kernel<D><<<dim3((unsigned)((n + RPB - 1) / RPB)), 256, 0, s>>>(out_unit, inv_norm, grad, n, grad_raw);
+    });
+    return mf_check_launch("mf_normalize_backward");
+}
+
 // ------------------------------------------------------------- chain norms ----
 __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ x, int64_t n, int d,
                                                          float* __restrict__ out) {

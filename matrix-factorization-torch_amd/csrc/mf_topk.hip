@@ -185,3 +185,69 @@ extern "C" int mf_topk_merge(const float* part_scores, const int64_t* part_idx, 
         part_scores, part_idx, G, Q, k, out_scores, out_idx);
     return mf_check_launch("mf_topk_merge");
 }
+
+// ------------------------------------------------------------ retrieval metrics ----
+// one wave per query; lane t holds the item retrieved at rank t
+__global__ __launch_bounds__(64) void retrieval_metrics_kernel(const int64_t* __restrict__ topk_idx, int k,
+                                                               const int64_t* __restrict__ tgt_off,
+                                                               const int64_t* __restrict__ tgt_idx,
+                                                               const float* __restrict__ tgt_rel, float* __restrict__ out) {
+    const int64_t q = blockIdx.x;
+    const int lane = mf_lane();
+    const int64_t e0 = tgt_off[q], e1 = tgt_off[q + 1];
+    const int64_t item = lane < k ? topk_idx[q * k + lane] : -1;
+    float rel = 0.f;                                   // rating of the item at this rank (0: not a target)
+    // a target the search missed ranks right below the retrieved items (list order): it only enters the
+    // top k when fewer than k items were retrieved, exactly as in the reference's union of both sets
+    int slot = __popcll(__ballot(item >= 0));
+    for (int64_t e = e0; e < e1; ++e) {
+        const bool mine = item >= 0 && tgt_idx[e] == item;
+        if (mine) rel = tgt_rel[e];
+        if (!__any(mine)) {
+            if (lane == slot && lane < k) rel = tgt_rel[e];
+            ++slot;
+        }
+    }
+    // ideal DCG: the targets' ratings in descending order (rank by counting), best k of them
+    float idcg = 0.f;
+    int npos = 0;
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+        const float r = tgt_rel[e];
+        npos += r > 0.f ? 1 : 0;
+        int rank = 0;
+        for (int64_t f = e0; f < e1; ++f) {
+            const float o = tgt_rel[f];
+            rank += (o > r || (o == r && f < e)) ? 1 : 0;
+        }
+        if (rank < k) idcg += r / log2f((float)rank + 2.f);
+    }
+    float dcg = rel / log2f((float)lane + 2.f);
+    for (int o = 32; o > 0; o >>= 1) {
+        dcg += __shfl_xor(dcg, o, 64);
+        idcg += __shfl_xor(idcg, o, 64);
+        npos += __shfl_xor(npos, o, 64);
+    }
+    const unsigned long long hit = __ballot(rel > 0.f);
+    const int hits = __popcll(hit);
+    float ap = 0.f;                                    // precision at every relevant rank
+    if (rel > 0.f) ap = (float)__popcll(hit & ((2ull << lane) - 1ull)) / (float)(lane + 1);
+    for (int o = 32; o > 0; o >>= 1) ap += __shfl_xor(ap, o, 64);
+    if (lane == 0) {
+        float* o = out + q * 6;
+        const bool any = npos > 0;
+        o[0] = (any && idcg > 0.f) ? dcg / idcg : 0.f;
+        o[1] = any ? (float)hits / (float)npos : 0.f;
+        o[2] = any ? (float)hits / (float)k : 0.f;
+        o[3] = hits > 0 ? ap / (float)hits : 0.f;
+        o[4] = hits > 0 ? 1.f : 0.f;
+        o[5] = hits > 0 ? 1.f / (float)(__builtin_ctzll(hit) + 1) : 0.f;
+    }
+}
+
+extern "C" int mf_retrieval_metrics(const int64_t* topk_idx, int64_t Q, int k, const int64_t* tgt_off,
+                                    const int64_t* tgt_idx, const float* tgt_rel, float* out, mf_stream_t stream) {
+    if (!topk_idx || !tgt_off || !tgt_idx || !tgt_rel || !out || Q <= 0) return mf_set_error(MF_EINVAL, "mf_retrieval_metrics: bad argument");
+    if (k <= 0 || k > 64) return mf_set_error(MF_ENOTSUP, "mf_retrieval_metrics: k = %d outside 1..64", k);
+    retrieval_metrics_kernel<<<dim3((unsigned)Q), 64, 0, static_cast<hipStream_t>(stream)>>>(topk_idx, k, tgt_off, tgt_idx, tgt_rel, out);
+    return mf_check_launch("mf_retrieval_metrics");
+}

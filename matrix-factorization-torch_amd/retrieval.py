@@ -128,3 +128,53 @@ class ItemProcessor:
                 "score": scores[0].cpu()[keep].numpy(),
             }
         )
+
+
+METRIC_NAMES = ("RetrievalNormalizedDCG", "RetrievalRecall", "RetrievalPrecision", "RetrievalMAP", "RetrievalHitRate",
+                "RetrievalMRR")
+
+
+class RetrievalMetrics:
+    """The reference's ``MetricCollection`` of six retrieval metrics @top_k
+    (xfmr_rec/lightning.py:289-306), fed with whole batches of top-k results instead of one
+    ``update`` per example (``update_metrics`` :149-187).  ``compute()`` returns
+    ``{prefix + class name: mean over all queries seen}`` like ``MetricCollection.compute``."""
+
+    def __init__(self, top_k: int = TOP_K, prefix: str = "") -> None:
+        self.top_k, self.prefix = int(top_k), prefix
+        self.reset()
+
+    def reset(self) -> None:
+        self._sum, self._n = None, 0
+
+    @torch.no_grad()
+    def update(self, topk_idx: torch.Tensor, target_offsets: torch.Tensor, target_idx: torch.Tensor,
+               target_rating: torch.Tensor) -> torch.Tensor:
+        """``topk_idx`` [Q, top_k] retrieved item ids, best first (``ItemIndex.search``); the targets of query q
+        are ``target_idx / target_rating[target_offsets[q] : target_offsets[q + 1]]``.  Returns [Q, 6]."""
+        ti = _lib.dev_i64(topk_idx, "topk_idx")
+        q, k = ti.shape
+        if k != self.top_k:
+            msg = f"expected top_k = {self.top_k} columns: {k = }"
+            raise ValueError(msg)
+        off = _lib.dev_i64(target_offsets, "target_offsets")
+        ids = _lib.dev_i64(target_idx, "target_idx")
+        rel = _lib.dev_f32(target_rating, "target_rating")
+        if off.numel() != q + 1 or ids.numel() != rel.numel():
+            msg = f"target CSR does not match the queries: {off.numel() = }, {q = }, {ids.numel() = }, {rel.numel() = }"
+            raise ValueError(msg)
+        if ids.numel() == 0:       # keep the pointers valid
+            ids, rel = torch.zeros(1, dtype=torch.int64, device=ti.device), torch.zeros(1, device=ti.device)
+        out = torch.empty(q, 6, dtype=torch.float32, device=ti.device)
+        _lib.check(_lib.lib().mf_retrieval_metrics(ti.data_ptr(), q, k, off.data_ptr(), ids.data_ptr(), rel.data_ptr(),
+                                                   out.data_ptr(), _lib.stream_ptr()))
+        tot = out.sum(dim=0, dtype=torch.float64)
+        self._sum = tot if self._sum is None else self._sum + tot
+        self._n += q
+        return out
+
+    def compute(self) -> dict[str, torch.Tensor]:
+        if not self._n:
+            return {self.prefix + name: torch.tensor(0.0) for name in METRIC_NAMES}
+        mean = (self._sum / self._n).to(torch.float32)
+        return {self.prefix + name: mean[j] for j, name in enumerate(METRIC_NAMES)}

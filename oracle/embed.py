@@ -18,6 +18,34 @@ def gather(table: torch.Tensor, idx: torch.Tensor, normalize: bool = True) -> to
     return rows
 
 
+_M64 = (1 << 64) - 1
+
+
+def hash_buckets(idx: torch.Tensor, num_hashes: int, seed: int, num_buckets: int) -> torch.Tensor:
+    """``[*, num_hashes]`` bucket rows: SplitMix64 output function of id + seed + (j + 1) * golden gamma,
+    modulo num_buckets (include/mf_numerics.h ``mf_hash_bucket``; our spec).  Python ints: exact."""
+    out = []
+    for x in idx.reshape(-1).tolist():
+        for j in range(num_hashes):
+            z = (x + seed + (j + 1) * 0x9E3779B97F4A7C15) & _M64
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+            z ^= z >> 31
+            out.append(z % num_buckets)
+    return torch.tensor(out, dtype=torch.int64).reshape(*idx.shape, num_hashes)
+
+
+def gather_hashed(table: torch.Tensor, idx: torch.Tensor, num_hashes: int, seed: int, normalize: bool = True) -> torch.Tensor:
+    """Bloom embedding: sum of the id's bucket rows (hash order), optionally L2-normalised."""
+    b = hash_buckets(idx, num_hashes, seed, table.shape[0])
+    rows = table[b[..., 0]]
+    for j in range(1, num_hashes):
+        rows = rows + table[b[..., j]]
+    if normalize:
+        rows = rows / rows.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    return rows
+
+
 def normalize_backward(rows_raw: torch.Tensor, grad_out: torch.Tensor) -> torch.Tensor:
     """d/d raw of (raw / max(||raw||, 1e-12)) applied to grad_out (row-wise)."""
     nrm = rows_raw.norm(dim=-1, keepdim=True).clamp_min(1e-12)

@@ -363,3 +363,83 @@ def test_negative_masks_random_ids_bit_exact(mf, cfg):
                             pos_idx=None if pos_idx is None else pos_idx.to(DEV)).cpu()
     want = ol.negative_masks(item_idx, pos_idx, b)
     assert torch.equal(got, want), int((got != want).sum())
+
+
+# --------------------------------------------------------- hash / bloom towers (config 5) ---
+@pytest.mark.parametrize("d", [32, 256])
+@pytest.mark.parametrize("num_hashes", [1, 2, 4])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_hash_tower_forward_matches_oracle(mf, d, num_hashes, normalize):
+    g = torch.Generator().manual_seed(d + num_hashes)
+    table = torch.randn(997, d, generator=g)
+    idx = torch.randint(0, 10**9, (5, 41), generator=g)
+    idx[0, 0], idx[0, 1] = 0, -3
+    tower = mf.models.HashEmbeddingTower(997, d, num_hashes=num_hashes, seed=11, normalize=normalize, device=DEV)
+    with torch.no_grad():
+        tower.weight.copy_(table.to(DEV))
+    assert torch.equal(tower.buckets(idx.to(DEV)).cpu(), oembed.hash_buckets(idx, num_hashes, 11, 997))   # bit-exact
+    got = tower(idx.to(DEV)).detach().cpu()
+    want = oembed.gather_hashed(table, idx, num_hashes, 11, normalize)
+    if normalize:
+        torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    else:
+        assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_hash_tower_training_step_matches_oracle(mf, opt):
+    """Gradient of the normalised bloom sum reaches every bucket row of an id; collisions and duplicate
+    ids are summed like any duplicate row."""
+    g = torch.Generator().manual_seed(3)
+    rows, d, n, nh = 61, 64, 300, 2                      # few buckets: plenty of collisions
+    table0 = torch.randn(rows, d, generator=g)
+    idx = torch.randint(0, 500, (n,), generator=g)
+    tower = mf.models.HashEmbeddingTower(rows, d, num_hashes=nh, seed=5, device=DEV)
+    with torch.no_grad():
+        tower.weight.copy_(table0.to(DEV))
+    optim = (mf.optim.SparseSGD(tower.parameters(), lr=0.1) if opt == "sgd" else mf.optim.RowAdam(tower.parameters(), lr=0.05))
+    ref = table0.clone()
+    m, v = torch.zeros_like(ref), torch.zeros_like(ref)
+    b = oembed.hash_buckets(idx, nh, 5, rows)
+    for step in (1, 2):
+        gout = torch.randn(n, d, generator=g)
+        tower(idx.to(DEV)).backward(gout.to(DEV))
+        optim.step()
+        optim.zero_grad()
+        raw = ref[b[:, 0]] + ref[b[:, 1]]
+        graw = oembed.normalize_backward(raw, gout)
+        ids, grads = b.reshape(-1), graw.repeat_interleave(nh, dim=0)
+        if opt == "sgd":
+            oembed.sgd_update(ref, ids, grads, 0.1, 0.0)
+        else:
+            oembed.adam_update(ref, m, v, ids, grads, step=step, lr=0.05, weight_decay=0.01)
+        torch.testing.assert_close(tower.weight.detach().cpu(), ref, rtol=5e-5, atol=5e-6)
+
+
+# ------------------------------------------------------------- retrieval metrics (f-1) ---
+@pytest.mark.parametrize("k", [1, 20, 64])
+def test_retrieval_metrics_match_oracle(mf, k):
+    g = torch.Generator().manual_seed(k)
+    q, n_items = 97, 500
+    topk = torch.stack([torch.randperm(n_items, generator=g)[:k] for _ in range(q)])
+    topk[3, k // 2:] = -1                                     # a query with fewer than k results
+    targets, off, ids, rel = [], [0], [], []
+    for r in range(q):
+        m = int(torch.randint(0, 40, (1,), generator=g)) if r != 5 else 0
+        own = torch.randperm(n_items, generator=g)[:m].tolist()
+        if m and r % 2 == 0:                                  # make sure some targets are retrieved
+            own[: min(m, 3)] = topk[r, : min(m, 3)].tolist()
+        own = [i for i in dict.fromkeys(own) if i >= 0]
+        rat = torch.randint(0, 6, (len(own),), generator=g).tolist()   # rating 0: listed but not relevant
+        targets.append(dict(zip(own, map(float, rat))))
+        ids += own
+        rel += rat
+        off.append(len(ids))
+    metric = mf.retrieval.RetrievalMetrics(top_k=k, prefix="val/")
+    got = metric.update(topk.to(DEV), torch.tensor(off, device=DEV), torch.tensor(ids, dtype=torch.int64, device=DEV),
+                        torch.tensor(rel, dtype=torch.float32, device=DEV)).cpu().numpy()
+    want = oretr.retrieval_metrics(topk.numpy(), targets, k)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    agg = metric.compute()
+    assert set(agg) == {"val/" + n for n in oretr.METRIC_NAMES}
+    np.testing.assert_allclose(float(agg["val/RetrievalNormalizedDCG"]), want[:, 0].mean(), rtol=1e-5)

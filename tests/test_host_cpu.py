@@ -6,6 +6,7 @@ import pathlib
 import re
 
 import pytest
+import numpy as np
 import torch
 
 ROOT = pathlib.Path(__file__).resolve().parents[1]
@@ -97,3 +98,27 @@ def test_collate_and_synthetic_batches(mf):
     syn = mf.data.SyntheticInteractions(100, 50, max_positives=8, seed=1).batch(16)
     assert syn["user"]["pos_idx"].shape == (16, 8) and (syn["user"]["pos_idx"][:, 0] == syn["item"]["idx"]).all()
     assert int(syn["item"]["idx"].min()) >= 1 and int(syn["neg_item"]["idx"].max()) < 50
+
+
+def test_hash_bucket_known_answer_and_range():
+    """The hash of the bloom towers is pinned by SplitMix64's published first output (state 0)."""
+    from oracle import embed as oembed
+
+    assert int(oembed.hash_buckets(torch.tensor([0]), 1, 0, 1 << 62)[0, 0]) == 0xE220A8397B1DCDAF % (1 << 62)
+    ids = torch.tensor([0, 1, 2, 62_423, 10**12, -5])
+    b = oembed.hash_buckets(ids, 3, 7, 1000)
+    assert b.shape == (6, 3) and int(b.min()) >= 0 and int(b.max()) < 1000
+    assert len({tuple(r) for r in b.tolist()}) == 6          # distinct ids -> distinct bucket triples here
+    assert torch.equal(b, oembed.hash_buckets(ids, 3, 7, 1000))
+
+
+def test_oracle_retrieval_metrics_hand_example():
+    """k = 4, retrieved [7, 3, 9, 5]; targets {3: 5, 5: 2, 8: 4} (8 was missed)."""
+    from oracle import retrieval as oretr
+
+    m = oretr.retrieval_metrics(np.array([[7, 3, 9, 5]]), [{3: 5.0, 5: 2.0, 8: 4.0}], 4)[0]
+    dcg = 5 / np.log2(3) + 2 / np.log2(5)
+    idcg = 5 / np.log2(2) + 4 / np.log2(3) + 2 / np.log2(4)
+    want = [dcg / idcg, 2 / 3, 2 / 4, (1 / 2 + 2 / 4) / 2, 1.0, 1 / 2]
+    assert np.allclose(m, want)
+    assert not oretr.retrieval_metrics(np.array([[1, 2, 3, 4]]), [{}], 4).any()          # no target: all 0
