@@ -197,6 +197,18 @@ int mf_topk_merge(const float* part_scores, const int64_t* part_idx, int G, int6
 int mf_retrieval_metrics(const int64_t* topk_idx, int64_t Q, int k, const int64_t* tgt_off,
                          const int64_t* tgt_idx, const float* tgt_rel, float* out, mf_stream_t stream);
 
+/* The batch producer on the device (replaces the host datapipe of
+ * xfmr_rec/data/lightning.py:311-363 + data/load.py:38-141 for id-only towers).  The interaction list
+ * pair_*[n_pairs] and the users' positive lists (CSR pos_off[num_users + 1], pos_items) stay in HBM;
+ * examples start .. start + B - 1 of the reshuffled-every-epoch stream are written as one batch:
+ * out_user[B], out_item[2 B] (the pairs' items, then B uniform negatives in 1 .. num_items - 1),
+ * out_target[B], out_pos[B, P] (the user's positives, truncated to P, 0-padded on the right).
+ * Counter-based: a batch depends on (seed, start) only (mf_data.hip; spec oracle/data.py). */
+int mf_sample_batch(const int64_t* pair_user, const int64_t* pair_item, const float* pair_target, int64_t n_pairs,
+                    const int64_t* pos_off, const int64_t* pos_items, int64_t num_items, uint64_t seed,
+                    int64_t start, int64_t B, int P, int64_t* out_user, int64_t* out_item, float* out_target,
+                    int64_t* out_pos, mf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,8 @@ SIGNATURES = {
                                c_f32, c_f32, c_f32, c_vp, c_sz, c_vp]),
     "mf_topk_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int]),
     "mf_topk": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "mf_sample_batch": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.c_uint64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp,
+                                c_vp, c_vp]),
     "mf_retrieval_metrics": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mf_topk_merge": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
 }

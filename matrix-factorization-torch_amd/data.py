@@ -108,6 +108,56 @@ class SyntheticInteractions:
             yield self.batch()
 
 
+class DeviceInteractionSampler:
+    """The training batches, produced on the GPU from HBM-resident interactions (``mf_sample_batch``):
+    the counterpart of ``InteractionProcessor.get_batch_data`` (xfmr_rec/data/lightning.py:311-363) for
+    id-only towers.  ``pair_user / pair_item / pair_target``: one entry per rating; the positive list
+    of user u is ``pos_items[pos_off[u] : pos_off[u + 1]]`` (``UserProcessor.process``, :274-280).
+    ``batch(step)`` is example positions ``step * batch_size ...`` of a stream that is reshuffled
+    every epoch; the same (seed, step) always gives the same batch."""
+
+    def __init__(self, pair_user, pair_item, pair_target, pos_off, pos_items, *, num_items: int,
+                 batch_size: int = BATCH_SIZE, pos_pad: int = 64, seed: int = 0, device="cuda") -> None:
+        from . import _lib
+
+        self._lib = _lib
+        i64 = lambda t: torch.as_tensor(t, dtype=torch.int64).to(device).contiguous()  # noqa: E731
+        self.pair_user, self.pair_item = i64(pair_user), i64(pair_item)
+        self.pair_target = torch.as_tensor(pair_target, dtype=torch.float32).to(device).contiguous()
+        self.pos_off, self.pos_items = i64(pos_off), i64(pos_items)
+        if self.pos_items.numel() == 0:
+            self.pos_items = torch.zeros(1, dtype=torch.int64, device=device)
+        self.num_items, self.batch_size, self.pos_pad, self.seed = int(num_items), int(batch_size), int(pos_pad), int(seed)
+        n = self.pair_user.numel()
+        if not (self.pair_item.numel() == n == self.pair_target.numel()) or n == 0:
+            msg = "pair_user, pair_item and pair_target must have the same, non-zero length"
+            raise ValueError(msg)
+
+    @property
+    def steps_per_epoch(self) -> int:
+        return -(-self.pair_user.numel() // self.batch_size)
+
+    def batch(self, step: int) -> InteractionBatchType:
+        b, p, dev = self.batch_size, self.pos_pad, self.pair_user.device
+        user = torch.empty(b, dtype=torch.int64, device=dev)
+        item = torch.empty(2 * b, dtype=torch.int64, device=dev)
+        target = torch.empty(b, dtype=torch.float32, device=dev)
+        pos = torch.empty(b, p, dtype=torch.int64, device=dev)
+        lib = self._lib
+        lib.check(lib.lib().mf_sample_batch(self.pair_user.data_ptr(), self.pair_item.data_ptr(), self.pair_target.data_ptr(),
+                                            self.pair_user.numel(), self.pos_off.data_ptr(), self.pos_items.data_ptr(),
+                                            self.num_items, self.seed, int(step) * b, b, p, user.data_ptr(), item.data_ptr(),
+                                            target.data_ptr(), pos.data_ptr(), lib.stream_ptr()))
+        return {"target": target, "user": {"idx": user, "pos_idx": pos}, "item": {"idx": item[:b]},
+                "neg_item": {"idx": item[b:]}}
+
+    def __iter__(self) -> Iterator[InteractionBatchType]:
+        step = 0
+        while True:
+            yield self.batch(step)
+            step += 1
+
+
 def to_device(batch, device):
     if isinstance(batch, dict):
         return {k: to_device(v, device) for k, v in batch.items()}

@@ -22,7 +22,7 @@ import torch
 from . import losses as mf_losses
 from . import models, optim
 from .params import TOP_K
-from .retrieval import ItemProcessor
+from .retrieval import RetrievalMetrics, ItemProcessor
 
 try:  # pragma: no cover - Lightning is absent from the build image
     from lightning import LightningModule as _Base
@@ -59,6 +59,7 @@ class MatrixFactorizationLitModule(_Base):
         self.item_processor: ItemProcessor | None = None
         self.history: dict[int, list[int]] = {}      # user_rn -> item ids already consumed (recommend excludes them)
         self.logq: torch.Tensor | None = None         # [num_items] log sampling probability, when use_logq
+        self.metrics: dict[str, RetrievalMetrics] | None = None
 
     # ------------------------------------------------------------------ towers ---
     def forward(self, idx: torch.Tensor, *, tower: str = "user") -> torch.Tensor:
@@ -101,6 +102,39 @@ class MatrixFactorizationLitModule(_Base):
             for fn in self.loss_fns
         }
 
+    # ------------------------------------------------------------------ metrics ---
+    @torch.no_grad()
+    def update_metrics(self, batch, step_name: str = "val") -> dict[str, torch.Tensor]:
+        """Batched counterpart of ``update_metrics`` (xfmr_rec/lightning.py:149-187, one example per
+        call upstream): top-k for all users of the batch with their histories excluded
+        (``predict_step`` -> ``recommend``, :76-95), then the six retrieval metrics on the device.
+        ``batch``: ``user.idx`` [Q]; ``history`` = (offsets [Q+1], item rows) to exclude; ``target`` =
+        (offsets [Q+1], item rows, ratings) -- item rows are the index's ``movie_rn``."""
+        if self.metrics is None:
+            msg = "`metrics` must be initialised first"
+            raise ValueError(msg)
+        if self.item_processor is None or self.item_processor.index is None:
+            msg = "`user_processor` and `item_processor` must be initialised first"
+            raise ValueError(msg)
+        queries = self(batch["user"]["idx"], tower="user")
+        _, rows = self.item_processor.index.search(queries, self.config.top_k, exclude_csr=batch.get("history"))
+        off, ids, rating = batch["target"]
+        metric = self.metrics[step_name]
+        metric.update(rows, off, ids, rating)
+        return metric.compute()
+
+    def validation_step(self, batch, _: int = 0) -> None:
+        self.log_dict(self.update_metrics(batch, step_name="val"))
+
+    def test_step(self, batch, _: int = 0) -> None:
+        self.log_dict(self.update_metrics(batch, step_name="test"))
+
+    @torch.no_grad()
+    def predict_step(self, batch, _: int = 0) -> tuple[torch.Tensor, torch.Tensor]:
+        """``(scores, item rows)`` [Q, top_k] of the batch's users, histories excluded."""
+        queries = self(batch["user"]["idx"], tower="user")
+        return self.item_processor.index.search(queries, self.config.top_k, exclude_csr=batch.get("history"))
+
     def training_step(self, batch, _: int = 0) -> torch.Tensor:
         losses = self.compute_losses(batch, step_name="train")
         self.log_dict(losses)
@@ -120,6 +154,8 @@ class MatrixFactorizationLitModule(_Base):
             self.loss_fns = self.get_loss_fns()
         if self.item_processor is None:
             self.item_processor = ItemProcessor()
+        if self.metrics is None:
+            self.metrics = self.get_metrics()
 
     def get_model(self, device=None) -> torch.nn.ModuleDict:
         return models.init_towers(self.config, device=device)
@@ -139,5 +175,14 @@ class MatrixFactorizationLitModule(_Base):
             [cls(num_negatives=cfg.num_negatives, sigma=cfg.sigma, margin=cfg.margin) for cls in loss_classes]
         )
 
+    def get_metrics(self) -> dict[str, RetrievalMetrics]:
+        """NDCG / Recall / Precision / MAP / HitRate / MRR @top_k for "val" and "test" (lightning.py:289-306)."""
+        return {step: RetrievalMetrics(top_k=self.config.top_k, prefix=f"{step}/") for step in ("val", "test")}
+
     def on_validation_start(self) -> None:
         self.item_processor.get_index(self)
+        self.metrics["val"].reset()
+
+    def on_test_start(self) -> None:
+        self.item_processor.get_index(self)
+        self.metrics["test"].reset()

@@ -59,6 +59,37 @@ def test_training_loop_reduces_loss_and_recommend_excludes_history(mf, opt):
     assert df["score"].is_monotonic_decreasing and float(df["score"].max()) <= 1.0 + 1e-5
 
 
+def test_validation_step_metrics_match_oracle(mf):
+    """validation_step = batched top-k (history excluded) + the six retrieval metrics, all on the device."""
+    from oracle import retrieval as oretr
+
+    m = _module(mf, top_k=10)
+    m.on_validation_start()
+    g = torch.Generator().manual_seed(4)
+    users = torch.arange(1, 41)
+    n_items = m.towers["item"].num_embeddings
+    hist = [torch.randperm(n_items, generator=g)[: int(torch.randint(0, 30, (1,), generator=g))].sort().values for _ in users]
+    tgts = [dict(zip(torch.randperm(n_items, generator=g)[:12].tolist(), torch.randint(1, 6, (12,), generator=g).float().tolist()))
+            for _ in users]
+    with torch.no_grad():                               # plant hits: a user's vector points at some of its targets
+        iw = m.towers["item"].weight
+        for r, t in enumerate(tgts):
+            m.towers["user"].weight[users[r]] = iw[list(t)[:3]].sum(dim=0)
+    csr = lambda lists: (torch.tensor([0] + list(np.cumsum([len(x) for x in lists])), device=DEV),  # noqa: E731
+                         torch.cat([torch.as_tensor(list(x), dtype=torch.int64) for x in lists]).to(DEV))
+    t_off, t_ids = csr([list(t) for t in tgts])
+    t_rel = torch.tensor([v for t in tgts for v in t.values()], device=DEV)
+    batch = {"user": {"idx": users.to(DEV)}, "history": csr(hist), "target": (t_off, t_ids, t_rel)}
+    m.validation_step(batch, 0)
+    got = m.metrics["val"].compute()
+    _, rows = m.predict_step(batch, 0)
+    assert not any(set(rows[r].tolist()) & set(hist[r].tolist()) for r in range(len(users)))
+    want = oretr.retrieval_metrics(rows.cpu().numpy(), tgts, 10).mean(axis=0)
+    assert list(got) == ["val/" + n for n in oretr.METRIC_NAMES]
+    np.testing.assert_allclose([float(v) for v in got.values()], want, rtol=1e-5, atol=1e-6)
+    assert float(got["val/RetrievalHitRate"]) > 0.5      # the planted targets are found
+
+
 def _torch_infonce(u, v, target, item_idx, pos_idx, logq):
     """Plain torch fp32 reference on the GPU for full-size checks (dense, no mining)."""
     b = u.shape[0]

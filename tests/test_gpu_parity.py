@@ -443,3 +443,38 @@ def test_retrieval_metrics_match_oracle(mf, k):
     agg = metric.compute()
     assert set(agg) == {"val/" + n for n in oretr.METRIC_NAMES}
     np.testing.assert_allclose(float(agg["val/RetrievalNormalizedDCG"]), want[:, 0].mean(), rtol=1e-5)
+
+
+# ------------------------------------------------------------- batch producer (f-2) ---
+def test_device_batch_producer_matches_oracle_and_feeds_the_module(mf):
+    from oracle import data as odata
+
+    g = torch.Generator().manual_seed(12)
+    n_users, n_items, n_pairs = 200, 300, 1500
+    pu = torch.randint(1, n_users, (n_pairs,), generator=g)
+    pi = torch.randint(1, n_items, (n_pairs,), generator=g)
+    pt = torch.randint(1, 6, (n_pairs,), generator=g).float()
+    lists = [sorted(set(pi[pu == u].tolist())) for u in range(n_users)]       # a user's positives = its rated items
+    off = torch.tensor([0] + list(np.cumsum([len(x) for x in lists])))
+    items = torch.tensor([i for x in lists for i in x], dtype=torch.int64)
+    sampler = mf.data.DeviceInteractionSampler(pu, pi, pt, off, items, num_items=n_items, batch_size=64, pos_pad=10, seed=77,
+                                               device=DEV)
+    seen = []
+    for step in (0, 5, 23, 24):                              # 23 -> 24 crosses the epoch boundary (1500 / 64 = 23.4)
+        b = sampler.batch(step)
+        u, it, t, pos = odata.sample_batch(pu.tolist(), pi.tolist(), pt.tolist(), off.tolist(), items.tolist(), n_items, 77,
+                                           step * 64, 64, 10)
+        assert torch.equal(b["user"]["idx"].cpu(), u)
+        assert torch.equal(torch.cat([b["item"]["idx"], b["neg_item"]["idx"]]).cpu(), it)
+        assert torch.equal(b["target"].cpu(), t) and torch.equal(b["user"]["pos_idx"].cpu(), pos)
+        assert int(b["neg_item"]["idx"].min()) >= 1 and int(b["neg_item"]["idx"].max()) < n_items
+        seen.append(b)
+    assert torch.equal(sampler.batch(5)["user"]["idx"], seen[1]["user"]["idx"])          # a function of (seed, step)
+    # one epoch visits every interaction exactly once
+    epoch = torch.cat([sampler.batch(s)["item"]["idx"] for s in range(24)])[:n_pairs].cpu()
+    assert torch.equal(torch.sort(epoch).values, torch.sort(pi).values)
+    # and the batch goes straight into the training step
+    m = mf.lightning.MatrixFactorizationLitModule({"num_users": n_users, "num_items": n_items, "hidden_size": 32})
+    m.configure_model(device=DEV)
+    loss = m.training_step(seen[0], 0)
+    assert torch.isfinite(loss)

@@ -122,3 +122,12 @@ def test_oracle_retrieval_metrics_hand_example():
     want = [dcg / idcg, 2 / 3, 2 / 4, (1 / 2 + 2 / 4) / 2, 1.0, 1 / 2]
     assert np.allclose(m, want)
     assert not oretr.retrieval_metrics(np.array([[1, 2, 3, 4]]), [{}], 4).any()          # no target: all 0
+
+
+def test_oracle_epoch_permutation_is_a_bijection():
+    from oracle import data as odata
+
+    for n in (1, 2, 7, 100, 1000):
+        for epoch in (0, 1):
+            assert sorted(odata.feistel_perm(x, n, epoch, 9) for x in range(n)) == list(range(n))
+    assert [odata.feistel_perm(x, 100, 0, 9) for x in range(100)] != [odata.feistel_perm(x, 100, 1, 9) for x in range(100)]
