@@ -208,11 +208,15 @@ def main() -> None:
             b["user"] = trainer.user_lo + b["user"] % span_u
     else:
         trainer = Trainer(mf, device, args.optimizer, args.num_negatives)
+    if dist_on:      # the sharded step prefetches the exchange plan of the batch after it (ids are known ahead)
+        run_step = lambda j: trainer.step(batches[j % n_batches], next_b=batches[(j + 1) % n_batches])  # noqa: E731
+    else:
+        run_step = lambda j: trainer.step(batches[j % n_batches])  # noqa: E731
     for i in range(W):
-        trainer.step(batches[i % n_batches])
+        run_step(i)
     lib.mf_timing_reset()
     lib.mf_timing_enable(TIME_EVERY)
-    dt_train = timed(lambda i: trainer.step(batches[(W + i) % n_batches]), K, dist_on)
+    dt_train = timed(lambda i: run_step(W + i), K, dist_on)
     lib.mf_timing_enable(0)
     pairs_per_s = world * B * K / dt_train
     N = 2 * B

@@ -60,6 +60,11 @@ struct LossWs {
     size_t total;
 };
 
+#ifndef FWD_MIN_WG
+#define FWD_MIN_WG 2           // workgroups per CU the forward kernel is compiled for ...
+#define FWD_TARGET_WGS 512     // ... and the grid size that fills them
+#endif
+
 static void split_geometry(int x_tiles, int y_tiles, int* nsplit, int* tps, int target_blocks) {
     int want = (target_blocks + x_tiles - 1) / x_tiles;
     if (want < 1) want = 1;
@@ -76,7 +81,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.Bp = (B + 127) / 128 * 128; w.Np = (N + 127) / 128 * 128;   // 4 waves x 32 rows per workgroup
     w.BT = (int)(w.Bp / 32); w.NT = (int)(w.Np / 32);
     w.mined = mining_on(num_negatives, N);
-    split_geometry(w.BT / 4, w.NT, &w.nsplit_f, &w.tps_f, 512);
+    split_geometry(w.BT / 4, w.NT, &w.nsplit_f, &w.tps_f, FWD_TARGET_WGS);
     split_geometry(w.BT / 4, w.NT, &w.nsplit_u, &w.tps_u, 512);
     split_geometry(w.NT / 4, w.BT, &w.nsplit_v, &w.tps_v, 512);
     const int k = num_negatives;
@@ -418,7 +423,7 @@ __device__ __forceinline__ void stats_add_masked(RowStats& s, float Lm, float sm
 }
 
 template <int D, int NEED>
-__global__ __launch_bounds__(256) void loss_fwd_dense_kernel(FwdParams p) {
+__global__ __launch_bounds__(256, FWD_MIN_WG) void loss_fwd_dense_kernel(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = TileGeom<D>;
     using L = FwdLds<D>;

@@ -82,9 +82,10 @@ __device__ __forceinline__ void mf_stage_small(char* lds_dst, const void* src, i
         __builtin_amdgcn_global_load_lds((mf_glb_ptr)(reinterpret_cast<const char*>(src) + lane * 16),
                                          (mf_lds_ptr)lds_dst, 16, 0, CPOL);
 }
-// fire-and-forget device-scope max (no return value, so no wait is ever attached to it)
+// fire-and-forget device-scope max (no return value, so no wait is ever attached to it); sc1: performed
+// past the XCD's own L2, so that workgroups on the other XCDs see it (the L2s are not coherent)
 __device__ __forceinline__ void mf_global_umax(unsigned* p, unsigned v) {
-    asm volatile("global_atomic_umax %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_atomic_umax %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
 // LDS stores that must not drain the DMA queue: while a global_load_lds is in flight, hipcc puts

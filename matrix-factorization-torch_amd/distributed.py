@@ -151,18 +151,58 @@ class ShardedTrainer:
         local = (rows - self.user_lo) % max(self.user_table.shape[0], 1)
         return self.ops.gather(self.user_table, local, True)
 
+    # -- exchange plans ------------------------------------------------------------------------
+    def _plan(self, item_ids: torch.Tensor) -> RowExchange:
+        """The routing plan of a batch's item ids.  Building one costs a host sync (the split sizes);
+        ``prefetch`` moves that sync off the critical path."""
+        hit = self._plans.pop(item_ids.data_ptr(), None) if hasattr(self, "_plans") else None
+        if hit is None:
+            return RowExchange(item_ids, self.num_items)
+        ex, ready = hit
+        if ready is not None:                      # built on the side stream: order it before our use
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ready)
+            for t in (ex.order, ex.local_ids):
+                t.record_stream(cur)
+        return ex
+
+    def prefetch(self, next_b) -> None:
+        """Build the plan of the NEXT batch now, on a side stream: its small kernels, its two tiny
+        all-to-alls and the host read of the split sizes run beside the current step's MFMA sweeps
+        instead of stalling the start of the next step (ids of the next batch are known: prefetching
+        loader).  Every rank must call it at the same point of its step (collective order)."""
+        if not hasattr(self, "_plans"):
+            self._plans, self._plan_stream = {}, None
+        ids = next_b["item"]
+        if ids.data_ptr() in self._plans:
+            return
+        if not ids.is_cuda:
+            self._plans[ids.data_ptr()] = (RowExchange(ids, self.num_items), None)
+            return
+        if self._plan_stream is None:
+            # high priority: its own hardware queue, so the small plan kernels are dispatched beside the sweeps
+            self._plan_stream = torch.cuda.Stream(device=ids.device, priority=-1)
+        with torch.cuda.stream(self._plan_stream):
+            ex = RowExchange(ids, self.num_items)
+            ready = torch.cuda.Event()
+            ready.record(self._plan_stream)
+        self._plans[ids.data_ptr()] = (ex, ready)
+
     # -- one step -----------------------------------------------------------------------------
-    def step(self, b) -> torch.Tensor:
+    def step(self, b, next_b=None) -> torch.Tensor:
         """``b``: ``user`` (global rows inside this rank's user shard), ``item`` (2B global rows:
-        positives then negatives), ``target``, ``pos``."""
+        positives then negatives), ``target``, ``pos``.  ``next_b``: the batch after it, if known
+        (its exchange plan is then prefetched behind this step's compute)."""
         self.steps += 1
         user_local = b["user"] - self.user_lo
-        ex = RowExchange(b["item"], self.num_items)
+        ex = self._plan(b["item"])
         v = ex.fetch(self.ops.gather(self.item_table, ex.local_ids, True))
         u = self.ops.gather(self.user_table, user_local, True)
         logq = self.logq[b["item"]] if self.logq is not None else None
         loss, du, dv = self.ops.loss_and_grads(self.kind, u, v, b["target"], b["item"], b["pos"], logq,
                                                self.num_negatives, 1.0, 1.0)
+        if next_b is not None:
+            self.prefetch(next_b)                 # the GPU is busy with the sweeps just queued
         dv_owned = ex.push(dv)
         jobs = [lambda: self.ops.update(self.optimizer, self.item_table, self.state["item"], ex.local_ids, dv_owned, True,
                                         self.steps, self.lr),
@@ -195,7 +235,10 @@ class ShardedIndex:
         all_q = torch.empty(world * q, d, dtype=queries.dtype, device=queries.device)
         dist.all_gather_into_tensor(all_q, queries.contiguous())
         csr = None
-        if exclude_csr is not None:
+        key = None if exclude_csr is None else (exclude_csr[0].data_ptr(), exclude_csr[1].data_ptr(), exclude_csr[1].numel(), q)
+        if key is not None and getattr(self, "_csr_key", None) == key:
+            csr = self._csr_all                       # same exclusion lists as the last call: gathered once
+        elif exclude_csr is not None:
             off, ids = exclude_csr
             n_loc = torch.tensor([ids.numel()], dtype=torch.int64, device=queries.device)
             n_all = [torch.empty_like(n_loc) for _ in range(world)]
@@ -214,6 +257,7 @@ class ShardedIndex:
                 offs.append(all_off[r * (q + 1) + 1: (r + 1) * (q + 1)] + base)
                 base += n_all[r]
             csr = (torch.cat(offs), torch.cat(pieces) if base else torch.zeros(1, dtype=torch.int64, device=queries.device))
+            self._csr_key, self._csr_all, self._csr_src = key, csr, exclude_csr   # (keeps the source tensors alive)
         ps, pi = self.ops.topk(all_q, self.items, top_k, csr, self.idx_base)     # [world * q, k]
         rs = torch.empty_like(ps)
         ri = torch.empty_like(pi)

@@ -95,7 +95,11 @@ def _train_case(rank: int, world: int, out_dir: str) -> None:
     for opt in ("sgd", "adam"):
         tr = mfd.ShardedTrainer(mf, "cpu", opt, 0, num_users=N_USERS, num_items=N_ITEMS, dim=DIM, ops=OracleOps(), lr=0.05,
                                 kind="PairwiseLogisticLoss")
-        loss = tr.step(_batch(rank, world, mfd))
+        b = _batch(rank, world, mfd)
+        tr.prefetch(b)                                   # the plan built ahead of time is the one the step uses
+        assert b["item"].data_ptr() in tr._plans
+        loss = tr.step(b, next_b=b)
+        assert list(tr._plans) == [b["item"].data_ptr()]  # consumed, and the next one prefetched
         torch.save({"user": tr.user_table, "item": tr.item_table, "loss": loss}, f"{out_dir}/{opt}_{rank}.pt")
 
 
