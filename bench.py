@@ -247,7 +247,7 @@ def main() -> None:
         offs.append(offs[-1] + pieces[-1].numel())
     csr = (torch.tensor(offs, dtype=torch.int64, device=device), torch.cat(pieces).to(device))
     if dist_on:
-        searcher = mf.distributed.ShardedIndex(trainer.item_shard(), trainer.item_shard_base(), NUM_ITEMS)
+        searcher = mf.distributed.ShardedIndex(trainer.item_shard(), trainer.item_offset(), NUM_ITEMS, stride=trainer.item_stride())
         run_topk = lambda i: searcher.search(queries, TOP_K, exclude_csr=csr)   # noqa: E731
     else:
         index = mf.retrieval.ItemIndex(items)

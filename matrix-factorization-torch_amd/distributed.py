@@ -4,9 +4,11 @@ over xGMI on ROCm; ``gloo`` in the CPU tests).
 The reference has no explicit collective anywhere (implicit DDP of a
 dense BERT); the sharding below is the north-star's and our design:
 
-* **item table row-sharded** in contiguous blocks (rank r owns rows
-  ``[r * rows_per, (r + 1) * rows_per)``); **user table sharded the same way** and the
-  training pairs partitioned by user shard, so user rows never travel;
+* **item table row-sharded, rows dealt round-robin** (rank r owns rows ``r, r + G, r + 2G, ...``):
+  item popularity is heavy-tailed and id order often follows it, so contiguous blocks would send most
+  of every batch to one owner (its gather, sort and update then set the step time of the whole job);
+  **user table sharded in contiguous blocks** and the training pairs partitioned by user shard, so
+  user rows never travel;
 * **training step**: each rank needs the item rows of its own batch (B positives + B
   sampled negatives).  Rows are fetched from their owners with one all-to-all of ids
   and one all-to-all of rows (8 MB per rank at B = 8192, d = 128 -- latency-bound on
@@ -16,7 +18,7 @@ dense BERT); the sharding below is the north-star's and our design:
   their owners with one more all-to-all and each owner applies ONE sparse update per
   step (duplicates summed in (rank, batch) order: deterministic);
 * **retrieval**: queries are all-gathered, every rank scans ITS shard for all queries
-  (``mf_topk`` with ``idx_base``), the partial top-k travel back to the query's rank by
+  (``mf_topk`` on local rows, mapped to global rows before they leave), the partial top-k travel back to the query's rank by
   all-to-all and are merged exactly (``mf_topk_merge``): bit-identical to the
   single-GPU result.
 
@@ -83,22 +85,27 @@ def _all_to_all_rows(x: torch.Tensor, send_counts: list[int], recv_counts: list[
     return out
 
 
-class RowExchange:
-    """Routes a list of global row ids to their owning ranks and back (contiguous block sharding)."""
+def cyclic_rows(n_rows: int, world: int, rank: int) -> int:
+    """Rows of a table dealt round-robin that land on ``rank``."""
+    return (n_rows - rank + world - 1) // world if n_rows > rank else 0
 
-    def __init__(self, ids: torch.Tensor, n_rows: int) -> None:
+
+class RowExchange:
+    """Routes a list of global row ids to their owning ranks and back (rows dealt round-robin:
+    owner = id mod world, local row = id div world)."""
+
+    def __init__(self, ids: torch.Tensor, n_rows: int) -> None:  # noqa: ARG002
         world = dist.get_world_size()
-        per = (n_rows + world - 1) // world
-        owner = torch.div(ids, per, rounding_mode="floor").clamp_(0, world - 1)
+        owner = torch.remainder(ids, world)
         self.order = torch.argsort(owner, stable=True)              # batch position of every sent slot
         send = torch.bincount(owner, minlength=world)
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send)
         # NCCL/RCCL needs the split sizes on the host: the one host sync of the step
         self.send_counts, self.recv_counts = send.tolist(), recv.tolist()
-        lo = dist.get_rank() * per
         # rows of MY shard that the others (and I) asked for, grouped by requesting rank
-        self.local_ids = _all_to_all_rows(ids[self.order], self.send_counts, self.recv_counts) - lo
+        self.local_ids = torch.div(_all_to_all_rows(ids[self.order], self.send_counts, self.recv_counts), world,
+                                   rounding_mode="floor")
 
     def fetch(self, rows_for_requests: torch.Tensor) -> torch.Tensor:
         """owner -> requester: rows gathered for ``local_ids`` come back in batch order."""
@@ -124,12 +131,11 @@ class ShardedTrainer:
         self.lr = lr if lr is not None else (1e-4 if optimizer == "adam" else 1e-2)
         self.num_users, self.num_items, self.dim = num_users, num_items, dim
         self.user_lo, self.user_hi = shard_bounds(num_users, self.world, self.rank)
-        self.item_lo, self.item_hi = shard_bounds(num_items, self.world, self.rank)
         g = torch.Generator().manual_seed(seed)                     # same full tables on every rank, then sliced
         full_u = torch.randn(num_users, dim, generator=g) / dim**0.5
         full_i = torch.randn(num_items, dim, generator=g) / dim**0.5
         self.user_table = full_u[self.user_lo:self.user_hi].contiguous().to(device)
-        self.item_table = full_i[self.item_lo:self.item_hi].contiguous().to(device)
+        self.item_table = full_i[self.rank::self.world].contiguous().to(device)     # rows rank, rank + world, ...
         self.state = {name: {"m": torch.zeros_like(t), "v": torch.zeros_like(t)}
                       for name, t in (("user", self.user_table), ("item", self.item_table))}
         self.logq = logq
@@ -140,8 +146,12 @@ class ShardedTrainer:
         ids = torch.arange(self.item_table.shape[0], device=self.item_table.device)
         return self.ops.gather(self.item_table, ids, True)
 
-    def item_shard_base(self) -> int:
-        return self.item_lo
+    def item_offset(self) -> int:
+        """Global row of local item row l is ``l * item_stride() + item_offset()``."""
+        return self.rank
+
+    def item_stride(self) -> int:
+        return self.world
 
     def item_matrix(self) -> torch.Tensor:
         return self.item_shard()
@@ -219,18 +229,26 @@ class ShardedTrainer:
 
 
 class ShardedIndex:
-    """Exact top-k over a row-sharded catalog; bit-identical to the single-GPU result."""
+    """Exact top-k over a row-sharded catalog; bit-identical to the single-GPU result.  Local row l of
+    this rank's shard is global item row ``l * stride + offset`` (round-robin rows: stride = world,
+    offset = rank; contiguous blocks: stride = 1, offset = first row)."""
 
-    def __init__(self, item_shard: torch.Tensor, idx_base: int, num_items: int, ops=None, mf=None) -> None:
-        self.items, self.idx_base, self.num_items = item_shard, int(idx_base), num_items
+    def __init__(self, item_shard: torch.Tensor, offset: int, num_items: int, *, stride: int = 1, ops=None, mf=None) -> None:
+        self.items, self.offset, self.stride, self.num_items = item_shard, int(offset), int(stride), num_items
         if ops is None:
             import importlib
 
             ops = HipOps(mf if mf is not None else importlib.import_module(__package__))
         self.ops = ops
 
+    def _localise(self, ids: torch.Tensor) -> torch.Tensor:
+        """Global item rows -> rows of this shard (-1: not ours, ignored by the scan)."""
+        d = ids - self.offset
+        ours = (d >= 0) & (torch.remainder(d, self.stride) == 0)
+        return torch.where(ours, torch.div(d, self.stride, rounding_mode="floor"), torch.full_like(d, -1))
+
     def search(self, queries: torch.Tensor, top_k: int, *, exclude_csr=None):
-        world, rank = dist.get_world_size(), dist.get_rank()
+        world, rank = dist.get_world_size(), dist.get_rank()  # noqa: F841
         q, d = queries.shape
         all_q = torch.empty(world * q, d, dtype=queries.dtype, device=queries.device)
         dist.all_gather_into_tensor(all_q, queries.contiguous())
@@ -256,9 +274,11 @@ class ShardedIndex:
                 pieces.append(all_ids[r * cap: r * cap + n_all[r]])
                 offs.append(all_off[r * (q + 1) + 1: (r + 1) * (q + 1)] + base)
                 base += n_all[r]
-            csr = (torch.cat(offs), torch.cat(pieces) if base else torch.zeros(1, dtype=torch.int64, device=queries.device))
+            ids_all = torch.cat(pieces) if base else torch.zeros(1, dtype=torch.int64, device=queries.device)
+            csr = (torch.cat(offs), self._localise(ids_all) if base else ids_all - 1)
             self._csr_key, self._csr_all, self._csr_src = key, csr, exclude_csr   # (keeps the source tensors alive)
-        ps, pi = self.ops.topk(all_q, self.items, top_k, csr, self.idx_base)     # [world * q, k]
+        ps, pi = self.ops.topk(all_q, self.items, top_k, csr, 0)                 # [world * q, k], local rows
+        pi = torch.where(pi >= 0, pi * self.stride + self.offset, pi)            # -> global rows, before the merge
         rs = torch.empty_like(ps)
         ri = torch.empty_like(pi)
         dist.all_to_all_single(rs, ps.contiguous())                              # block g -> rank g

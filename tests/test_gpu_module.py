@@ -197,12 +197,12 @@ def test_sharded_classes_on_one_rank_use_the_hip_path(mf):
                   pos_idx=batch["pos"])
         want.backward()
         opt.step()
-        got = tr.step(batch)
+        got = tr.step(batch, next_b=batch)       # with the next batch's exchange plan prefetched on the side stream
         assert float(got) == float(want)
         torch.testing.assert_close(tr.item_table, towers["item"].weight.detach(), rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(tr.user_table, towers["user"].weight.detach(), rtol=1e-6, atol=1e-7)
         q = tr.user_vectors(torch.arange(1, 9, device=DEV))
-        s1, i1 = mf.distributed.ShardedIndex(tr.item_shard(), tr.item_shard_base(), ni).search(q, 10)
+        s1, i1 = mf.distributed.ShardedIndex(tr.item_shard(), tr.item_offset(), ni, stride=tr.item_stride()).search(q, 10)
         s2, i2 = mf.retrieval.ItemIndex(tr.item_shard()).search(q, 10)
         assert torch.equal(i1, i2) and torch.equal(s1, s2)
     finally:
