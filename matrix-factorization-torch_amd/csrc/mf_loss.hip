@@ -44,6 +44,7 @@ struct LossWs {
     int nsplit_u, tps_u;          // dU pass: item-range splits
     int nsplit_v, tps_v;          // dV pass: user-range splits
     int T, CAP, nchunk, tpc;      // mining select geometry (nchunk = candidate sets per row)
+    int NW;                       // waves per workgroup of the sweeps (mf_nw(d))
     SelectPlan plan;
     float *nu, *nv, *lii, *dii, *sgn, *logq;
     long long* gtab;
@@ -60,11 +61,6 @@ struct LossWs {
     size_t total;
 };
 
-#ifndef FWD_MIN_WG
-#define FWD_MIN_WG 2           // workgroups per CU the forward kernel is compiled for ...
-#define FWD_TARGET_WGS 512     // ... and the grid size that fills them
-#endif
-
 static void split_geometry(int x_tiles, int y_tiles, int* nsplit, int* tps, int target_blocks) {
     int want = (target_blocks + x_tiles - 1) / x_tiles;
     if (want < 1) want = 1;
@@ -78,12 +74,16 @@ static bool mining_on(int num_negatives, int64_t N) { return num_negatives > 0 &
 static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_negatives) {
     LossWs w{};
     w.B = B; w.N = N; w.d = d;
-    w.Bp = (B + 127) / 128 * 128; w.Np = (N + 127) / 128 * 128;   // 4 waves x 32 rows per workgroup
+    const int XB = 32 * mf_nw(d);                                 // X rows per workgroup of the sweeps
+    w.Bp = (B + XB - 1) / XB * XB; w.Np = (N + XB - 1) / XB * XB;
+    w.NW = mf_nw(d);
     w.BT = (int)(w.Bp / 32); w.NT = (int)(w.Np / 32);
     w.mined = mining_on(num_negatives, N);
-    split_geometry(w.BT / 4, w.NT, &w.nsplit_f, &w.tps_f, FWD_TARGET_WGS);
-    split_geometry(w.BT / 4, w.NT, &w.nsplit_u, &w.tps_u, 512);
-    split_geometry(w.NT / 4, w.BT, &w.nsplit_v, &w.tps_v, 512);
+    // enough workgroups for two waves per SIMD: 256 of eight waves, 512 of four
+    const int wgs = 2048 / w.NW;
+    split_geometry(w.BT / w.NW, w.NT, &w.nsplit_f, &w.tps_f, wgs);
+    split_geometry(w.BT / w.NW, w.NT, &w.nsplit_u, &w.tps_u, wgs);
+    split_geometry(w.NT / w.NW, w.BT, &w.nsplit_v, &w.tps_v, wgs);
     const int k = num_negatives;
     w.plan = mf_select_plan(B, N, d, k);
     w.T = w.plan.T; w.CAP = w.plan.CAP; w.nchunk = w.plan.nsets; w.tpc = w.plan.tpc;
@@ -397,7 +397,8 @@ __device__ __forceinline__ void stats_add(RowStats& s, int need, float L, float 
 template <int D>
 struct FwdLds {
     using G = TileGeom<D>;
-    static constexpr int AUX_NV = 512, AUX_LQ = 640, AUX_PAD = 768, AUXB = 1024;   // [0,512): 4 x 128 B mask words
+    // [0, NW x 128): per-wave mask words; then NW x 128 B staged by the waves: nv (wave 0), logq (wave 1), copies
+    static constexpr int AUX_NV = G::NW * 128, AUX_LQ = AUX_NV + 128, AUXB = 2 * G::NW * 128;
     static constexpr int AUX0 = 3 * G::TILEB;           // 4 side-input slots after the 3 tile slots
     static constexpr int BYTES = AUX0 + 4 * AUXB;
     static constexpr int NDMA = G::PPW + 2;             // DMA instructions per wave per stage (+ 4 stash stores per tile)
@@ -423,7 +424,7 @@ __device__ __forceinline__ void stats_add_masked(RowStats& s, float Lm, float sm
 }
 
 template <int D, int NEED>
-__global__ __launch_bounds__(256, FWD_MIN_WG) void loss_fwd_dense_kernel(FwdParams p) {
+__global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void loss_fwd_dense_kernel(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = TileGeom<D>;
     using L = FwdLds<D>;
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256, FWD_MIN_WG) void loss_fwd_dense_kernel(FwdPara
     const int wave = mf_wave_id();
     // grid = (item-range split, user block): consecutive workgroup ids -- dealt round-robin to the 8 XCDs --
     // differ in the SPLIT, so the workgroups of one XCD stream the same 1/nsplit of V through its L2
-    const int64_t i0 = (int64_t)blockIdx.y * 128;
+    const int64_t i0 = (int64_t)blockIdx.y * G::XB;
     const int64_t i = i0 + wave * 32 + c;
     const int t0 = blockIdx.x * p.tps, t1 = min(p.NT, t0 + p.tps);
     RowFrag<D> xf;
@@ -535,7 +536,7 @@ static void launch_fwd_n(dim3 grid, const FwdParams& fp, hipStream_t s) {
     auto fn = loss_fwd_dense_kernel<D, NEED>;
     if (FwdLds<D>::BYTES > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, FwdLds<D>::BYTES);
-    fn<<<grid, 256, FwdLds<D>::BYTES, s>>>(fp);
+    fn<<<grid, 64 * mf_nw(D), FwdLds<D>::BYTES, s>>>(fp);
 }
 template <int D>
 static void launch_fwd(int need, dim3 grid, const FwdParams& fp, hipStream_t s) {
@@ -664,21 +665,21 @@ struct MiningPolicy {
     };
     static constexpr int AUX_DMA = 2;
     static constexpr bool PREFILTER = false;     // the mining rank is not monotone in the raw dot product
-    static __device__ __forceinline__ void stage_aux(const Params& p, char* aux, int wave, int t, int64_t x0) {
+    static __device__ __forceinline__ void stage_aux(const Params& p, char* aux, int wave, int t, int64_t x0, int W0) {
         mf_stage_small(aux + wave * 128, p.maskW + (int64_t)t * p.Bp + x0, 128);
         const float* src = (wave == 1 && p.logq) ? p.logq : p.nv;
-        mf_stage_small(aux + 512 + wave * 128, src + (int64_t)t * 32, 128);   // 512: nv, 640: logq, rest: padding
+        mf_stage_small(aux + W0 + wave * 128, src + (int64_t)t * 32, 128);    // W0: nv, W0 + 128: logq, rest: copies
     }
     static __device__ __forceinline__ Row row_init(const Params& p, int64_t x, bool) {
         return Row{p.nu[x], p.sgn[x], p.lii[x]};
     }
-    static __device__ __forceinline__ Tile tile_init(const Params& p, const Row&, const char* aux, int wave, int c, int h) {
+    static __device__ __forceinline__ Tile tile_init(const Params& p, const Row&, const char* aux, int wave, int c, int h, int W0) {
         Tile t;
         t.mw = reinterpret_cast<const uint32_t*>(aux + wave * 128)[c];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            t.nv4[q] = *reinterpret_cast<const f32x4*>(aux + 512 + (8 * q + 4 * h) * 4);
-            t.lq4[q] = p.logq ? *reinterpret_cast<const f32x4*>(aux + 640 + (8 * q + 4 * h) * 4)
+            t.nv4[q] = *reinterpret_cast<const f32x4*>(aux + W0 + (8 * q + 4 * h) * 4);
+            t.lq4[q] = p.logq ? *reinterpret_cast<const f32x4*>(aux + W0 + 128 + (8 * q + 4 * h) * 4)
                               : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         return t;
@@ -818,12 +819,12 @@ struct BwdParams {
 template <int D, bool XU>
 struct BwdLds {
     using G = TileGeom<D>;
-    static constexpr int LT = G::TILEB;                  // 4 x 4 KiB stash blocks (one per wave)
-    static constexpr int SLOT = G::TILEB + 4 * 4096;
-    static constexpr int EXTRA = XU ? 0 : 4 * 32 * 32 * 4;   // dV: per-wave 32 x 32 transpose scratch (XOR-swizzled)
-    // the deepest ring that still lets TWO workgroups share a CU's 160 KiB (a second wave per SIMD hides
-    // the first one's barrier and VALU phases); 2 slots cost a second barrier per tile, measured free
-    static constexpr int NSLOT = (2 * (3 * SLOT + EXTRA) <= 160 * 1024) ? 3 : 2;
+    static constexpr int LT = G::TILEB;                  // NW x 4 KiB stash blocks (one per wave) behind the tile
+    static constexpr int SLOT = G::TILEB + G::NW * 4096;
+    static constexpr int EXTRA = XU ? 0 : G::NW * 32 * 32 * 4;   // dV: per-wave 32 x 32 transpose scratch (XOR-swizzled)
+    // the deepest ring that still puts two waves on every SIMD (two 4-wave workgroups per CU, or one of
+    // eight waves); 2 slots cost a second barrier per tile, measured free
+    static constexpr int NSLOT = ((G::NW == 8 ? 1 : 2) * (3 * SLOT + EXTRA) <= 160 * 1024) ? 3 : 2;
     static constexpr int TR = NSLOT * SLOT;
     static constexpr int BYTES = TR + EXTRA;
     static constexpr int NDMA = G::PPW + 4;              // DMA instructions per wave per stage
@@ -832,12 +833,12 @@ struct BwdLds {
 // XU = true : lanes hold users, item tiles stream, result d loss / d u   (reads L, writes G' back)
 // XU = false: lanes hold items, user tiles stream, result d loss / d v   (reads G')
 template <int D, bool XU, int GMODE>
-__global__ __launch_bounds__(256) void loss_bwd_dense_kernel(BwdParams p) {
+__global__ __launch_bounds__(64 * mf_nw(D)) void loss_bwd_dense_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using L = BwdLds<D, XU>;
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int wave = mf_wave_id();
-    const int64_t x0 = (int64_t)blockIdx.y * 128 + wave * 32;     // this wave's X tile (grid = (Y split, X block))
+    const int64_t x0 = (int64_t)blockIdx.y * TileGeom<D>::XB + wave * 32;     // this wave's X tile (grid = (Y split, X block))
     const int64_t x = x0 + c;
     const int xt = (int)(x0 >> 5);
     const int64_t nX = XU ? p.B : p.N, nY = XU ? p.N : p.B;
@@ -1034,7 +1035,7 @@ static void launch_bwd_g(dim3 grid, const BwdParams& bp, hipStream_t s) {
     auto fn = loss_bwd_dense_kernel<D, XU, GMODE>;
     if (BwdLds<D, XU>::BYTES > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, BwdLds<D, XU>::BYTES);
-    fn<<<grid, 256, BwdLds<D, XU>::BYTES, s>>>(bp);
+    fn<<<grid, 64 * mf_nw(D), BwdLds<D, XU>::BYTES, s>>>(bp);
 }
 template <int D, bool XU>
 static void launch_bwd(int gmode, dim3 grid, const BwdParams& bp, hipStream_t s) {
@@ -1092,7 +1093,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     if (scores_needed && !w.mined) {
         FwdParams fp{u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.part, w.stash, B, N, w.Bp, w.NT, w.tps_f, need, sigma, margin};
         MF_DISPATCH_D(d, {
-            dim3 grid((unsigned)w.nsplit_f, (unsigned)(w.BT / 4));
+            dim3 grid((unsigned)w.nsplit_f, (unsigned)(w.BT / w.NW));
             MF_TIMED("loss_fwd_dense", s, (launch_fwd<D>(need, grid, fp, s)));
         });
         merge_splits = w.nsplit_f;
@@ -1149,10 +1150,10 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
         BwdParams bp{u, v, w.rowc, w.stash, w.gstash, w.dpart, B, N, w.Bp, w.Np, w.NT, 0, 0};
         MF_DISPATCH_D(d, {
             bp.YT = w.NT; bp.tps = w.tps_u;
-            MF_TIMED("loss_bwd_du", s, (launch_bwd<D, true>(gmode, dim3((unsigned)w.nsplit_u, (unsigned)(w.BT / 4)), bp, s)));
+            MF_TIMED("loss_bwd_du", s, (launch_bwd<D, true>(gmode, dim3((unsigned)w.nsplit_u, (unsigned)(w.BT / w.NW)), bp, s)));
             sum_parts_kernel<<<dim3((unsigned)((B * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_u, B, w.Bp, D, du);
             bp.YT = w.BT; bp.tps = w.tps_v;
-            MF_TIMED("loss_bwd_dv", s, (launch_bwd<D, false>(G_EXP, dim3((unsigned)w.nsplit_v, (unsigned)(w.NT / 4)), bp, s)));
+            MF_TIMED("loss_bwd_dv", s, (launch_bwd<D, false>(G_EXP, dim3((unsigned)w.nsplit_v, (unsigned)(w.NT / w.NW)), bp, s)));
             sum_parts_kernel<<<dim3((unsigned)((N * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_v, N, w.Np, D, dv);
         });
     }

@@ -49,7 +49,7 @@ struct SelectCommon {
     int tiles_per_chunk;
     int64_t Xp;          // nX padded to 128
     int k;
-    int xw;              // X tiles per workgroup (1, 2 or 4); the 4 / xw waves that share an X tile
+    int xw;              // X tiles per workgroup (1, 2, 4 or 8); the NW / xw waves that share an X tile
                          // deal the chunk's Y tiles round-robin and keep separate candidate lists
     unsigned* gtau;      // [Xp], zeroed by the host: best known lower bound (rank) of every X row's k-th best key,
                          // shared by all chunks of the launch (max-published, so always a valid bound)
@@ -98,24 +98,25 @@ __device__ __forceinline__ unsigned long long mf_cand_load(const unsigned long l
 template <int D>
 struct SelectLds {
     using G = TileGeom<D>;
-    static constexpr int AUXB = 1536;                    // [4 x 128 B per-wave words][nv 128][logq 128][pad][4 x 128 B gtau]
-    static constexpr int GT0 = 1024;                     // per-wave copies of gtau[x0 .. x0 + 31]
+    static constexpr int W0 = G::NW * 128;               // [NW x 128 B per-wave words][W0: nv, logq, copies][GT0: NW x 128 B gtau]
+    static constexpr int GT0 = 2 * W0;                   // per-wave copies of gtau[x0 .. x0 + 31]
+    static constexpr int AUXB = 3 * W0;
     static constexpr int NSLOT = D == 256 ? 2 : 3;       // d = 256: 2-deep tile ring, 2 barriers per tile
     static constexpr int AUX0 = NSLOT * G::TILEB;        // 4 side-input slots after the tile slots
     static constexpr int RING = AUX0 + 4 * AUXB;
-    static constexpr int BYTES = RING + 4 * 32 * 8;      // + the exact 64-bit floors of the degenerate path
+    static constexpr int BYTES = RING + G::NW * 32 * 8;  // + the exact 64-bit floors of the degenerate path
 };
 
 // Policy interface:
 //   struct Params;  struct Row;  struct Tile;
 //   static constexpr int AUX_DMA;                   DMA instructions per wave per stage for side inputs
-//   static void stage_aux(P, aux, wave, t, x0)      issue them (side inputs of Y tile t for X rows x0..x0+31)
+//   static void stage_aux(P, aux, wave, t, x0, W0)  issue them (side inputs of Y tile t for X rows x0..x0+31; W0 = NW x 128)
 //   static Row  row_init(P, x, valid)
-//   static Tile tile_init(P, row, aux, wave, c, h)  read the staged side inputs
+//   static Tile tile_init(P, row, aux, wave, c, h, W0)  read the staged side inputs
 //   static bool key(P, row, tile, score, e, h, y, hi&, lo&)   false = never a candidate; (hi, lo) = key halves
 //   static constexpr bool PREFILTER                 true: hi is mf_orderable(score), so `score < bound` may skip key()
 template <int D, int T, class Policy>
-__global__ __launch_bounds__(256, D == 256 ? 1 : 2) void select_kernel(typename Policy::Params pp, SelectCommon sc) {
+__global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_kernel(typename Policy::Params pp, SelectCommon sc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = TileGeom<D>;
     using L = SelectLds<D>;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256, D == 256 ? 1 : 2) void select_kernel(typename 
 
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int wave = mf_wave_id();
-    const int nsub = 4 / sc.xw;
+    const int nsub = G::NW / sc.xw;
     const int sub = wave / sc.xw;
     // grid = (Y chunk, X block): the workgroups of one XCD (ids 8 apart) share chunks -> the catalog
     // slice they stream stays in that XCD's L2
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256, D == 256 ? 1 : 2) void select_kernel(typename 
     auto stage = [&](int t) {
         const int kk = t - t0;
         mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, sc.Y, (int64_t)t * 32, sc.nY);
-        Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t, x0);
+        Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t, x0, L::W0);
         mf_stage_small<17>(smem + L::AUX0 + (kk & 3) * L::AUXB + L::GT0 + wave * 128, sc.gtau + x0, 128);
     };
     auto mine_tile = [&](int t) { return (t - t0) % nsub == sub; };   // else another wave of this X tile takes tile t
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256, D == 256 ? 1 : 2) void select_kernel(typename 
             }
             const char* aux = smem + L::AUX0 + ((ty - t0) & 3) * L::AUXB;
             if (cur) {
-                tile = Policy::tile_init(pp, row, aux, wave, c, h);
+                tile = Policy::tile_init(pp, row, aux, wave, c, h, L::W0);
                 y0 = (unsigned)ty * 32u;
             }
             const bool warm = (ty - t0) < 2 * nsub;   // this wave's first two tiles: the T-lists fill
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256, D == 256 ? 1 : 2) void select_kernel(typename 
 // row are distinct elements, so the k-th largest of them (select_bound_kernel) is a valid lower bound
 // of the row's k-th best key; the main pass then starts from it and accepts only a few keys per row.
 template <int D, int T, class Policy>
-__global__ __launch_bounds__(256, D == 256 ? 1 : 2) void select_seed_kernel(typename Policy::Params pp, SelectCommon sc,
+__global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_seed_kernel(typename Policy::Params pp, SelectCommon sc,
                                                                             unsigned long long* __restrict__ seeds,
                                                                             int seeds_per_row) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256, D == 256 ? 1 : 2) void select_seed_kernel(type
     constexpr int NWAIT = G::PPW + Policy::AUX_DMA;
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int wave = mf_wave_id();
-    const int nsub = 4 / sc.xw;
+    const int nsub = G::NW / sc.xw;
     const int sub = wave / sc.xw;
     const int64_t x0 = ((int64_t)blockIdx.y * sc.xw + (wave % sc.xw)) * 32;
     const int64_t x = x0 + c;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256, D == 256 ? 1 : 2) void select_seed_kernel(type
     auto stage = [&](int t) {
         const int kk = t - t0;
         mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, sc.Y, (int64_t)t * 32, sc.nY);
-        Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t, x0);
+        Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t, x0, L::W0);
     };
     auto mine_tile = [&](int t) { return (t - t0) % nsub == sub; };
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256, D == 256 ? 1 : 2) void select_seed_kernel(type
                 if (L::NSLOT == 3 && ty + 3 < t1) stage(ty + 3);
             }
             if (cur) {
-                tile = Policy::tile_init(pp, row, smem + L::AUX0 + ((ty - t0) & 3) * L::AUXB, wave, c, h);
+                tile = Policy::tile_init(pp, row, smem + L::AUX0 + ((ty - t0) & 3) * L::AUXB, wave, c, h, L::W0);
                 y0 = (unsigned)ty * 32u;
             }
             const char* next_tile = smem + ((ty + 1 - t0) % L::NSLOT) * G::TILEB;
@@ -589,17 +590,18 @@ struct SelectPlan {
 };
 static inline SelectPlan mf_select_plan(int64_t nX, int64_t nY, int d, int k) {
     SelectPlan s{};
-    (void)d;
     s.T = mf_select_T(k);
     s.CAP = 2 * MF_SELECT_CAPH;                               // a row's two lanes
     s.ok = MF_SELECT_CAPH >= s.T + 16 && k <= MF_SELECT_CAPH;
-    s.Xp = (nX + 127) / 128 * 128;
+    const int nw = mf_nw(d);
+    s.Xp = (nX + 32 * nw - 1) / (32 * nw) * (32 * nw);
     const int xt = (int)((nX + 31) / 32);
-    s.xw = xt >= 4 ? 4 : xt >= 2 ? 2 : 1;
-    s.nsub = 4 / s.xw;
+    s.xw = (xt >= 8 && nw == 8) ? 8 : xt >= 4 ? 4 : xt >= 2 ? 2 : 1;
+    s.nsub = nw / s.xw;
     s.gx = (xt + s.xw - 1) / s.xw;
     s.YT = (int)((nY + 31) / 32);
-    int want = (512 + s.gx - 1) / s.gx;                      // ~ two workgroups per CU
+    const int wgs = 2048 / nw;                               // two waves per SIMD: 256 workgroups of eight waves
+    int want = (wgs + s.gx - 1) / s.gx;
     if (want > 128) want = 128;
     // a seeding pass over 1/8 of Y pays when Y is long enough to profit from its bound
     s.YTa = (s.YT >= 64) ? s.YT / 8 : 0;
@@ -624,7 +626,7 @@ static void mf_select_launch_t(const typename Policy::Params& pp, const SelectCo
     auto fn = select_kernel<D, T, Policy>;
     const int bytes = SelectLds<D>::BYTES;
     (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    fn<<<dim3((unsigned)nchunk, (unsigned)gx), 256, bytes, s>>>(pp, sc);
+    fn<<<dim3((unsigned)nchunk, (unsigned)gx), 64 * mf_nw(D), bytes, s>>>(pp, sc);
 }
 template <int D, class Policy>
 static void mf_select_launch(int T, const typename Policy::Params& pp, const SelectCommon& sc, int nchunk, int gx, hipStream_t s) {
@@ -644,7 +646,7 @@ static void mf_select_seed_t(const typename Policy::Params& pp, const SelectComm
     auto fn = select_seed_kernel<D, T, Policy>;
     const int bytes = SelectLds<D>::BYTES;
     (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    fn<<<dim3((unsigned)nchunk, (unsigned)gx), 256, bytes, s>>>(pp, sc, seeds, seeds_per_row);
+    fn<<<dim3((unsigned)nchunk, (unsigned)gx), 64 * mf_nw(D), bytes, s>>>(pp, sc, seeds, seeds_per_row);
 }
 // seeding pass + bound + main pass; `sc` arrives with everything but the tile range filled in, gtau and
 // cand_cnt zeroed; `seeds`: [Xp][plan.seeds_per_row] scratch

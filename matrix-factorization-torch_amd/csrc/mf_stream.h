@@ -1,6 +1,6 @@
 // mf_stream.h -- LDS-staged tile streaming for the score engines (gfx950).
 //
-// A 256-thread workgroup (4 wavefronts, each owning 32 "X" rows in registers) walks
+// A workgroup of 8 wavefronts (4 at d = 256), each owning 32 "X" rows in registers, walks
 // a range of 32-row "Y" tiles.  Every tile is brought from HBM/L2 into LDS ONCE per
 // workgroup by LDS-DMA (global_load_lds_dwordx4: whole 1 KiB pieces, full cache
 // lines, no VGPR staging) into a 3-deep ring, two tiles ahead of the MFMAs, with a
@@ -28,13 +28,29 @@
 typedef __attribute__((address_space(3))) void* mf_lds_ptr;
 typedef const __attribute__((address_space(1))) void* mf_glb_ptr;
 
+#ifndef MF_ABL_DMADIV
+#define MF_ABL_DMADIV 1   // A/B knob (tools/): stage only 1/DMADIV of every tile -- wrong results, measures the DMA's cost
+#endif
+
+// Waves per workgroup (each owns 32 X rows; all share one tile ring).  Everything below is written for
+// 4 or 8.  Measured at d = 128 (B = 8192): eight waves on ONE ring -- every Y tile DMA'd into LDS once
+// per CU instead of twice, same two waves per SIMD -- against two independent 4-wave workgroups per
+// CU: forward -2 %, dU +1 %, dV +8 %, selection -2 %: what the halved DMA saves, the barrier across
+// eight waves takes back.  Hence four.
+static constexpr int mf_nw(int d) { return (void)d, 4; }
+// workgroups per CU the sweeps are compiled for (two waves per SIMD either way)
+static constexpr int mf_wg_per_cu(int d) { return (mf_nw(d) == 8 || d == 256) ? 1 : 2; }
+
 template <int D>
 struct TileGeom {
+    static constexpr int NW = mf_nw(D);           // waves per workgroup
+    static constexpr int XB = 32 * NW;            // X rows per workgroup
     static constexpr int ROWB = D * 4;            // bytes per row
     static constexpr int TILEB = 32 * ROWB;       // bytes per tile
     static constexpr int CPR = D / 4;             // 16-byte chunks per row
-    static constexpr int PIECES = TILEB / 1024;   // 1 KiB DMA pieces per tile (D / 8)
-    static constexpr int PPW = PIECES / 4;        // pieces per wave
+    static constexpr int WAVEB = TILEB / NW;      // bytes of a tile each wave stages
+    static constexpr int PIECEB = WAVEB < 1024 ? WAVEB : 1024;   // bytes per DMA instruction (16 B per active lane)
+    static constexpr int PPW = WAVEB / PIECEB / MF_ABL_DMADIV;   // DMA instructions per wave and tile
     static __device__ __forceinline__ int swz(int row) { return CPR >= 16 ? (row & 15) : ((row >> 1) & 7); }
 };
 
@@ -47,28 +63,30 @@ __device__ __forceinline__ void mf_stage_tile(char* lds_tile, const float* __res
     const int lane = mf_lane();
     const int wave = mf_wave_id();
     const char* tile_src = reinterpret_cast<const char*>(Y) + y0 * G::ROWB;   // wave-uniform
+    const bool active = lane * 16 < G::PIECEB;                                 // d = 32: half a wave per piece
     if (y0 + 32 <= nY) {
         // interior tile: the per-lane offsets below depend only on (wave, lane) -> hoisted out of the tile loop
 #pragma unroll
         for (int q = 0; q < G::PPW; ++q) {
-            const int p = wave * G::PPW + q;
-            const int off = p * 1024 + lane * 16;
+            const int pb = (wave * G::PPW + q) * G::PIECEB;
+            const int off = pb + (active ? lane * 16 : 0);
             const int row = off / G::ROWB;
             const int ch = ((off % G::ROWB) >> 4) ^ G::swz(row);
-            __builtin_amdgcn_global_load_lds((mf_glb_ptr)(tile_src + row * G::ROWB + ch * 16),
-                                             (mf_lds_ptr)(lds_tile + p * 1024), 16, 0, 0);
+            if (active)
+                __builtin_amdgcn_global_load_lds((mf_glb_ptr)(tile_src + row * G::ROWB + ch * 16),
+                                                 (mf_lds_ptr)(lds_tile + pb), 16, 0, 0);
         }
     } else {
 #pragma unroll
         for (int q = 0; q < G::PPW; ++q) {
-            const int p = wave * G::PPW + q;
-            const int off = p * 1024 + lane * 16;
+            const int pb = (wave * G::PPW + q) * G::PIECEB;
+            const int off = pb + (active ? lane * 16 : 0);
             const int row = off / G::ROWB;
             const int ch = ((off % G::ROWB) >> 4) ^ G::swz(row);
             int64_t y = y0 + row;
             y = y < nY ? y : nY - 1;                                           // ragged last tile: clamp (masked later)
             const char* src = reinterpret_cast<const char*>(Y + y * D) + ch * 16;
-            __builtin_amdgcn_global_load_lds((mf_glb_ptr)src, (mf_lds_ptr)(lds_tile + p * 1024), 16, 0, 0);
+            if (active) __builtin_amdgcn_global_load_lds((mf_glb_ptr)src, (mf_lds_ptr)(lds_tile + pb), 16, 0, 0);
         }
     }
 }

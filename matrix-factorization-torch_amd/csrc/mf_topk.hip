@@ -27,11 +27,11 @@ struct RetrievalPolicy {
     };
     static constexpr int AUX_DMA = 1;
     static constexpr bool PREFILTER = true;      // hi = mf_orderable(score)
-    static __device__ __forceinline__ void stage_aux(const Params& p, char* aux, int wave, int t, int64_t x0) {
+    static __device__ __forceinline__ void stage_aux(const Params& p, char* aux, int wave, int t, int64_t x0, int) {
         mf_stage_small(aux + wave * 128, p.exclW + (int64_t)t * p.Qp + x0, 128);
     }
     static __device__ __forceinline__ Row row_init(const Params&, int64_t, bool) { return Row{}; }
-    static __device__ __forceinline__ Tile tile_init(const Params&, const Row&, const char* aux, int wave, int c, int) {
+    static __device__ __forceinline__ Tile tile_init(const Params&, const Row&, const char* aux, int wave, int c, int, int) {
         return Tile{reinterpret_cast<const uint32_t*>(aux + wave * 128)[c]};
     }
     static __device__ __forceinline__ bool key(const Params& p, const Row&, const Tile& t, float score, int e, int h,
