@@ -62,7 +62,11 @@ __device__ __forceinline__ void mf_stage_tile(char* lds_tile, const float* __res
     using G = TileGeom<D>;
     const int lane = mf_lane();
     const int wave = mf_wave_id();
+#ifdef MF_ABL_SAMETILE      // A/B knob: always stage tile 0 (cache-resident) -- wrong results, measures the memory side
+    const char* tile_src = reinterpret_cast<const char*>(Y);
+#else
     const char* tile_src = reinterpret_cast<const char*>(Y) + y0 * G::ROWB;   // wave-uniform
+#endif
     const bool active = lane * 16 < G::PIECEB;                                 // d = 32: half a wave per piece
     if (y0 + 32 <= nY) {
         // interior tile: the per-lane offsets below depend only on (wave, lane) -> hoisted out of the tile loop

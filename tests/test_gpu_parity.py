@@ -103,6 +103,19 @@ def test_masks_bit_exact_vs_oracle(mf, path):
             assert torch.equal(got, want), (path.stem, sigma, k, (got != want).sum().item())
 
 
+@pytest.mark.parametrize("cfg", [(300, 4096, 64, 4), (130, 2500, 128, 24), (64, 2100, 32, 64)], ids=lambda c: "x".join(map(str, c)))
+def test_mined_masks_bit_exact_long_item_axis(mf, cfg):
+    """Semi-hard mining where the item axis is long enough for the seeding pass and several chunks per row
+    (the golden / ragged cases above are shorter): the mined mask is bit-exact, duplicates and hits included."""
+    b, n, d, k = cfg
+    t = _random_case(b, n, d, 6, seed=sum(cfg), n_items=n // 3)
+    lg = torch.from_numpy(chain.logits(t["u"].numpy(), t["v"].numpy(), t["target"].numpy(), 1.0))
+    want = ol.semi_hard_mining(lg, ol.negative_masks(t["item_idx"], t["pos_idx"], b), k)
+    got = mf.losses.negative_mask(t["u"].to(DEV), t["v"].to(DEV), t["target"].to(DEV), item_idx=t["item_idx"].to(DEV),
+                                  pos_idx=t["pos_idx"].to(DEV), num_negatives=k, sigma=1.0).cpu()
+    assert torch.equal(got, want), int((got != want).sum())
+
+
 def _random_case(b, n, d, p, seed, n_items=None):
     g = torch.Generator().manual_seed(seed)
     n_items = n_items or max(n // 2, 4)
@@ -219,7 +232,8 @@ def test_sparse_update_matches_oracle(mf, d, normalize, opt):
 
 
 # --------------------------------------------------------------------- retrieval ---
-@pytest.mark.parametrize("cfg", [(50, 5000, 64, 20), (1, 3883, 64, 20), (33, 1000, 128, 5), (7, 300, 32, 64), (40, 2500, 256, 32)],
+@pytest.mark.parametrize("cfg", [(50, 5000, 64, 20), (1, 3883, 64, 20), (33, 1000, 128, 5), (7, 300, 32, 64), (40, 2500, 256, 32),
+                                 (150, 20000, 128, 64), (300, 9000, 256, 40), (1030, 4100, 32, 1)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_topk_bit_exact(mf, cfg):
     nq, n, d, k = cfg
@@ -244,6 +258,26 @@ def test_topk_degenerate_inputs(mf):
     small = mf.retrieval.ItemIndex(items[:6].to(DEV))
     s, i = small.search(torch.randn(2, 32).to(DEV), 8, exclude=[[0, 1], []])
     assert (i[0, 4:] == -1).all() and (i[1, 6:] == -1).all() and torch.isinf(s[0, 4:]).all()
+
+
+def test_topk_degenerate_inputs_long_catalog(mf):
+    """Equal scores over a catalog long enough for the seeding pass and many chunks: every list overflows,
+    the exact wave-cooperative path and its 64-bit floors decide, the lowest rows win; with exclusions."""
+    n, k = 6000, 33
+    items = torch.randn(n, 64)
+    index = mf.retrieval.ItemIndex(items.to(DEV))
+    excl = [[0, 2, 5], [], list(range(40)), [n - 1]]
+    s, i = index.search(torch.zeros(4, 64, device=DEV), k, exclude=excl)
+    for r, ex in enumerate(excl):
+        want = [j for j in range(n) if j not in set(ex)][:k]
+        assert i[r].cpu().tolist() == want
+    # two distinct score levels: the k best are the rows of the upper level, in row order
+    q = torch.zeros(1, 64)
+    q[0, 0] = 1.0
+    items2 = torch.zeros(n, 64)
+    items2[::7, 0] = 1.0
+    s, i = mf.retrieval.ItemIndex(items2.to(DEV)).search(q.to(DEV), k)
+    assert i[0].cpu().tolist() == list(range(0, 7 * k, 7)) and bool((s[0] == 1.0).all())
 
 
 def test_sharded_topk_merge_equals_full(mf):
