@@ -819,15 +819,20 @@ struct BwdParams {
 template <int D, bool XU>
 struct BwdLds {
     using G = TileGeom<D>;
-    static constexpr int LT = G::TILEB;                  // NW x 4 KiB stash blocks (one per wave) behind the tile
-    static constexpr int SLOT = G::TILEB + G::NW * 4096;
+    // Two schedules (see the kernel): SPREAD for long tiles (d >= 128) -- 2-slot tile ring, the wave's own
+    // 4 KiB stash / G' block comes straight into registers (it is wave-private: routing it through LDS
+    // only added 16 KiB of DMA writes and 16 KiB of reads per tile to an LDS port that the MFMA operand
+    // reads need); otherwise whole stages two tiles ahead, stash blocks behind the tile in each slot.
+    static constexpr bool SPREAD = D >= 128;
+    static constexpr int LT = G::TILEB;                  // (not SPREAD) NW x 4 KiB stash blocks behind the tile
+    static constexpr int SLOT = G::TILEB + (SPREAD ? 0 : G::NW * 4096);
     static constexpr int EXTRA = XU ? 0 : G::NW * 32 * 32 * 4;   // dV: per-wave 32 x 32 transpose scratch (XOR-swizzled)
     // the deepest ring that still puts two waves on every SIMD (two 4-wave workgroups per CU, or one of
     // eight waves); 2 slots cost a second barrier per tile, measured free
-    static constexpr int NSLOT = ((G::NW == 8 ? 1 : 2) * (3 * SLOT + EXTRA) <= 160 * 1024) ? 3 : 2;
+    static constexpr int NSLOT = SPREAD ? 2 : (((G::NW == 8 ? 1 : 2) * (3 * SLOT + EXTRA) <= 160 * 1024) ? 3 : 2);
     static constexpr int TR = NSLOT * SLOT;
     static constexpr int BYTES = TR + EXTRA;
-    static constexpr int NDMA = G::PPW + 4;              // DMA instructions per wave per stage
+    static constexpr int NDMA = G::PPW + 4;              // memory instructions per wave per stage (4 = the stash block)
 };
 
 // XU = true : lanes hold users, item tiles stream, result d loss / d u   (reads L, writes G' back)
@@ -857,31 +862,49 @@ __global__ __launch_bounds__(64 * mf_nw(D)) void loss_bwd_dense_kernel(BwdParams
     float rsum = 0.f;
 
     auto block_of = [&](int t) { return XU ? ((int64_t)xt * p.NT + t) : ((int64_t)t * p.NT + xt); };
-    auto stage = [&](int t, int slot_idx) {
-        char* slot = smem + slot_idx * L::SLOT;
-        mf_stage_tile<D>(slot, Y, (int64_t)t * 32, nY);
-        const char* lsrc = reinterpret_cast<const char*>((XU ? p.stash : p.gstash) + block_of(t) * 1024) + lane * 16;
+    // piece j of the staging of tile t: 0..3 the wave's 4 KiB stash / G' block (into LDS, or -- SPREAD --
+    // straight into the registers Gn), 4.. its share of the Y tile
+    constexpr bool SPREAD = L::SPREAD;
+    f32x4 Gn[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((mf_glb_ptr)(lsrc + q * 1024),
-                                             (mf_lds_ptr)(slot + L::LT + wave * 4096 + q * 1024), 16, 0, 0);
+    for (int q = 0; q < 4; ++q) Gn[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto stage_piece = [&](int t, int slot_idx, int j) {
+        char* slot = smem + slot_idx * L::SLOT;
+        if (j < 4) {
+            const char* lsrc = reinterpret_cast<const char*>((XU ? p.stash : p.gstash) + block_of(t) * 1024) + lane * 16;
+            if (SPREAD) Gn[j] = *reinterpret_cast<const f32x4*>(lsrc + j * 1024);
+            else __builtin_amdgcn_global_load_lds((mf_glb_ptr)(lsrc + j * 1024), (mf_lds_ptr)(slot + L::LT + wave * 4096 + j * 1024), 16, 0, 0);
+        } else {
+            mf_stage_tile_piece<D>(slot, Y, (int64_t)t * 32, nY, j - 4);
+        }
     };
+    auto stage = [&](int t, int slot_idx) {
+#pragma unroll
+        for (int j = 0; j < L::NDMA; ++j) stage_piece(t, slot_idx, j);
+    };
+    // Two schedules.  SPREAD (2-slot ring, d >= 128): the loads of tile ty+1 are issued ONE PER MFMA STEP
+    // inside the contraction of tile ty, the tile pieces into the slot tile ty-1 left; no second barrier.
+    // Otherwise (3 slots, short tiles): whole stages, two tiles ahead.
     if (t0 < t1) stage(t0, 0);
-    if (t0 + 1 < t1) stage(t0 + 1, 1);
+    if (!SPREAD && t0 + 1 < t1) stage(t0 + 1, 1);
     int cur = 0;
     for (int ty = t0; ty < t1; ++ty) {
-        // queue, oldest first: [DMA(ty)] [G stores(ty-2)] [DMA(ty+1)] [G stores(ty-1)]   (stores: dU only)
-        if (ty + 1 >= t1) mf_wait_vmcnt<0>();
-        else if (!XU || ty == t0) mf_wait_vmcnt<L::NDMA>();
-        else mf_wait_vmcnt<L::NDMA + 4>();
+        if (SPREAD) {
+            mf_wait_vmcnt<0>();           // tile ty: issued one tile ago, spread over the previous contraction
+        } else {
+            // queue, oldest first: [DMA(ty)] [G stores(ty-2)] [DMA(ty+1)] [G stores(ty-1)]   (stores: dU only)
+            if (ty + 1 >= t1) mf_wait_vmcnt<0>();
+            else if (!XU || ty == t0) mf_wait_vmcnt<L::NDMA>();
+            else mf_wait_vmcnt<L::NDMA + 4>();
+        }
         mf_block_barrier();
-        if (L::NSLOT == 3 && ty + 2 < t1) stage(ty + 2, cur >= 1 ? cur - 1 : 2);
+        if (!SPREAD && L::NSLOT == 3 && ty + 2 < t1) stage(ty + 2, cur >= 1 ? cur - 1 : 2);
         const char* slot = smem + cur * L::SLOT;
         const char* lt = slot + L::LT + wave * 4096;
         float Gv[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 t4 = *reinterpret_cast<const f32x4*>(lt + q * 1024 + lane * 16);
+            const f32x4 t4 = SPREAD ? Gn[q] : *reinterpret_cast<const f32x4*>(lt + q * 1024 + lane * 16);
 #pragma unroll
             for (int t = 0; t < 4; ++t) Gv[4 * q + t] = t4[t];
         }
@@ -912,15 +935,17 @@ __global__ __launch_bounds__(64 * mf_nw(D)) void loss_bwd_dense_kernel(BwdParams
 #pragma unroll
         for (int e = 0; e < 16; ++e) rsum += Gv[e];
         // dX[m][x] += sum_y Y[y][m] * G[y][x]   (the G tile is already a B operand)
+        const bool more = ty + 1 < t1;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             float yv[D / 32];
             mf_lds_cols<D>(yv, slot, mf_acc_row(t, h), c);
+            if (SPREAD && t < L::NDMA && more) stage_piece(ty + 1, cur ^ 1, t);
 #pragma unroll
             for (int j = 0; j < D / 32; ++j)
                 dacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv[j], Gv[t], dacc[j], 0, 0, 0);
         }
-        if (L::NSLOT == 2) {            // the slot just read is the one tile ty+2 lands in
+        if (!SPREAD && L::NSLOT == 2) {            // the slot just read is the one tile ty+2 lands in
             mf_block_barrier();
             if (ty + 2 < t1) stage(ty + 2, cur);
         }

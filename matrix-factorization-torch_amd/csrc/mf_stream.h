@@ -56,43 +56,37 @@ struct TileGeom {
 
 __device__ __forceinline__ int mf_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-// DMA one tile (rows y0 .. y0+31 of Y, rows past nY clamped to the last row) into `lds_tile`.
+// DMA piece q (0 .. PPW-1) of this wave's share of one tile (rows y0 .. y0+31 of Y, rows past nY clamped
+// to the last row) into `lds_tile`.
 template <int D>
-__device__ __forceinline__ void mf_stage_tile(char* lds_tile, const float* __restrict__ Y, int64_t y0, int64_t nY) {
+__device__ __forceinline__ void mf_stage_tile_piece(char* lds_tile, const float* __restrict__ Y, int64_t y0, int64_t nY, int q) {
     using G = TileGeom<D>;
     const int lane = mf_lane();
     const int wave = mf_wave_id();
+    const bool active = lane * 16 < G::PIECEB;                                 // d = 32 with 8 waves: half a wave per piece
+    const int pb = (wave * G::PPW + q) * G::PIECEB;
+    const int off = pb + (active ? lane * 16 : 0);
+    const int row = off / G::ROWB;
+    const int ch = ((off % G::ROWB) >> 4) ^ G::swz(row);
 #ifdef MF_ABL_SAMETILE      // A/B knob: always stage tile 0 (cache-resident) -- wrong results, measures the memory side
-    const char* tile_src = reinterpret_cast<const char*>(Y);
-#else
-    const char* tile_src = reinterpret_cast<const char*>(Y) + y0 * G::ROWB;   // wave-uniform
+    y0 = 0;
 #endif
-    const bool active = lane * 16 < G::PIECEB;                                 // d = 32: half a wave per piece
     if (y0 + 32 <= nY) {
-        // interior tile: the per-lane offsets below depend only on (wave, lane) -> hoisted out of the tile loop
-#pragma unroll
-        for (int q = 0; q < G::PPW; ++q) {
-            const int pb = (wave * G::PPW + q) * G::PIECEB;
-            const int off = pb + (active ? lane * 16 : 0);
-            const int row = off / G::ROWB;
-            const int ch = ((off % G::ROWB) >> 4) ^ G::swz(row);
-            if (active)
-                __builtin_amdgcn_global_load_lds((mf_glb_ptr)(tile_src + row * G::ROWB + ch * 16),
-                                                 (mf_lds_ptr)(lds_tile + pb), 16, 0, 0);
-        }
+        // interior tile: the per-lane offset depends only on (wave, lane, q) -> hoisted out of the tile loop
+        const char* tile_src = reinterpret_cast<const char*>(Y) + y0 * G::ROWB;   // wave-uniform
+        if (active)
+            __builtin_amdgcn_global_load_lds((mf_glb_ptr)(tile_src + row * G::ROWB + ch * 16), (mf_lds_ptr)(lds_tile + pb), 16, 0, 0);
     } else {
-#pragma unroll
-        for (int q = 0; q < G::PPW; ++q) {
-            const int pb = (wave * G::PPW + q) * G::PIECEB;
-            const int off = pb + (active ? lane * 16 : 0);
-            const int row = off / G::ROWB;
-            const int ch = ((off % G::ROWB) >> 4) ^ G::swz(row);
-            int64_t y = y0 + row;
-            y = y < nY ? y : nY - 1;                                           // ragged last tile: clamp (masked later)
-            const char* src = reinterpret_cast<const char*>(Y + y * D) + ch * 16;
-            if (active) __builtin_amdgcn_global_load_lds((mf_glb_ptr)src, (mf_lds_ptr)(lds_tile + pb), 16, 0, 0);
-        }
+        int64_t y = y0 + row;
+        y = y < nY ? y : nY - 1;                                               // ragged last tile: clamp (masked later)
+        const char* src = reinterpret_cast<const char*>(Y + y * D) + ch * 16;
+        if (active) __builtin_amdgcn_global_load_lds((mf_glb_ptr)src, (mf_lds_ptr)(lds_tile + pb), 16, 0, 0);
     }
+}
+template <int D>
+__device__ __forceinline__ void mf_stage_tile(char* lds_tile, const float* __restrict__ Y, int64_t y0, int64_t nY) {
+#pragma unroll
+    for (int q = 0; q < TileGeom<D>::PPW; ++q) mf_stage_tile_piece<D>(lds_tile, Y, y0, nY, q);
 }
 
 // DMA `nbytes` (multiple of 16, <= 1024) from src to lds_dst by the calling wave.
