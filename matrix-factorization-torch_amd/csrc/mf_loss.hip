@@ -61,6 +61,11 @@ struct LossWs {
     size_t total;
 };
 
+#ifndef BWD_MIN_WG
+#define BWD_MIN_WG 2      // A/B knob: workgroups per CU the backward sweeps are compiled for at d = 128 ...
+#define BWD_WGS 512       // ... and their grid size
+#endif
+
 static void split_geometry(int x_tiles, int y_tiles, int* nsplit, int* tps, int target_blocks) {
     int want = (target_blocks + x_tiles - 1) / x_tiles;
     if (want < 1) want = 1;
@@ -82,8 +87,8 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     // enough workgroups for two waves per SIMD: 256 of eight waves, 512 of four
     const int wgs = 2048 / w.NW;
     split_geometry(w.BT / w.NW, w.NT, &w.nsplit_f, &w.tps_f, wgs);
-    split_geometry(w.BT / w.NW, w.NT, &w.nsplit_u, &w.tps_u, wgs);
-    split_geometry(w.NT / w.NW, w.BT, &w.nsplit_v, &w.tps_v, wgs);
+    split_geometry(w.BT / w.NW, w.NT, &w.nsplit_u, &w.tps_u, d == 128 ? BWD_WGS : wgs);
+    split_geometry(w.NT / w.NW, w.BT, &w.nsplit_v, &w.tps_v, d == 128 ? BWD_WGS : wgs);
     const int k = num_negatives;
     w.plan = mf_select_plan(B, N, d, k);
     w.T = w.plan.T; w.CAP = w.plan.CAP; w.nchunk = w.plan.nsets; w.tpc = w.plan.tpc;
@@ -838,7 +843,7 @@ struct BwdLds {
 // XU = true : lanes hold users, item tiles stream, result d loss / d u   (reads L, writes G' back)
 // XU = false: lanes hold items, user tiles stream, result d loss / d v   (reads G')
 template <int D, bool XU, int GMODE>
-__global__ __launch_bounds__(64 * mf_nw(D)) void loss_bwd_dense_kernel(BwdParams p) {
+__global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss_bwd_dense_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using L = BwdLds<D, XU>;
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;

@@ -21,7 +21,7 @@ import torch
 
 from . import losses as mf_losses
 from . import models, optim
-from .params import TOP_K
+from .params import INDEX_PATH, PROCESSORS_JSON, TOP_K, TOWERS_PATH
 from .retrieval import RetrievalMetrics, ItemProcessor
 
 try:  # pragma: no cover - Lightning is absent from the build image
@@ -77,6 +77,67 @@ class MatrixFactorizationLitModule(_Base):
         device = self.towers["user"].weight.device
         embed = self(torch.tensor([int(user_idx)], device=device)).cpu().numpy()
         return self.item_processor.search(embed, exclude_item_ids=exclude_item_ids, top_k=top_k)
+
+    @torch.inference_mode()
+    def recommend_with_item_id(self, item_id: int, *, top_k: int = TOP_K, exclude_item_ids: list[int] | None = None):
+        """Items closest to item ``item_id`` -- the query is the item's own embedding and the item itself is
+        excluded (``Service.recommend_with_item_id`` -> ``recommend_with_item``, xfmr_rec/bentoml/service.py:220-247)."""
+        if self.item_processor is None or self.item_processor.index is None:
+            msg = "`user_processor` and `item_processor` must be initialised first"
+            raise ValueError(msg)
+        row = self.item_processor.row_of(item_id)
+        embed = self.item_processor.index.embeddings[row: row + 1, : self.config.hidden_size].cpu().numpy()
+        return self.item_processor.search(embed, exclude_item_ids=[*(exclude_item_ids or []), int(item_id)], top_k=top_k)
+
+    def recommend_with_user_id(self, user_idx: int, *, top_k: int = TOP_K, exclude_item_ids: list[int] | None = None):
+        """``Service.recommend_with_user_id`` (service.py:286-311): the user's history is excluded."""
+        return self.recommend(user_idx, top_k=top_k, exclude_item_ids=exclude_item_ids)
+
+    # ------------------------------------------------------------- save / load (f-3) ---
+    def save(self, path) -> None:
+        """The counterpart of ``save`` (xfmr_rec/lightning.py:312-328: ``transformer/`` + ``processors.json`` +
+        ``lance_db/``): the two tables (``towers.safetensors``), ``processors.json`` (config, item ids,
+        histories) and the built item index (``item_index.safetensors``: unit-norm item matrix + id map)."""
+        import json
+        import pathlib
+
+        from safetensors.torch import save_file
+
+        if self.towers is None:
+            msg = "`model` must be initialised first"
+            raise ValueError(msg)
+        path = pathlib.Path(path)
+        path.mkdir(parents=True, exist_ok=True)
+        save_file({f"{k}.weight": t.weight.detach().cpu().contiguous() for k, t in self.towers.items()}, str(path / TOWERS_PATH))
+        proc = {"config": self.config.model_dump(), "history": {str(k): list(map(int, v)) for k, v in self.history.items()}}
+        (path / PROCESSORS_JSON).write_text(json.dumps(proc, indent=2))
+        if self.item_processor is not None and self.item_processor.index is not None:
+            idx = self.item_processor.index
+            save_file({"embeddings": idx.embeddings[:, : idx.dim].cpu().contiguous(),
+                       "item_ids": self.item_processor.item_ids.contiguous()}, str(path / INDEX_PATH))
+
+    @classmethod
+    def load(cls, path, device="cuda") -> "MatrixFactorizationLitModule":
+        """What serving loads (``bentoml/service.py`` builds its processors from the same three pieces)."""
+        import json
+        import pathlib
+
+        from safetensors.torch import load_file
+
+        path = pathlib.Path(path)
+        proc = json.loads((path / PROCESSORS_JSON).read_text())
+        module = cls(proc["config"])
+        module.configure_model(device=device)
+        weights = load_file(str(path / TOWERS_PATH))
+        with torch.no_grad():
+            for k, t in module.towers.items():
+                t.weight.copy_(weights[f"{k}.weight"].to(device))
+        module.history = {int(k): v for k, v in proc.get("history", {}).items()}
+        if (path / INDEX_PATH).exists():
+            idx = load_file(str(path / INDEX_PATH))
+            module.item_processor = ItemProcessor(idx["item_ids"])
+            module.item_processor.set_index(idx["embeddings"].to(device))
+        return module
 
     # ------------------------------------------------------------------ losses ---
     def compute_losses(self, batch, step_name: str = "train") -> dict[str, torch.Tensor]:

@@ -19,3 +19,6 @@ ITEMS_TABLE_NAME = "movies"
 MODEL_NAME = "xfmr_rec"
 PROCESSORS_JSON = "processors.json"
 USERS_TABLE_NAME = "users"
+# save() layout (xfmr_rec/params.py:24-29 has transformer/ + processors.json + lance_db/; tables replace both stores)
+TOWERS_PATH = "towers.safetensors"
+INDEX_PATH = "item_index.safetensors"

@@ -109,6 +109,20 @@ class ItemProcessor:
         self._row_of_id = {int(i): r for r, i in enumerate(self.item_ids.tolist())}
         return self.index
 
+    def set_index(self, embeddings: torch.Tensor) -> ItemIndex:
+        """Install a prebuilt (loaded) item matrix; row r belongs to ``item_ids[r]``."""
+        self.index = ItemIndex(embeddings)
+        if self.item_ids is None:
+            self.item_ids = torch.arange(embeddings.shape[0])
+        self._row_of_id = {int(i): r for r, i in enumerate(self.item_ids.tolist())}
+        return self.index
+
+    def row_of(self, item_id: int) -> int:
+        if self._row_of_id is None or int(item_id) not in self._row_of_id:
+            msg = f"unknown item id: {item_id = }"
+            raise KeyError(msg)
+        return self._row_of_id[int(item_id)]
+
     def search(self, embedding, exclude_item_ids: list[int] | None = None, top_k: int = TOP_K):
         import pandas as pd
 

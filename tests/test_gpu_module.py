@@ -59,6 +59,24 @@ def test_training_loop_reduces_loss_and_recommend_excludes_history(mf, opt):
     assert df["score"].is_monotonic_decreasing and float(df["score"].max()) <= 1.0 + 1e-5
 
 
+def test_save_load_roundtrip_and_serving_shims(mf, tmp_path):
+    """save() -> load(): same tables, same index, same recommendations; item-to-item excludes the item."""
+    m = _module(mf)
+    m.on_validation_start()
+    m.history[9] = [11, 12]
+    before = m.recommend_with_user_id(9, top_k=15, exclude_item_ids=[3])
+    m.save(tmp_path / "model")
+    assert {p.name for p in (tmp_path / "model").iterdir()} == {"towers.safetensors", "processors.json", "item_index.safetensors"}
+    m2 = mf.lightning.MatrixFactorizationLitModule.load(tmp_path / "model", device=DEV)
+    assert torch.equal(m2.towers["item"].weight, m.towers["item"].weight) and m2.history == m.history
+    after = m2.recommend_with_user_id(9, top_k=15, exclude_item_ids=[3])
+    assert before.equals(after) and not set(after["movie_id"]) & {3, 11, 12}
+    sim = m2.recommend_with_item_id(42, top_k=10)
+    assert len(sim) == 10 and 42 not in set(sim["movie_id"]) and sim["score"].is_monotonic_decreasing
+    with pytest.raises(KeyError):
+        m2.recommend_with_item_id(10**9)
+
+
 def test_validation_step_metrics_match_oracle(mf):
     """validation_step = batched top-k (history excluded) + the six retrieval metrics, all on the device."""
     from oracle import retrieval as oretr
