@@ -15,6 +15,12 @@ timed region starts.
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+The timed region starts on an idle device (the contract's synchronize): on this part the first ~25 steps after ANY
+idle gap -- even the few hundred microseconds of a synchronize -- run slower (the three sweeps 371 -> 325 us at
+constant sclk / mclk, the step 1.6 -> 1.16 ms; tools/ramp_probe.py, tools/clock_probe.py: neither a GEMM spin-up nor
+running the same kernels on scratch data beforehand avoids it, only uninterrupted work does).  K = 20 therefore reads
+~1.26 ms / step, K = 100 ~1.18, the steady state is 1.16; the defaults are K = 100, W = 10 (0.13 s of device time).
+
 Prints ONE JSON line (rank 0).  `value` is train pairs/s over all ranks; the top-k
 leg is reported beside it (`topk`), each with the roofline of its dominant kernel,
 and the CPU baseline (the oracle's restatement of the same step, torch CPU, all host
@@ -38,7 +44,7 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 NUM_USERS, NUM_ITEMS, DIM = 162_541, 62_423, 128       # ML-25M shape
-TIME_EVERY = 4      # HIP-event pairs around every 4th launch of each timed kernel, inside the timed region
+TIME_EVERY = int(os.environ.get("MF_BENCH_TIME_EVERY", "4"))   # HIP-event pairs around every 4th launch of each timed kernel, inside the timed region
                     # (an event pair costs ~6 us of stream time around the kernel it brackets)
 PEAK_F32_MFMA_TFLOPS = 157.3                            # MI355X_MICROARCH.md, fp32 matrix
 PEAK_HBM_GBS = 8000.0
@@ -48,8 +54,8 @@ TOP_K, POS_PAD = 20, 64
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8192, help="pairs per GPU per step")
     ap.add_argument("--queries", type=int, default=1024, help="queries per GPU per retrieval step")
     ap.add_argument("--optimizer", choices=("adam", "sgd"), default="adam")
@@ -110,9 +116,12 @@ class Trainer:
         return self.towers["user"](rows).detach()
 
     def step(self, b) -> torch.Tensor:
+        # the hit masks depend on the ids only: built on a side stream while the towers gather
+        masks = self.loss_fn.prepare_masks(b["item"], b["pos"], batch_size=b["user"].numel(), embedding_dim=DIM)
         u = self.towers["user"](b["user"])
         v = self.towers["item"](b["item"])
-        loss = self.loss_fn(u, v, b["target"], item_idx=b["item"], pos_idx=b["pos"], logq=self.logq[b["item"]])
+        loss = self.loss_fn(u, v, b["target"], item_idx=b["item"], pos_idx=b["pos"], logq=self.logq[b["item"]],
+                            prepared=masks)
         loss.backward()
         self.opt.step()
         return loss

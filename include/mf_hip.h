@@ -121,8 +121,15 @@ int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64_t* sorted_
  * word [i][w] = column 32w+c) receives the post-mining negative mask
  * (negative_masks + semi_hard_mining, losses.py:92-162) for tests.
  * num_negatives follows losses.py:137-141: <= 0 or >= N disables mining.
- * Mining supports num_negatives <= 64 (MF_ENOTSUP beyond). */
+ * Mining supports num_negatives <= 64 (MF_ENOTSUP beyond).
+ *
+ * The hit masks (negative_masks, losses.py:92-110) depend on the ids only.  mf_loss_masks builds
+ * them into the workspace ahead of time -- typically on a second stream, beside the tower gathers --
+ * and the forward is then called with item_idx = NULL on the SAME workspace, after the caller has
+ * ordered the two streams (event); with item_idx != NULL mf_loss_fwd builds them itself. */
 size_t mf_loss_ws_bytes(int64_t B, int64_t N, int d, int P, int num_negatives);
+int mf_loss_masks(int64_t B, int64_t N, int d, int P, int num_negatives, const int64_t* item_idx,
+                  const int64_t* pos_idx, void* ws, size_t ws_bytes, mf_stream_t stream);
 int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
                 int kind_mask, const float* u, const float* v, const float* target,
                 const int64_t* item_idx, const int64_t* pos_idx, const float* logq, void* ws,

@@ -33,6 +33,7 @@ SIGNATURES = {
     "mf_sort_ws_bytes": (c_sz, [c_i64]),
     "mf_sort_keys": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mf_loss_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int, c_int]),
+    "mf_loss_masks": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mf_loss_fwd": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp,
                             c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
     "mf_loss_bwd": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp,
@@ -114,6 +115,32 @@ def ptr(t: torch.Tensor | None) -> int | None:
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+_ws_pool: dict = {}
+
+
+class LeasedWorkspace:
+    """A loss workspace (1 GB at B = 8192: it holds the logit stashes) taken from a small pool and given
+    back when the last reference goes (autograd drops it with the graph).  The loss path uses two streams
+    (masks are built on a side stream), and handing such blocks back to torch's caching allocator every step
+    made it allocate fresh ones for the first dozens of steps (a block recorded on two streams is reused
+    late).  A pooled block is only ever reused behind work that is already ordered before the new use: the
+    same stream, or the side stream after ``wait_stream``."""
+
+    def __init__(self, nbytes: int, device) -> None:
+        dev = torch.device(device)
+        self.key = (dev.index if dev.index is not None else torch.cuda.current_device(), max(int(nbytes), 256))
+        free = _ws_pool.setdefault(self.key, [])
+        self.tensor = free.pop() if free else torch.empty(self.key[1], dtype=torch.uint8, device=device)
+
+    def __del__(self) -> None:
+        try:
+            free = _ws_pool.setdefault(self.key, [])
+            if len(free) < 4:  # noqa: PLR2004
+                free.append(self.tensor)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 SUPPORTED_WIDTHS = (32, 64, 128, 256)

@@ -1089,13 +1089,36 @@ static int check_loss_args(const char* what, int64_t B, int64_t N, int d, int P,
     return MF_OK;
 }
 
+// The hit masks depend on the batch's ids only: built ahead of the forward (on another stream, beside the
+// tower gathers) they leave its critical path.  Fills ws's maskW; the forward is then called with
+// item_idx = NULL ("masks are in ws").
+extern "C" int mf_loss_masks(int64_t B, int64_t N, int d, int P, int num_negatives, const int64_t* item_idx,
+                             const int64_t* pos_idx, void* ws, size_t ws_bytes, mf_stream_t stream) {
+    if (B <= 0 || N < B || !mf_width_ok(d) || P < 0 || !item_idx || !ws || (P > 0 && !pos_idx))
+        return mf_set_error(MF_EINVAL, "mf_loss_masks: bad argument");
+    if (N >= (1 << 24)) return mf_set_error(MF_ENOTSUP, "mf_loss_masks: N >= 2^24");
+    if (ws_bytes < mf_loss_ws_bytes(B, N, d, P, num_negatives)) return mf_set_error(MF_ENOSPC, "mf_loss_masks: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LossWs w = loss_ws(ws, B, N, d, P, num_negatives);
+    PrepParams pp{};
+    pp.gtab = reinterpret_cast<uint4*>(w.gtab); pp.gtab16 = (int64_t)w.M * 8 / 16;
+    pp.gfirst = reinterpret_cast<uint4*>(w.gfirst); pp.gfirst16 = (int64_t)w.M * 4 / 16;
+    pp.ubits = reinterpret_cast<uint4*>(w.ubits); pp.ubits16 = (int64_t)w.NT * w.Bp * 4 / 16;
+    pp.ticket = w.ticket;
+    const int64_t want = (pp.ubits16 + 256 * 8 - 1) / (256 * 8);
+    prep_kernel<<<dim3((unsigned)(want < 2048 ? (want > 0 ? want : 1) : 2048)), 256, 0, s>>>(pp);   // Np = 0: clears only
+    build_masks(w, item_idx, pos_idx, B, N, P, s);
+    return mf_check_launch("mf_loss_masks");
+}
+
 extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
                            int kind_mask, const float* u, const float* v, const float* target,
                            const int64_t* item_idx, const int64_t* pos_idx, const float* logq, void* ws,
                            size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits, mf_stream_t stream) {
     int rc = check_loss_args("mf_loss_fwd", B, N, d, P, num_negatives, u, v, target, ws, ws_bytes);
     if (rc) return rc;
-    if (!item_idx || !out_losses || (P > 0 && !pos_idx) || !(kind_mask & 0x7F))
+    const bool masks_ready = item_idx == nullptr;       // mf_loss_masks ran on this workspace
+    if (!out_losses || (!masks_ready && P > 0 && !pos_idx) || !(kind_mask & 0x7F))
         return mf_set_error(MF_EINVAL, "mf_loss_fwd: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     LossWs w = loss_ws(ws, B, N, d, P, num_negatives);
@@ -1106,7 +1129,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
         PrepParams pp{u, v, target, logq, B, N, w.Bp, w.Np, d, sigma, w.nu, w.nv, w.lii, w.dii, w.sgn, w.logq,
                       nullptr, 0, nullptr, 0, nullptr, 0, w.ticket};
         int nb = (int)((w.Np + 255) / 256);
-        if (scores_needed) {
+        if (scores_needed && !masks_ready) {
             pp.gtab = reinterpret_cast<uint4*>(w.gtab); pp.gtab16 = (int64_t)w.M * 8 / 16;
             pp.gfirst = reinterpret_cast<uint4*>(w.gfirst); pp.gfirst16 = (int64_t)w.M * 4 / 16;
             pp.ubits = reinterpret_cast<uint4*>(w.ubits); pp.ubits16 = (int64_t)w.NT * w.Bp * 4 / 16;
@@ -1115,7 +1138,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
         }
         prep_kernel<<<dim3((unsigned)nb), 256, 0, s>>>(pp);
     }
-    if (scores_needed) build_masks(w, item_idx, pos_idx, B, N, P, s);
+    if (scores_needed && !masks_ready) build_masks(w, item_idx, pos_idx, B, N, P, s);
     // logq is read by whole float4s up to the padded width: prep_kernel keeps a zero-padded copy in ws
     // (all zeros when there is no logQ correction: L - 0 is exact, and the kernels stay branch-free)
     const float* logq_p = w.logq;

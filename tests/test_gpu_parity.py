@@ -157,6 +157,30 @@ def test_losses_match_oracle_ragged_shapes(mf, shape, k):
                 np.testing.assert_allclose(dv, v.grad.numpy(), rtol=2e-4, atol=2e-5 * sigma, err_msg=kind)
 
 
+@pytest.mark.parametrize("k", [0, 4])
+def test_prepared_masks_give_the_same_loss_and_gradients(mf, k):
+    """Masks built ahead on the side stream (prepare_masks) == masks built inside the forward, bit for bit."""
+    t = _random_case(150, 420, 64, 9, seed=77)
+    fn = mf.losses.PairwiseHingeLoss(num_negatives=k)
+    dev = {name: v.to(DEV) for name, v in t.items()}
+    outs = []
+    for use in (False, True):
+        u, v = dev["u"].clone().requires_grad_(), dev["v"].clone().requires_grad_()
+        prep = fn.prepare_masks(dev["item_idx"], dev["pos_idx"], batch_size=150, embedding_dim=64) if use else None
+        loss = fn(u, v, dev["target"], item_idx=dev["item_idx"], pos_idx=dev["pos_idx"], prepared=prep)
+        loss.backward()
+        outs.append((loss.detach().clone(), u.grad.clone(), v.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    if k == 0:
+        assert torch.equal(outs[0][2], outs[1][2])
+    else:       # mined dV goes through fp32 atomics: last-bit run-to-run variation (DESIGN.md)
+        torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError, match="another batch"):
+        other = dev["item_idx"].clone()
+        fn(dev["u"], dev["v"], dev["target"], item_idx=other, pos_idx=dev["pos_idx"],
+           prepared=fn.prepare_masks(dev["item_idx"], dev["pos_idx"], batch_size=150, embedding_dim=64))
+
+
 def test_fused_losses_equal_individual(mf):
     t = _random_case(96, 192, 64, 8, seed=5)
     dev = {k: x.to(DEV) for k, x in t.items()}
