@@ -116,8 +116,10 @@ class Trainer:
         return self.towers["user"](rows).detach()
 
     def step(self, b) -> torch.Tensor:
-        # the hit masks depend on the ids only: built on a side stream while the towers gather
-        masks = self.loss_fn.prepare_masks(b["item"], b["pos"], batch_size=b["user"].numel(), embedding_dim=DIM)
+        # the hit masks depend on the ids only and can be built on a side stream while the towers gather; measured
+        # equal (1.1718 vs 1.1732 ms / step: the cross-stream join costs what the overlap saves), so off by default
+        masks = (self.loss_fn.prepare_masks(b["item"], b["pos"], batch_size=b["user"].numel(), embedding_dim=DIM)
+                 if os.environ.get("MF_BENCH_PREPARE", "0") == "1" else None)
         u = self.towers["user"](b["user"])
         v = self.towers["item"](b["item"])
         loss = self.loss_fn(u, v, b["target"], item_idx=b["item"], pos_idx=b["pos"], logq=self.logq[b["item"]],

@@ -10,6 +10,8 @@ subclasses, so Lightning's automatic optimisation can drive them.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -34,14 +36,16 @@ _side_streams: dict = {}
 
 
 def run_table_jobs(jobs) -> None:
-    """Run independent per-table update jobs (callables issuing work on the *current* stream) side by
-    side: the first on the caller's stream, the others on cached side streams, forked from and joined
-    back into the caller's stream with events.  The updates of different tables touch disjoint memory,
-    and each is a chain of small latency-bound kernels, so they overlap almost perfectly."""
+    """Run independent per-table update jobs (callables issuing work on the *current* stream).  Default: one
+    after the other on the caller's stream.  With ``MF_TABLE_STREAMS=1`` the first runs on the caller's stream
+    and the others on cached side streams, forked from and joined back with events: the chains do overlap
+    (~35 us of small kernels), but on this part a cross-stream join costs a 20-30 us bubble in the stream it
+    rejoins -- measured at B = 8192: 1.1767 ms / step with two streams against 1.1644 on one."""
     if not jobs:
         return
-    if len(jobs) == 1:
-        jobs[0]()
+    if len(jobs) == 1 or os.environ.get("MF_TABLE_STREAMS") != "1":
+        for job in jobs:
+            job()
         return
     cur = torch.cuda.current_stream()
     fork = torch.cuda.Event()
