@@ -159,8 +159,9 @@ __device__ __forceinline__ void fill16(uint4* dst, int64_t n16, unsigned pat, in
     for (int64_t q = tid; q < n16; q += nthreads) dst[q] = v;
 }
 
-__global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// 64-thread workgroups: the per-row chains are serial, so the rows are spread over as many CUs as possible
+__global__ __launch_bounds__(64) void prep_kernel(PrepParams p) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (i < p.Np) {
         const bool hv = i < p.N, hu = i < p.B;                  // B <= N: a user row always has its item row
         float nvv = 0.f, nuu = 0.f, dot = 0.f;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepParams p) {
         }
     }
     if (i == 0) *p.ticket = 0u;
-    const int64_t nthreads = (int64_t)gridDim.x * 256;
+    const int64_t nthreads = (int64_t)gridDim.x * 64;
     fill16(p.gtab, p.gtab16, 0x80808080u, i, nthreads);
     fill16(p.gfirst, p.gfirst16, 0x7f7f7f7fu, i, nthreads);
     fill16(p.ubits, p.ubits16, 0u, i, nthreads);
@@ -1105,8 +1106,8 @@ extern "C" int mf_loss_masks(int64_t B, int64_t N, int d, int P, int num_negativ
     pp.gfirst = reinterpret_cast<uint4*>(w.gfirst); pp.gfirst16 = (int64_t)w.M * 4 / 16;
     pp.ubits = reinterpret_cast<uint4*>(w.ubits); pp.ubits16 = (int64_t)w.NT * w.Bp * 4 / 16;
     pp.ticket = w.ticket;
-    const int64_t want = (pp.ubits16 + 256 * 8 - 1) / (256 * 8);
-    prep_kernel<<<dim3((unsigned)(want < 2048 ? (want > 0 ? want : 1) : 2048)), 256, 0, s>>>(pp);   // Np = 0: clears only
+    const int64_t want = (pp.ubits16 + 64 * 8 - 1) / (64 * 8);
+    prep_kernel<<<dim3((unsigned)(want < 8192 ? (want > 0 ? want : 1) : 8192)), 64, 0, s>>>(pp);   // Np = 0: clears only
     build_masks(w, item_idx, pos_idx, B, N, P, s);
     return mf_check_launch("mf_loss_masks");
 }
@@ -1128,15 +1129,15 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     {
         PrepParams pp{u, v, target, logq, B, N, w.Bp, w.Np, d, sigma, w.nu, w.nv, w.lii, w.dii, w.sgn, w.logq,
                       nullptr, 0, nullptr, 0, nullptr, 0, w.ticket};
-        int nb = (int)((w.Np + 255) / 256);
+        int nb = (int)((w.Np + 63) / 64);
         if (scores_needed && !masks_ready) {
             pp.gtab = reinterpret_cast<uint4*>(w.gtab); pp.gtab16 = (int64_t)w.M * 8 / 16;
             pp.gfirst = reinterpret_cast<uint4*>(w.gfirst); pp.gfirst16 = (int64_t)w.M * 4 / 16;
             pp.ubits = reinterpret_cast<uint4*>(w.ubits); pp.ubits16 = (int64_t)w.NT * w.Bp * 4 / 16;
-            const int64_t want = (pp.ubits16 + 256 * 8 - 1) / (256 * 8);     // ~8 stores per thread
-            if (want > nb) nb = (int)(want < 2048 ? want : 2048);
+            const int64_t want = (pp.ubits16 + 64 * 8 - 1) / (64 * 8);       // ~8 stores per thread
+            if (want > nb) nb = (int)(want < 8192 ? want : 8192);
         }
-        prep_kernel<<<dim3((unsigned)nb), 256, 0, s>>>(pp);
+        prep_kernel<<<dim3((unsigned)nb), 64, 0, s>>>(pp);
     }
     if (scores_needed && !masks_ready) build_masks(w, item_idx, pos_idx, B, N, P, s);
     // logq is read by whole float4s up to the padded width: prep_kernel keeps a zero-padded copy in ws
