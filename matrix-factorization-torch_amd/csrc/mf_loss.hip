@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void loss_fwd_dense
     // the next tile: slices 0..15 turn score e into logit e (and stash it), slices 16..31 fold
     // logit e into the running statistics.
     float Lg[16];
-    float tmax = -FLT_MAX, nmx = -FLT_MAX;
+    float tmax = -FLT_MAX, nmx = -FLT_MAX, nmx2 = 0.f;
     uint32_t mw = 0u;
     f32x4 nv4 = {0.f, 0.f, 0.f, 0.f}, lq4 = {0.f, 0.f, 0.f, 0.f};
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -474,6 +474,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void loss_fwd_dense
                 tmax = -FLT_MAX;
                 // valid negatives among this lane's 16 rows of the tile (rows (e&3) + 8 (e>>2) + 4 h)
                 st.cnt += (float)(16 - __builtin_popcount(mw & (h ? 0xF0F0F0F0u : 0x0F0F0F0Fu)));
+                mw >>= 4 * h;           // this lane's rows now sit at the compile-time bit (e&3) + 8 (e>>2)
             }
             if (r == 0) {
                 nv4 = *reinterpret_cast<const f32x4*>(aux + L::AUX_NV + (8 * q + 4 * h) * 4);
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void loss_fwd_dense
             // masked logit: -inf where the column is not a valid negative -> every statistic below and
             // every dloss/dL of the backward is exactly 0 there, with no further mask test
             const float Lraw = mf_logit(nu_i, nv4[r], acc[e], s_i, p.sigma, lq4[r]);
-            Lg[e] = ((mw >> mf_acc_row(e, h)) & 1u) ? -INFINITY : Lraw;
+            Lg[e] = (mw & (1u << mf_acc_row(e, 0))) ? -INFINITY : Lraw;
             tmax = fmaxf(tmax, Lg[e]);
             if (r == 3) {   // stash 4 masked logits of the block for the backward sweeps
                 float* blk = p.stash + ((int64_t)(i0 / 32 + wave) * p.NT + te) * 1024 + lane * 4;
@@ -494,9 +495,12 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void loss_fwd_dense
                 nmx = fmaxf(st.mx, tmax);
                 if (NEED & NEED_LSE) st.se *= __expf(st.mx - nmx);
                 st.mx = nmx;
+                // exp(L - nmx) = exp2(fma(L, log2 e, -nmx log2 e)): one fma + one exp2 per element; the clamp
+                // keeps the constant finite while nothing valid has been seen (nmx = -FLT_MAX, every L = -inf)
+                nmx2 = -fmaxf(nmx, -1e30f) * 1.44269504088896341f;
             }
             stats_add_masked<NEED>(st, Lg[e], sm, lii, p.margin);
-            if (NEED & NEED_LSE) st.se += __expf(Lg[e] - nmx);
+            if (NEED & NEED_LSE) st.se += __builtin_amdgcn_exp2f(__builtin_fmaf(Lg[e], 1.44269504088896341f, nmx2));
         }
     };
 
