@@ -220,10 +220,11 @@ __device__ __forceinline__ unsigned ht_hash(long long id, unsigned slots_mask) {
     return ((((unsigned)id * 2654435761u) ^ ((unsigned)((unsigned long long)id >> 32) * 40503u)) >> 5) & slots_mask;
 }
 
-__global__ __launch_bounds__(256) void gt_insert_kernel(const int64_t* __restrict__ item_idx, int64_t N, int M,
+// (64-thread workgroups: every thread is one chain of dependent memory operations; spread over all CUs)
+__global__ __launch_bounds__(64) void gt_insert_kernel(const int64_t* __restrict__ item_idx, int64_t N, int M,
                                                         long long* __restrict__ gtab, int32_t* __restrict__ gfirst,
                                                         int32_t* __restrict__ colslot) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j >= N) return;
     const long long key = item_idx[j];
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(gtab);
@@ -1050,7 +1051,7 @@ static void clear_mask_tables(const LossWs& w, hipStream_t s) {     // mf_loss_f
 // expects gtab / gfirst / ubits cleared
 static void build_masks(const LossWs& w, const int64_t* item_idx, const int64_t* pos_idx, int64_t B, int64_t N, int P,
                         hipStream_t s) {
-    gt_insert_kernel<<<dim3((unsigned)((N + 255) / 256)), 256, 0, s>>>(item_idx, N, w.M, w.gtab, w.gfirst, w.colslot);
+    gt_insert_kernel<<<dim3((unsigned)((N + 63) / 64)), 64, 0, s>>>(item_idx, N, w.M, w.gtab, w.gfirst, w.colslot);
     const int nb_col = (int)((w.Np + 1023) / 1024);
     const int nb_u = (int)((B + 31) / 32);
     int cap = 64;

@@ -604,7 +604,10 @@ static inline SelectPlan mf_select_plan(int64_t nX, int64_t nY, int d, int k) {
     int want = (wgs + s.gx - 1) / s.gx;
     if (want > 128) want = 128;
     // a seeding pass over 1/8 of Y pays when Y is long enough to profit from its bound
-    s.YTa = (s.YT >= 64) ? s.YT / 8 : 0;
+#ifndef MF_SEED_DIV
+#define MF_SEED_DIV 8      // A/B knob: the seeding pass scans 1 / MF_SEED_DIV of Y
+#endif
+    s.YTa = (s.YT >= 64) ? s.YT / MF_SEED_DIV : 0;
     if (s.YTa > 0) {
         int na = want < s.YTa / 4 ? want : s.YTa / 4;        // >= 4 tiles per chunk
         if (na < 1) na = 1;
