@@ -675,7 +675,28 @@ struct MiningPolicy {
         f32x4 nv4[4], lq4[4];
     };
     static constexpr int AUX_DMA = 2;
-    static constexpr bool PREFILTER = false;     // the mining rank is not monotone in the raw dot product
+    // The mining rank orders Dm = L_ij - L_ii: semi-hard (Dm < 0, larger first) above hard (Dm >= 0, smaller
+    // first), so `rank >= bound` is an INTERVAL of Dm: [v, 0) for a semi-hard bound, (-inf, v'] for a hard one.
+    // Dm is computed exactly as key() does; the interval is widened to the bound's 30 kept rank bits
+    // (conservative), everything exact happens in key().
+    struct Thr {
+        float lo, hi;
+    };
+    static __device__ __forceinline__ Thr thr_all() { return Thr{-__builtin_inff(), __builtin_inff()}; }
+    static __device__ __forceinline__ Thr thr_none() { return Thr{__builtin_inff(), -__builtin_inff()}; }
+    static __device__ __forceinline__ Thr make_thr(unsigned bound) {
+        const unsigned cls = bound >> 30;
+        const float v = mf_unorderable((bound & 0x3FFFFFFFu) << 2);   // smallest value whose rank has these 30 bits
+        if (cls == 2u) return Thr{v, 0.f};              // semi-hard bound: Dm in [v, 0]  (Dm = 0 itself fails key())
+        if (cls == 1u) return Thr{-__builtin_inff(), 0.f - v};   // hard bound at -Dm >= v: every Dm <= -v
+        return cls == 0u ? thr_all() : thr_none();
+    }
+    static __device__ __forceinline__ bool maybe(const Params& p, const Row& r, const Tile& t, float score, int e, int,
+                                                 const Thr& th) {
+        const float L = mf_logit(r.nu, t.nv4[e >> 2][e & 3], score, r.sgn, p.sigma, t.lq4[e >> 2][e & 3]);
+        const float dm = L - r.lii;
+        return dm >= th.lo && dm <= th.hi;
+    }
     static __device__ __forceinline__ void stage_aux(const Params& p, char* aux, int wave, int t, int64_t x0, int W0) {
         mf_stage_small(aux + wave * 128, p.maskW + (int64_t)t * p.Bp + x0, 128);
         const float* src = (wave == 1 && p.logq) ? p.logq : p.nv;

@@ -114,7 +114,9 @@ struct SelectLds {
 //   static Row  row_init(P, x, valid)
 //   static Tile tile_init(P, row, aux, wave, c, h, W0)  read the staged side inputs
 //   static bool key(P, row, tile, score, e, h, y, hi&, lo&)   false = never a candidate; (hi, lo) = key halves
-//   static constexpr bool PREFILTER                 true: hi is mf_orderable(score), so `score < bound` may skip key()
+//   struct Thr;  static Thr thr_all(), thr_none(), make_thr(unsigned rank_bound)
+//   static bool maybe(P, row, tile, score, e, h, thr)   cheap, CONSERVATIVE test of `rank >= bound` on the raw score:
+//                                                    false only if key() could not pass the exact test
 template <int D, int T, class Policy>
 __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_kernel(typename Policy::Params pp, SelectCommon sc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -174,18 +176,18 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_kernel(
     const bool row_ok = x < sc.nX;               // padding rows (all-zero X) never collect candidates
     unsigned y0 = 0u;                            // first Y row of the current tile (rows < 2^32)
 #ifdef MF_ABL_NOPASS
-    float thr_f = __builtin_inff();
+    typename Policy::Thr thr = Policy::thr_none();
 #else
-    float thr_f = __builtin_bit_cast(float, 0xFFFFFFFFu);   // NaN: everything passes until a bound exists
+    typename Policy::Thr thr = Policy::thr_all();            // everything passes until a bound exists
 #endif
     unsigned pub = 0u;                                       // last bound this lane published
     // 32-bit-only fast path: rank (= high key word) against the row bound; the exact 64-bit floor of
     // the degenerate path is checked by halves as well.  WARM: the T-lists are still filling.
     auto slice_t = [&](int e, auto warm_tag) {
         constexpr bool WARM = decltype(warm_tag)::value;
-        // one compare per element on the raw score where the policy's rank is monotone in it
-        // (conservative: NaN and signed zeros pass), everything exact happens behind the branch
-        if (Policy::PREFILTER && (acc[e] < thr_f)) return;
+        // a cheap conservative test on the raw score first (retrieval: one compare), everything exact
+        // happens behind the branch
+        if (!Policy::maybe(pp, row, tile, acc[e], e, h, thr)) return;
 #ifdef MF_PROBE
         if (lane == (int)__builtin_ctzll(__ballot(1))) dbg[5] += 1;
 #endif
@@ -291,12 +293,12 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_kernel(
         }
         {
             const unsigned t = max(tau_row, (unsigned)(fl >> 32));
-            thr_f = row_ok ? mf_unorderable(t) : __builtin_inff();
+            thr = row_ok ? Policy::make_thr(t) : Policy::thr_none();
             MF_PROBE_T(ps3);
             MF_PROBE_ADD(3, ps3 - ps2);
             MF_PROBE_ADD(1, ps3 - ps0);
 #ifdef MF_ABL_NOPASS
-            thr_f = __builtin_inff();
+            thr = Policy::thr_none();
 #endif
         }
     };

@@ -26,7 +26,17 @@ struct RetrievalPolicy {
         uint32_t ew;
     };
     static constexpr int AUX_DMA = 1;
-    static constexpr bool PREFILTER = true;      // hi = mf_orderable(score)
+    // the rank is mf_orderable(score): monotone in the raw score, so the bound is one float (NaN and signed
+    // zeros pass: conservative)
+    struct Thr {
+        float f;
+    };
+    static __device__ __forceinline__ Thr thr_all() { return Thr{__builtin_bit_cast(float, 0xFFFFFFFFu)}; }   // NaN: nothing is below it
+    static __device__ __forceinline__ Thr thr_none() { return Thr{__builtin_inff()}; }
+    static __device__ __forceinline__ Thr make_thr(unsigned bound) { return Thr{mf_unorderable(bound)}; }
+    static __device__ __forceinline__ bool maybe(const Params&, const Row&, const Tile&, float score, int, int, const Thr& t) {
+        return !(score < t.f);
+    }
     static __device__ __forceinline__ void stage_aux(const Params& p, char* aux, int wave, int t, int64_t x0, int) {
         mf_stage_small(aux + wave * 128, p.exclW + (int64_t)t * p.Qp + x0, 128);
     }
