@@ -233,9 +233,6 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_kernel(
     // T distinct accepted elements, so tl[T-1] stays a valid and, with the row's best spread over many
     // tiles, nearly tight lower bound, at the cost of one branch-free insertion per tile.
     auto settle = [&](const char* aux) {
-#ifdef MF_ABL_NOSETTLE
-        return;
-#endif
         MF_PROBE_T(ps0);
         if (tmaxr > tl[T - 1]) mf_tlist_insert<T>(tl, tmaxr);
         tmaxr = 0u;
