@@ -1240,6 +1240,17 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
     return mf_check_launch("mf_loss_bwd");
 }
 
+#ifdef MF_PROBE
+extern "C" void mf_probe_mining_counters(unsigned long long* out16, int reset) {   // tools/mined_probe.py
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(mf_sel_dbg), 16 * 8);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(mf_sel_dbg), z, 16 * 8);
+    }
+}
+#endif
+
 // ------------------------------------------------- public mask / mining helpers ----
 // API parity with the reference's EmbeddingLoss methods on caller-provided tensors:
 // negative_masks (losses.py:92-110), hard_mining (:112-132, never called upstream) and

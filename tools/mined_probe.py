@@ -33,4 +33,12 @@ for name, k in (("InfomationNoiseContrastiveEstimationLoss", 0), ("PairwiseHinge
     tot = ctypes.c_double(0.0)
     n = lib.mf_timing_get(b"mining_select", ctypes.byref(tot))
     sel = f"  mining_select {tot.value / n:.3f} ms" if n else ""
+    if hasattr(lib, "mf_probe_mining_counters") and k:
+        buf = (ctypes.c_ulonglong * 16)()
+        lib.mf_probe_mining_counters(buf, 1)
+        tr.step(batches[0])
+        lib.mf_probe_mining_counters(buf, 1)
+        w = max(buf[8], 1)
+        names = ["cycles", "settle", "-", "compact_slow", "accepted", "body_slices", "compact_calls", "slow_rows"]
+        sel += "  per_wave{" + ", ".join(f"{nm}={buf[j] / w:.0f}" for j, nm in enumerate(names) if nm != "-") + f"}} waves={buf[8]}"
     print(f"{name:44s} num_negatives={k:2d}: {1e3 * dt:.3f} ms / step  ({8192 / dt / 1e6:.2f} M pairs/s){sel}")
