@@ -130,9 +130,11 @@ class LeasedWorkspace:
 
     def __init__(self, nbytes: int, device) -> None:
         dev = torch.device(device)
-        self.key = (dev.index if dev.index is not None else torch.cuda.current_device(), max(int(nbytes), 256))
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        # keyed by the leasing stream as well: a block is only handed to work that is ordered behind its last use
+        self.key = (index, torch.cuda.current_stream(index).cuda_stream, max(int(nbytes), 256))
         free = _ws_pool.setdefault(self.key, [])
-        self.tensor = free.pop() if free else torch.empty(self.key[1], dtype=torch.uint8, device=device)
+        self.tensor = free.pop() if free else torch.empty(self.key[2], dtype=torch.uint8, device=device)
 
     def __del__(self) -> None:
         try:
