@@ -259,6 +259,12 @@ def main() -> None:
         run_step = lambda j: trainer.step(batches[j % n_batches], next_b=batches[(j + 1) % n_batches])  # noqa: E731
     else:
         run_step = lambda j: trainer.step(batches[j % n_batches])  # noqa: E731
+    if dist_on:      # everything that would stall the first sharded step happens before the spin-up: RCCL's lazy
+        # initialisation (first collective) and the first batch's exchange plan (a host sync)
+        warm = torch.zeros(world, dtype=torch.int64, device=device)
+        torch.distributed.all_to_all_single(torch.empty_like(warm), warm)
+        trainer.prefetch(batches[0])
+        torch.cuda.synchronize()
     spin_up(mf, device, "train")
     for i in range(W):
         run_step(i)
