@@ -449,10 +449,13 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void loss_fwd_dense
     RowStats st;
     stats_init(st);
 
+    TileSrc<D> tsrc;
+    mf_tile_src_init<D>(tsrc);
+    const int nYi = (int)p.N;
     auto stage = [&](int t) {
         const int k = t - t0;
         const int64_t j0 = (int64_t)t * 32;
-        mf_stage_tile<D>(smem + (k % 3) * G::TILEB, p.v, j0, p.N);
+        mf_stage_tile<D>(smem + (k % 3) * G::TILEB, p.v, t * 32, nYi, tsrc);
         char* aux = smem + L::AUX0 + (k & 3) * L::AUXB;
         mf_stage_small(aux + wave * 128, p.maskW + (int64_t)t * p.Bp + i0 + wave * 32, 128);
         mf_stage_small(aux + L::AUX_NV + wave * 128, (wave == 1 ? p.logq : p.nv) + j0, 128);   // 512: nv, 640: logq (zeros if none)
@@ -893,6 +896,9 @@ __global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss
         for (int e = 0; e < 16; ++e) dacc[mb][e] = 0.f;
     float rsum = 0.f;
 
+    TileSrc<D> tsrc;
+    mf_tile_src_init<D>(tsrc);
+    const int nYi = (int)nY;
     auto block_of = [&](int t) { return XU ? ((int64_t)xt * p.NT + t) : ((int64_t)t * p.NT + xt); };
     // piece j of the staging of tile t: 0..3 the wave's 4 KiB stash / G' block (into LDS, or -- SPREAD --
     // straight into the registers Gn), 4.. its share of the Y tile
@@ -907,7 +913,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss
             if (SPREAD) Gn[j] = *reinterpret_cast<const f32x4*>(lsrc + j * 1024);
             else __builtin_amdgcn_global_load_lds((mf_glb_ptr)(lsrc + j * 1024), (mf_lds_ptr)(slot + L::LT + wave * 4096 + j * 1024), 16, 0, 0);
         } else {
-            mf_stage_tile_piece<D>(slot, Y, (int64_t)t * 32, nY, j - 4);
+            mf_stage_tile_piece<D>(slot, Y, t * 32, nYi, j - 4, tsrc, mf_tile_interior<D>(t * 32, nYi));
         }
     };
     auto stage = [&](int t, int slot_idx) {

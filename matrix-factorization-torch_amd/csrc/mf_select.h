@@ -160,9 +160,12 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_kernel(
     int cnt = 0;
     if (lane < 32) floor64[lane] = 0ull;
 
+    TileSrc<D> tsrc;
+    mf_tile_src_init<D>(tsrc);
+    const int nYi = (int)sc.nY;
     auto stage = [&](int t) {
         const int kk = t - t0;
-        mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, sc.Y, (int64_t)t * 32, sc.nY);
+        mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, sc.Y, t * 32, nYi, tsrc);
         Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t, x0, L::W0);
         mf_stage_small<17>(smem + L::AUX0 + (kk & 3) * L::AUXB + L::GT0 + wave * 128, sc.gtau + x0, 128);
     };
@@ -411,9 +414,12 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_seed_ke
 #pragma unroll
     for (int i = 0; i < T; ++i) tl[i] = 0u;
 
+    TileSrc<D> tsrc;
+    mf_tile_src_init<D>(tsrc);
+    const int nYi = (int)sc.nY;
     auto stage = [&](int t) {
         const int kk = t - t0;
-        mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, sc.Y, (int64_t)t * 32, sc.nY);
+        mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, sc.Y, t * 32, nYi, tsrc);
         Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t, x0, L::W0);
     };
     auto mine_tile = [&](int t) { return (t - t0) % nsub == sub; };

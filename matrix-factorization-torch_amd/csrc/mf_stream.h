@@ -54,49 +54,100 @@ struct TileGeom {
     static __device__ __forceinline__ int swz(int row) { return CPR >= 16 ? (row & 15) : ((row >> 1) & 7); }
 };
 
+__device__ __forceinline__ unsigned mf_lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
 __device__ __forceinline__ int mf_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-// DMA piece q (0 .. PPW-1) of this wave's share of one tile (rows y0 .. y0+31 of Y, rows past nY clamped
-// to the last row) into `lds_tile`.
+// Per-lane source offsets of the DMA pieces, computed ONCE per kernel (PPW registers): piece q of this wave
+// covers bytes [(wave PPW + q) PIECEB, +PIECEB) of the tile's LDS image; lane l writes 16 bytes at + 16 l, and
+// reads them from row r, chunk ch ^ swz(r) of the source tile.  Inside the tile loop a piece is then ONE
+// global_load_lds with a wave-uniform base (SGPR pair) and this 32-bit lane offset -- no per-tile VALU
+// address arithmetic (measured in tools/lab/sweep_lab.hip: the generic per-piece index math the compiler
+// emits costs ~25 VALU instructions per piece, i.e. 3 % of the matrix pipe's time on its own).
 template <int D>
-__device__ __forceinline__ void mf_stage_tile_piece(char* lds_tile, const float* __restrict__ Y, int64_t y0, int64_t nY, int q) {
+struct TileSrc {
+    unsigned off[TileGeom<D>::PPW > 0 ? TileGeom<D>::PPW : 1];
+    int wave_pb;        // LDS byte offset of this wave's first piece inside a tile image (wave-uniform)
+};
+template <int D>
+__device__ __forceinline__ void mf_tile_src_init(TileSrc<D>& ts) {
     using G = TileGeom<D>;
     const int lane = mf_lane();
     const int wave = mf_wave_id();
-    const bool active = lane * 16 < G::PIECEB;                                 // d = 32 with 8 waves: half a wave per piece
-    const int pb = (wave * G::PPW + q) * G::PIECEB;
-    const int off = pb + (active ? lane * 16 : 0);
-    const int row = off / G::ROWB;
-    const int ch = ((off % G::ROWB) >> 4) ^ G::swz(row);
+    ts.wave_pb = __builtin_amdgcn_readfirstlane(wave * G::PPW * G::PIECEB);
+#pragma unroll
+    for (int q = 0; q < G::PPW; ++q) {
+        const int off = (wave * G::PPW + q) * G::PIECEB + ((lane * 16 < G::PIECEB) ? lane * 16 : 0);
+        const int row = off / G::ROWB;
+        const int ch = ((off % G::ROWB) >> 4) ^ G::swz(row);
+        ts.off[q] = (unsigned)(row * G::ROWB + ch * 16);
+        asm volatile("" : "+v"(ts.off[q]));          // keep it in a register: never rematerialised inside the loop
+    }
+}
+
+// DMA piece q (0 .. PPW-1) of this wave's share of one tile (rows y0 .. y0+31 of Y) into `lds_tile`.
+// INTERIOR (y0 + 32 <= nY, decided once per tile by the caller: wave-uniform): SGPR base + 32-bit lane offset.
+// Inline asm: the builtin form gets tail-merged with the ragged path into per-lane 64-bit address arithmetic
+// (7 VALU instructions per piece).  M0 (the LDS destination) is written and restored inside the statement
+// (cdna_hip_programming.md 5.7); the base is formed by scalar instructions only (kernel argument + loop
+// counter), so no VALU->SGPR hazard precedes it.  Otherwise (ragged last tile): rows past nY are clamped to
+// the last row (masked later by the kernels).
+template <int D>
+__device__ __forceinline__ void mf_stage_tile_piece(char* lds_tile, const float* __restrict__ Y, int y0, int nY, int q,
+                                                    const TileSrc<D>& ts, bool interior) {
+    using G = TileGeom<D>;
+    const bool active = mf_lane() * 16 < G::PIECEB;                            // (fewer than 64 lanes per piece only for short tiles)
+    const int pb = ts.wave_pb + q * G::PIECEB;
 #ifdef MF_ABL_SAMETILE      // A/B knob: always stage tile 0 (cache-resident) -- wrong results, measures the memory side
     y0 = 0;
 #endif
-    if (y0 + 32 <= nY) {
-        // interior tile: the per-lane offset depends only on (wave, lane, q) -> hoisted out of the tile loop
-        const char* tile_src = reinterpret_cast<const char*>(Y) + y0 * G::ROWB;   // wave-uniform
+    if (interior) {
+        const char* tile_src = reinterpret_cast<const char*>(Y) + (int64_t)y0 * G::ROWB;   // wave-uniform
+        const unsigned dst = mf_lds_addr(lds_tile) + (unsigned)pb;
+        unsigned keep;
         if (active)
-            __builtin_amdgcn_global_load_lds((mf_glb_ptr)(tile_src + row * G::ROWB + ch * 16), (mf_lds_ptr)(lds_tile + pb), 16, 0, 0);
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(ts.off[q]), "s"(tile_src), "s"(dst) : "memory");
     } else {
-        int64_t y = y0 + row;
-        y = y < nY ? y : nY - 1;                                               // ragged last tile: clamp (masked later)
-        const char* src = reinterpret_cast<const char*>(Y + y * D) + ch * 16;
+        const unsigned row = ts.off[q] / (unsigned)G::ROWB, rem = ts.off[q] % (unsigned)G::ROWB;
+        int y = y0 + (int)row;
+        y = y < nY ? y : nY - 1;
+        const char* src = reinterpret_cast<const char*>(Y) + (int64_t)y * G::ROWB + rem;
         if (active) __builtin_amdgcn_global_load_lds((mf_glb_ptr)src, (mf_lds_ptr)(lds_tile + pb), 16, 0, 0);
     }
 }
 template <int D>
-__device__ __forceinline__ void mf_stage_tile(char* lds_tile, const float* __restrict__ Y, int64_t y0, int64_t nY) {
+__device__ __forceinline__ bool mf_tile_interior(int y0, int nY) { return __builtin_expect(y0 + 32 <= nY, 1); }
+template <int D>
+__device__ __forceinline__ void mf_stage_tile(char* lds_tile, const float* __restrict__ Y, int y0, int nY, const TileSrc<D>& ts) {
+    if (mf_tile_interior<D>(y0, nY)) {
 #pragma unroll
-    for (int q = 0; q < TileGeom<D>::PPW; ++q) mf_stage_tile_piece<D>(lds_tile, Y, y0, nY, q);
+        for (int q = 0; q < TileGeom<D>::PPW; ++q) mf_stage_tile_piece<D>(lds_tile, Y, y0, nY, q, ts, true);
+    } else {
+#pragma unroll
+        for (int q = 0; q < TileGeom<D>::PPW; ++q) mf_stage_tile_piece<D>(lds_tile, Y, y0, nY, q, ts, false);
+    }
 }
 
 // DMA `nbytes` (multiple of 16, <= 1024) from src to lds_dst by the calling wave.
 // CPOL: cache-policy bits of the load (0 = default; 17 = sc0 sc1: read at L2, past a possibly stale L1 line)
 template <int CPOL = 0>
 __device__ __forceinline__ void mf_stage_small(char* lds_dst, const void* src, int nbytes) {
+    // `src` is wave-uniform (SGPR pair) -- the lane part is the 32-bit offset 16 * lane: no 64-bit VALU address
+    static_assert(CPOL == 0 || CPOL == 17, "cache policy: default or sc0 sc1");
     const int lane = mf_lane();
-    if (lane * 16 < nbytes)
-        __builtin_amdgcn_global_load_lds((mf_glb_ptr)(reinterpret_cast<const char*>(src) + lane * 16),
-                                         (mf_lds_ptr)lds_dst, 16, 0, CPOL);
+    const unsigned voff = (unsigned)lane * 16u;
+    const unsigned dst = mf_lds_addr(lds_dst);
+    unsigned keep;
+    if (lane * 16 < nbytes) {
+        if (CPOL == 0)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc0 sc1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
+    }
 }
 // fire-and-forget device-scope max (no return value, so no wait is ever attached to it); sc1: performed
 // past the XCD's own L2, so that workgroups on the other XCDs see it (the L2s are not coherent)
@@ -109,9 +160,6 @@ __device__ __forceinline__ void mf_global_umax(unsigned* p, unsigned v) {
 // not alias the DMA destination).  These go through inline asm instead; the "memory" clobber keeps
 // their order against the surrounding C++ accesses, and the LDS itself executes a wave's
 // operations in order.
-__device__ __forceinline__ unsigned mf_lds_addr(const void* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
 __device__ __forceinline__ void mf_lds_store_b64(void* p, unsigned lo, unsigned hi) {
     const unsigned long long v = ((unsigned long long)hi << 32) | lo;
     asm volatile("ds_write_b64 %0, %1" ::"v"(mf_lds_addr(p)), "v"(v) : "memory");

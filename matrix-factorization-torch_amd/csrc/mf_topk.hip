@@ -167,7 +167,7 @@ extern "C" int mf_topk(const float* q, int64_t Q, const float* items, int64_t N,
         return mf_set_error(MF_EINVAL, "mf_topk: bad argument");
     if (k <= 0 || k > 64) return mf_set_error(MF_ENOTSUP, "mf_topk: k = %d outside 1..64", k);
     if (!mf_width_ok(d)) return mf_set_error(MF_EINVAL, "mf_topk: embedding width %d not in {32,64,128,256}", d);
-    if (N >= (1ll << 32) || idx_base < 0 || idx_base + N > (1ll << 32))
+    if (N >= (1ll << 31) || idx_base < 0 || idx_base + N > (1ll << 32))
         return mf_set_error(MF_ENOTSUP, "mf_topk: item indices must fit 32 bits");
     if ((excl_off == nullptr) != (excl_idx == nullptr)) return mf_set_error(MF_EINVAL, "mf_topk: excl_off/excl_idx mismatch");
     if (ws_bytes < mf_topk_ws_bytes(Q, N, d, k)) return mf_set_error(MF_ENOSPC, "mf_topk: workspace too small");
