@@ -46,13 +46,13 @@ struct LossWs {
     int T, CAP, nchunk, tpc;      // mining select geometry (nchunk = candidate sets per row)
     int NW;                       // waves per workgroup of the sweeps (mf_nw(d))
     SelectPlan plan;
-    float *nu, *nv, *lii, *dii, *sgn, *logq;
+    float *nu, *nv, *lii, *dii, *sgn, *logq;      // logq: zero-padded NEGATED copy (-logq_j)
     long long* gtab;
     int M;
     int32_t *colslot, *gfirst, *colfirst;
     uint32_t* ubits;
     uint32_t* maskW;
-    float *part, *stats, *rowloss, *rowc, *dpart, *stash, *gstash, *blockpart;
+    float *part, *stats, *rowloss, *rowc, *dpart, *rpart, *stash, *gstash, *blockpart;
     unsigned* ticket;
     unsigned long long *cand, *priv, *seeds;
     int32_t *cand_cnt, *sel, *sel_cnt;
@@ -126,6 +126,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
         size_t rows_v = (size_t)w.nsplit_v * w.Np;
         if (rows_v > rows) rows = rows_v;
         w.dpart = a.take<float>(rows * d);
+        w.rpart = a.take<float>(rows);
         w.stash = a.take<float>((size_t)w.Bp * w.Np);
         w.gstash = a.take<float>((size_t)w.Bp * w.Np);
     }
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64) void prep_kernel(PrepParams p) {
         }
         p.nv[i] = nvv;
         const float lq = (p.logq && hv) ? p.logq[i] : 0.f;
-        p.wlogq[i] = lq;
+        p.wlogq[i] = -lq;                 // the sweeps read -logq (one fma operand, no negation in the loop)
         if (i < p.Bp) {
             float l = 0.f, dd = 0.f, sg = 0.f;
             if (hu) {
@@ -450,12 +451,11 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void loss_fwd_dense
     stats_init(st);
 
     TileSrc<D> tsrc;
-    mf_tile_src_init<D>(tsrc);
-    const int nYi = (int)p.N;
+    mf_tile_src_init<D>(tsrc, p.v, p.N, (int64_t)t0 * 32);
     auto stage = [&](int t) {
         const int k = t - t0;
         const int64_t j0 = (int64_t)t * 32;
-        mf_stage_tile<D>(smem + (k % 3) * G::TILEB, p.v, t * 32, nYi, tsrc);
+        mf_stage_tile<D>(smem + (k % 3) * G::TILEB, t * 32, tsrc);
         char* aux = smem + L::AUX0 + (k & 3) * L::AUXB;
         mf_stage_small(aux + wave * 128, p.maskW + (int64_t)t * p.Bp + i0 + wave * 32, 128);
         mf_stage_small(aux + L::AUX_NV + wave * 128, (wave == 1 ? p.logq : p.nv) + j0, 128);   // 512: nv, 640: logq (zeros if none)
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void loss_fwd_dense
             }
             // masked logit: -inf where the column is not a valid negative -> every statistic below and
             // every dloss/dL of the backward is exactly 0 there, with no further mask test
-            const float Lraw = mf_logit(nu_i, nv4[r], acc[e], s_i, p.sigma, lq4[r]);
+            const float Lraw = mf_logit(nu_i, nv4[r], acc[e], s_i, p.sigma, -lq4[r]);      // lq4 holds -logq
             Lg[e] = (mw & (1u << mf_acc_row(e, 0))) ? -INFINITY : Lraw;
             tmax = fmaxf(tmax, Lg[e]);
             if (r == 3) {   // stash 4 masked logits of the block for the backward sweeps
@@ -696,7 +696,7 @@ struct MiningPolicy {
     }
     static __device__ __forceinline__ bool maybe(const Params& p, const Row& r, const Tile& t, float score, int e, int,
                                                  const Thr& th) {
-        const float L = mf_logit(r.nu, t.nv4[e >> 2][e & 3], score, r.sgn, p.sigma, t.lq4[e >> 2][e & 3]);
+        const float L = mf_logit(r.nu, t.nv4[e >> 2][e & 3], score, r.sgn, p.sigma, -t.lq4[e >> 2][e & 3]);   // lq4 holds -logq
         const float dm = L - r.lii;
         return dm >= th.lo && dm <= th.hi;
     }
@@ -721,7 +721,7 @@ struct MiningPolicy {
     }
     static __device__ __forceinline__ bool key(const Params& p, const Row& r, const Tile& t, float score, int e, int h,
                                                unsigned y, unsigned& hi, unsigned& lo) {
-        const float L = mf_logit(r.nu, t.nv4[e >> 2][e & 3], score, r.sgn, p.sigma, t.lq4[e >> 2][e & 3]);
+        const float L = mf_logit(r.nu, t.nv4[e >> 2][e & 3], score, r.sgn, p.sigma, -t.lq4[e >> 2][e & 3]);
         const float dm = L - r.lii;
         hi = mf_key_mining_hi(dm);
         lo = mf_key_mining_lo(dm, y);
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void mined_stats_kernel(const float* __restric
         for (int t = 0; t < n; ++t) {
             const int64_t j = sel[i * KSEL_MAX + t];
             const float dot = mf_dot_chain(u + i * d, v + j * d, d);
-            const float L = mf_logit(nu[i], nv[j], dot, s_i, sigma, logq ? logq[j] : 0.f);
+            const float L = mf_logit(nu[i], nv[j], dot, s_i, sigma, logq ? -logq[j] : 0.f);     // ws copy holds -logq
             sel_L[i * KSEL_MAX + t] = L;
             stats_add(st, need, L, sm, l, margin);
             if (need & NEED_LSE) lse_merge(st.mx, st.se, L, 1.f);
@@ -847,6 +847,7 @@ struct BwdParams {
     const float* stash;      // masked logits (forward); stays intact so that a backward can be repeated
     float* gstash;           // G' = dloss/dL blocks: written by the dU sweep, read by the dV sweep
     float* dpart;
+    float* rpart;            // [split][Xp] partial row sums of G'
     int64_t B, N, Bp, Np;
     int NT, YT, tps;
 };
@@ -897,8 +898,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss
     float rsum = 0.f;
 
     TileSrc<D> tsrc;
-    mf_tile_src_init<D>(tsrc);
-    const int nYi = (int)nY;
+    mf_tile_src_init<D>(tsrc, Y, nY, (int64_t)t0 * 32);
     auto block_of = [&](int t) { return XU ? ((int64_t)xt * p.NT + t) : ((int64_t)t * p.NT + xt); };
     // piece j of the staging of tile t: 0..3 the wave's 4 KiB stash / G' block (into LDS, or -- SPREAD --
     // straight into the registers Gn), 4.. its share of the Y tile
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss
             if (SPREAD) Gn[j] = *reinterpret_cast<const f32x4*>(lsrc + j * 1024);
             else __builtin_amdgcn_global_load_lds((mf_glb_ptr)(lsrc + j * 1024), (mf_lds_ptr)(slot + L::LT + wave * 4096 + j * 1024), 16, 0, 0);
         } else {
-            mf_stage_tile_piece<D>(slot, Y, t * 32, nYi, j - 4, tsrc, mf_tile_interior<D>(t * 32, nYi));
+            mf_stage_tile_piece<D>(slot, t * 32, j - 4, tsrc);
         }
     };
     auto stage = [&](int t, int slot_idx) {
@@ -973,15 +973,22 @@ __global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss
 #pragma unroll
         for (int e = 0; e < 16; ++e) rsum += Gv[e];
         // dX[m][x] += sum_y Y[y][m] * G[y][x]   (the G tile is already a B operand)
+        // (the Y fragment of step t + 1 is read before the MFMAs of step t are issued)
         const bool more = ty + 1 < t1;
+        float yv[D / 32];
+        mf_lds_cols<D>(yv, slot, mf_acc_row(0, h), c);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            float yv[D / 32];
-            mf_lds_cols<D>(yv, slot, mf_acc_row(t, h), c);
+            float yn[D / 32];
+            if (t + 1 < 16) mf_lds_cols<D>(yn, slot, mf_acc_row(t + 1, h), c);
             if (SPREAD && t < L::NDMA && more) stage_piece(ty + 1, cur ^ 1, t);
 #pragma unroll
             for (int j = 0; j < D / 32; ++j)
                 dacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv[j], Gv[t], dacc[j], 0, 0, 0);
+            if (t + 1 < 16) {
+#pragma unroll
+                for (int j = 0; j < D / 32; ++j) yv[j] = yn[j];
+            }
         }
         if (!SPREAD && L::NSLOT == 2) {            // the slot just read is the one tile ty+2 lands in
             mf_block_barrier();
@@ -989,30 +996,47 @@ __global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss
         }
         cur = cur + 1 == L::NSLOT ? 0 : cur + 1;
     }
+    mf_wait_vmcnt<0>();                 // nothing of this workgroup may still be on its way into LDS when it ends
     rsum += mf_shfl_xor32(rsum);
-    // dX[x][m] = dacc - rsum * X[x][m];  register e of block j is feature m = NB * row(e, h) + j
+    // dX[x][m] = sum over splits of (dacc - rsum * X[x][m]): this sweep writes its partial dacc (register e of
+    // block j is feature m = NB * row(e, h) + j: NB consecutive floats per register index) and its partial row sum;
+    // sum_parts_kernel adds the splits in order and applies the X term once.
     if (x < nX) {
         constexpr int NB = D / 32;
         float* o = p.dpart + ((int64_t)blockIdx.x * Xp + x) * D;
-        const float* xr = X + x * D;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m0 = NB * mf_acc_row(e, h);
+            if constexpr (NB == 4) {
+                *reinterpret_cast<f32x4*>(o + m0) = f32x4{dacc[0][e], dacc[1][e], dacc[2][e], dacc[3][e]};
+            } else if constexpr (NB == 8) {
+                *reinterpret_cast<f32x4*>(o + m0) = f32x4{dacc[0][e], dacc[1][e], dacc[2][e], dacc[3][e]};
+                *reinterpret_cast<f32x4*>(o + m0 + 4) = f32x4{dacc[4][e], dacc[5][e], dacc[6][e], dacc[7][e]};
+            } else {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) o[m0 + j] = dacc[j][e] - rsum * xr[m0 + j];
+                for (int j = 0; j < NB; ++j) o[m0 + j] = dacc[j][e];
+            }
         }
+        if (h == 0) p.rpart[(int64_t)blockIdx.x * Xp + x] = rsum;
     }
 }
 
-__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ dpart, int nsplit, int64_t rows,
+// out[r] = sum over splits (in split order) of dpart[s][r]  -  (sum over splits of rpart[s][r]) * X[r]
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ dpart, const float* __restrict__ rpart,
+                                                        const float* __restrict__ X, int nsplit, int64_t rows,
                                                         int64_t rows_p, int d, float* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one float4 each
     const int64_t per_row = d / 4;
     if (t >= rows * per_row) return;
     const int64_t r = t / per_row, cidx = t % per_row;
     f32x4 acc = reinterpret_cast<const f32x4*>(dpart + r * d)[cidx];
-    for (int s = 1; s < nsplit; ++s) acc += reinterpret_cast<const f32x4*>(dpart + ((int64_t)s * rows_p + r) * d)[cidx];
-    reinterpret_cast<f32x4*>(out + r * d)[cidx] = acc;
+    float rs = rpart[r];
+    for (int s = 1; s < nsplit; ++s) {
+        acc += reinterpret_cast<const f32x4*>(dpart + ((int64_t)s * rows_p + r) * d)[cidx];
+        rs += rpart[(int64_t)s * rows_p + r];
+    }
+    const f32x4 xr = reinterpret_cast<const f32x4*>(X + r * d)[cidx];
+    reinterpret_cast<f32x4*>(out + r * d)[cidx] = acc - rs * xr;
 }
 
 // alignment-only backward: only the diagonal carries gradient
@@ -1233,14 +1257,14 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
                                                                                         w.Bp, gmode, du, dv);
         });
     } else {
-        BwdParams bp{u, v, w.rowc, w.stash, w.gstash, w.dpart, B, N, w.Bp, w.Np, w.NT, 0, 0};
+        BwdParams bp{u, v, w.rowc, w.stash, w.gstash, w.dpart, w.rpart, B, N, w.Bp, w.Np, w.NT, 0, 0};
         MF_DISPATCH_D(d, {
             bp.YT = w.NT; bp.tps = w.tps_u;
             MF_TIMED("loss_bwd_du", s, (launch_bwd<D, true>(gmode, dim3((unsigned)w.nsplit_u, (unsigned)(w.BT / w.NW)), bp, s)));
-            sum_parts_kernel<<<dim3((unsigned)((B * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_u, B, w.Bp, D, du);
+            sum_parts_kernel<<<dim3((unsigned)((B * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.rpart, u, w.nsplit_u, B, w.Bp, D, du);
             bp.YT = w.BT; bp.tps = w.tps_v;
             MF_TIMED("loss_bwd_dv", s, (launch_bwd<D, false>(G_EXP, dim3((unsigned)w.nsplit_v, (unsigned)(w.NT / w.NW)), bp, s)));
-            sum_parts_kernel<<<dim3((unsigned)((N * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.nsplit_v, N, w.Np, D, dv);
+            sum_parts_kernel<<<dim3((unsigned)((N * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.rpart, v, w.nsplit_v, N, w.Np, D, dv);
         });
     }
     return mf_check_launch("mf_loss_bwd");

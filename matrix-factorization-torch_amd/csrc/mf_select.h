@@ -161,11 +161,10 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_kernel(
     if (lane < 32) floor64[lane] = 0ull;
 
     TileSrc<D> tsrc;
-    mf_tile_src_init<D>(tsrc);
-    const int nYi = (int)sc.nY;
+    mf_tile_src_init<D>(tsrc, sc.Y, sc.nY, (int64_t)t0 * 32);
     auto stage = [&](int t) {
         const int kk = t - t0;
-        mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, sc.Y, t * 32, nYi, tsrc);
+        mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, t * 32, tsrc);
         Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t, x0, L::W0);
         mf_stage_small<17>(smem + L::AUX0 + (kk & 3) * L::AUXB + L::GT0 + wave * 128, sc.gtau + x0, 128);
     };
@@ -415,11 +414,10 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_seed_ke
     for (int i = 0; i < T; ++i) tl[i] = 0u;
 
     TileSrc<D> tsrc;
-    mf_tile_src_init<D>(tsrc);
-    const int nYi = (int)sc.nY;
+    mf_tile_src_init<D>(tsrc, sc.Y, sc.nY, (int64_t)t0 * 32);
     auto stage = [&](int t) {
         const int kk = t - t0;
-        mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, sc.Y, t * 32, nYi, tsrc);
+        mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, t * 32, tsrc);
         Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t, x0, L::W0);
     };
     auto mine_tile = [&](int t) { return (t - t0) % nsub == sub; };

@@ -59,22 +59,40 @@ __device__ __forceinline__ unsigned mf_lds_addr(const void* p) {
 }
 __device__ __forceinline__ int mf_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-// Per-lane source offsets of the DMA pieces, computed ONCE per kernel (PPW registers): piece q of this wave
-// covers bytes [(wave PPW + q) PIECEB, +PIECEB) of the tile's LDS image; lane l writes 16 bytes at + 16 l, and
-// reads them from row r, chunk ch ^ swz(r) of the source tile.  Inside the tile loop a piece is then ONE
-// global_load_lds with a wave-uniform base (SGPR pair) and this 32-bit lane offset -- no per-tile VALU
-// address arithmetic (measured in tools/lab/sweep_lab.hip: the generic per-piece index math the compiler
-// emits costs ~25 VALU instructions per piece, i.e. 3 % of the matrix pipe's time on its own).
+// Tile source of a workgroup: a raw buffer descriptor over the rows [row0, nY) of Y plus the per-lane source
+// offsets of the DMA pieces, both computed ONCE per kernel.  Piece q of this wave covers bytes
+// [(wave PPW + q) PIECEB, +PIECEB) of the tile's LDS image; lane l writes 16 bytes at + 16 l and reads them from
+// row r, chunk ch ^ swz(r) of the source tile.  Inside the tile loop a piece is then ONE
+//     buffer_load_dwordx4 v_off, s[rsrc], s_tile_offset offen lds
+// -- no per-tile VALU address arithmetic (measured in tools/lab/sweep_lab.hip: the generic per-piece index math
+// the compiler otherwise emits costs ~25 VALU instructions per piece, 3 % of the matrix pipe's time) and no
+// ragged-tile branch: the hardware range check covers voffset + soffset at dword granularity (measured:
+// tools/lab/srd_bounds.hip), so rows past nY arrive as ZEROS (the kernels mask them anyway).  The descriptor
+// starts at the workgroup's first row, so offsets stay below 4 GiB for any catalog.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t mf_rsrc_t;
+#else
+struct mf_rsrc_t { int w[4]; };     // host pass of hipcc: the target type does not exist there (never executed)
+#endif
 template <int D>
 struct TileSrc {
+    mf_rsrc_t rsrc;
     unsigned off[TileGeom<D>::PPW > 0 ? TileGeom<D>::PPW : 1];
     int wave_pb;        // LDS byte offset of this wave's first piece inside a tile image (wave-uniform)
+    int row0;
 };
 template <int D>
-__device__ __forceinline__ void mf_tile_src_init(TileSrc<D>& ts) {
+__device__ __forceinline__ void mf_tile_src_init(TileSrc<D>& ts, const float* __restrict__ Y, int64_t nY, int64_t row0) {
     using G = TileGeom<D>;
     const int lane = mf_lane();
     const int wave = mf_wave_id();
+    // row0 / nY derive from kernel arguments and blockIdx only: the descriptor is provably wave-uniform (no waterfall loop)
+    int64_t bytes = (nY - row0) * (int64_t)G::ROWB;
+    bytes = bytes < 0 ? 0 : (bytes > 0xFFFFF000ll ? 0xFFFFF000ll : bytes);
+#if defined(__HIP_DEVICE_COMPILE__)
+    ts.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Y + row0 * D), 0, (int)(unsigned)bytes, 0x00020000);
+#endif
+    ts.row0 = (int)row0;
     ts.wave_pb = __builtin_amdgcn_readfirstlane(wave * G::PPW * G::PIECEB);
 #pragma unroll
     for (int q = 0; q < G::PPW; ++q) {
@@ -86,48 +104,26 @@ __device__ __forceinline__ void mf_tile_src_init(TileSrc<D>& ts) {
     }
 }
 
-// DMA piece q (0 .. PPW-1) of this wave's share of one tile (rows y0 .. y0+31 of Y) into `lds_tile`.
-// INTERIOR (y0 + 32 <= nY, decided once per tile by the caller: wave-uniform): SGPR base + 32-bit lane offset.
-// Inline asm: the builtin form gets tail-merged with the ragged path into per-lane 64-bit address arithmetic
-// (7 VALU instructions per piece).  M0 (the LDS destination) is written and restored inside the statement
-// (cdna_hip_programming.md 5.7); the base is formed by scalar instructions only (kernel argument + loop
-// counter), so no VALU->SGPR hazard precedes it.  Otherwise (ragged last tile): rows past nY are clamped to
-// the last row (masked later by the kernels).
+// DMA piece q (0 .. PPW-1) of this wave's share of the tile of rows y0 .. y0+31 into `lds_tile`
 template <int D>
-__device__ __forceinline__ void mf_stage_tile_piece(char* lds_tile, const float* __restrict__ Y, int y0, int nY, int q,
-                                                    const TileSrc<D>& ts, bool interior) {
+__device__ __forceinline__ void mf_stage_tile_piece(char* lds_tile, int y0, int q, const TileSrc<D>& ts) {
     using G = TileGeom<D>;
     const bool active = mf_lane() * 16 < G::PIECEB;                            // (fewer than 64 lanes per piece only for short tiles)
-    const int pb = ts.wave_pb + q * G::PIECEB;
-#ifdef MF_ABL_SAMETILE      // A/B knob: always stage tile 0 (cache-resident) -- wrong results, measures the memory side
-    y0 = 0;
+#ifdef MF_ABL_SAMETILE      // A/B knob: always stage the first tile (cache-resident) -- wrong results, measures the memory side
+    y0 = ts.row0;
 #endif
-    if (interior) {
-        const char* tile_src = reinterpret_cast<const char*>(Y) + (int64_t)y0 * G::ROWB;   // wave-uniform
-        const unsigned dst = mf_lds_addr(lds_tile) + (unsigned)pb;
-        unsigned keep;
-        if (active)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(ts.off[q]), "s"(tile_src), "s"(dst) : "memory");
-    } else {
-        const unsigned row = ts.off[q] / (unsigned)G::ROWB, rem = ts.off[q] % (unsigned)G::ROWB;
-        int y = y0 + (int)row;
-        y = y < nY ? y : nY - 1;
-        const char* src = reinterpret_cast<const char*>(Y) + (int64_t)y * G::ROWB + rem;
-        if (active) __builtin_amdgcn_global_load_lds((mf_glb_ptr)src, (mf_lds_ptr)(lds_tile + pb), 16, 0, 0);
-    }
+    const int soff = (y0 - ts.row0) * G::ROWB;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (active)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ts.rsrc, (mf_lds_ptr)(lds_tile + ts.wave_pb + q * G::PIECEB), 16, (int)ts.off[q], soff, 0, 0);
+#else
+    (void)active; (void)soff; (void)lds_tile;
+#endif
 }
 template <int D>
-__device__ __forceinline__ bool mf_tile_interior(int y0, int nY) { return __builtin_expect(y0 + 32 <= nY, 1); }
-template <int D>
-__device__ __forceinline__ void mf_stage_tile(char* lds_tile, const float* __restrict__ Y, int y0, int nY, const TileSrc<D>& ts) {
-    if (mf_tile_interior<D>(y0, nY)) {
+__device__ __forceinline__ void mf_stage_tile(char* lds_tile, int y0, const TileSrc<D>& ts) {
 #pragma unroll
-        for (int q = 0; q < TileGeom<D>::PPW; ++q) mf_stage_tile_piece<D>(lds_tile, Y, y0, nY, q, ts, true);
-    } else {
-#pragma unroll
-        for (int q = 0; q < TileGeom<D>::PPW; ++q) mf_stage_tile_piece<D>(lds_tile, Y, y0, nY, q, ts, false);
-    }
+    for (int q = 0; q < TileGeom<D>::PPW; ++q) mf_stage_tile_piece<D>(lds_tile, y0, q, ts);
 }
 
 // DMA `nbytes` (multiple of 16, <= 1024) from src to lds_dst by the calling wave.
