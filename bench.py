@@ -110,6 +110,7 @@ class Trainer:
         if optimizer == "adam":
             self.opt.init_state()              # moment tables allocated here, not inside the first step
         self.logq = logq_table(device)
+        self.one = torch.ones((), device=device)      # upstream gradient of loss.backward(): no fill kernel per step
 
     def item_matrix(self) -> torch.Tensor:
         return self.towers["item"](torch.arange(NUM_ITEMS, device=self.logq.device)).detach()
@@ -124,9 +125,10 @@ class Trainer:
                  if os.environ.get("MF_BENCH_PREPARE", "0") == "1" else None)
         u = self.towers["user"](b["user"])
         v = self.towers["item"](b["item"])
-        loss = self.loss_fn(u, v, b["target"], item_idx=b["item"], pos_idx=b["pos"], logq=self.logq[b["item"]],
+        # the int64 targets and the logQ table go to the kernel as they are (converted / looked up in its set-up launch)
+        loss = self.loss_fn(u, v, b["target"], item_idx=b["item"], pos_idx=b["pos"], logq_table=self.logq,
                             prepared=masks)
-        loss.backward()
+        loss.backward(self.one)
         self.opt.step()
         return loss
 

@@ -111,9 +111,14 @@ int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64_t* sorted_
  * Replaces `EmbeddingLoss.forward` for all seven classes
  * (xfmr_rec/losses.py:39-52; call site xfmr_rec/lightning.py:137-146):
  *   u[B,d] user_embed, v[N,d] item_embed (N >= B; row j < B is the positive of
- *   user j), target[B] (fp32 copy of the rating), item_idx[N], pos_idx[B,P]
- *   (0-padded, nullable with P = 0), logq[N] (nullable; our logQ correction
- *   L_ij -= logq[j]).
+ *   user j), target[B] (the rating: fp32, or the reference's int64 with MF_LOSS_TARGET_I64),
+ *   item_idx[N], pos_idx[B,P] (0-padded, nullable with P = 0), logq (nullable; our logQ
+ *   correction L_ij -= logq_j: one value per column, logq[N], when logq_rows = 0, else a
+ *   table of logq_rows values looked up by the batch ids, logq_j = logq[item_idx[j]],
+ *   ids outside the table counting as 0 -- which needs item_idx != NULL).
+ * flags: MF_LOSS_TARGET_I64 (target is int64), MF_LOSS_ROWC (kind_mask has ONE bit set and that
+ *   loss will be differentiated: the forward's tail also prepares the backward's per-row
+ *   coefficients, and mf_loss_bwd is then called with MF_LOSS_ROWC too and skips that launch).
  * kind_mask selects which losses to evaluate in the one pass (bit k = kind k);
  * out_losses[7] receives them (the entries of the other kinds are set to 0).  The workspace keeps
  * the per-row statistics / mined negatives for mf_loss_bwd and must stay intact
@@ -130,19 +135,21 @@ int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64_t* sorted_
 size_t mf_loss_ws_bytes(int64_t B, int64_t N, int d, int P, int num_negatives);
 int mf_loss_masks(int64_t B, int64_t N, int d, int P, int num_negatives, const int64_t* item_idx,
                   const int64_t* pos_idx, void* ws, size_t ws_bytes, mf_stream_t stream);
+enum { MF_LOSS_TARGET_I64 = 1, MF_LOSS_ROWC = 2 };
 int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
-                int kind_mask, const float* u, const float* v, const float* target,
-                const int64_t* item_idx, const int64_t* pos_idx, const float* logq, void* ws,
-                size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits, mf_stream_t stream);
+                int kind_mask, const float* u, const float* v, const void* target,
+                const int64_t* item_idx, const int64_t* pos_idx, const float* logq, int64_t logq_rows,
+                int flags, void* ws, size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits,
+                mf_stream_t stream);
 
 /* Backward of one loss of the preceding mf_loss_fwd (same shapes/hyper-parameters,
  * same ws): du[B,d] = grad_out * dloss/du, dv[N,d] = grad_out * dloss/dv, with
  * grad_out a device scalar.  Masks and mining are constants of the backward
- * (@torch.no_grad in the reference, losses.py:92,134). */
+ * (@torch.no_grad in the reference, losses.py:92,134).  The targets and logQ values are the
+ * workspace's copies of the forward's.  flags: MF_LOSS_ROWC as above. */
 int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
-                int kind, const float* u, const float* v, const float* target, const float* logq,
-                void* ws, size_t ws_bytes, const float* grad_out, float* du, float* dv,
-                mf_stream_t stream);
+                int kind, const float* u, const float* v, int flags, void* ws, size_t ws_bytes,
+                const float* grad_out, float* du, float* dv, mf_stream_t stream);
 
 /* API parity with the public helper methods of EmbeddingLoss, on caller-provided tensors (not the
  * hot path): negative_masks (losses.py:92-110) -> out_mask[B,N] bytes, 1 = valid negative;

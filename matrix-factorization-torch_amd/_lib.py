@@ -35,8 +35,8 @@ SIGNATURES = {
     "mf_loss_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int, c_int]),
     "mf_loss_masks": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mf_loss_fwd": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp,
-                            c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
-    "mf_loss_bwd": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp,
+                            c_vp, c_vp, c_i64, c_int, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "mf_loss_bwd": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_int,
                             c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
     "mf_negative_masks_ws_bytes": (c_sz, [c_i64, c_i64, c_int]),
     "mf_negative_masks": (c_int, [c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp]),
@@ -52,6 +52,8 @@ SIGNATURES = {
     "mf_retrieval_metrics": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mf_topk_merge": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
 }
+
+LOSS_TARGET_I64, LOSS_ROWC = 1, 2     # flags of mf_loss_fwd / mf_loss_bwd (include/mf_hip.h)
 
 _lib: ctypes.CDLL | None = None
 

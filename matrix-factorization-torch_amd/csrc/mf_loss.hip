@@ -47,6 +47,7 @@ struct LossWs {
     int NW;                       // waves per workgroup of the sweeps (mf_nw(d))
     SelectPlan plan;
     float *nu, *nv, *lii, *dii, *sgn, *logq;      // logq: zero-padded NEGATED copy (-logq_j)
+    float* tgt;                                  // fp32 copy of the targets (the forward may receive int64)
     long long* gtab;
     int M;
     int32_t *colslot, *gfirst, *colfirst;
@@ -96,6 +97,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.nu = a.take<float>(w.Bp); w.nv = a.take<float>(w.Np);
     w.lii = a.take<float>(w.Bp); w.dii = a.take<float>(w.Bp); w.sgn = a.take<float>(w.Bp);
     w.logq = a.take<float>(w.Np);
+    w.tgt = a.take<float>(w.Bp);
     (void)P;
     w.M = 64;
     while (w.M < 2 * w.Np) w.M *= 2;
@@ -144,11 +146,16 @@ extern "C" size_t mf_loss_ws_bytes(int64_t B, int64_t N, int d, int P, int num_n
 // diagonal (L_ii, D_ii, sign), the zero-padded logQ copy, and the clearing of the hash table, the
 // per-user bit rows and the reduction ticket.  (Each of these used to be its own ~5 us launch.)
 struct PrepParams {
-    const float *u, *v, *target, *logq;
+    const float *u, *v;
+    const void* target;
+    const float* logq;
+    const int64_t* item_idx;      // logq_rows > 0: logq is a table looked up by these ids
+    int64_t logq_rows;
+    int target_i64;
     int64_t B, N, Bp, Np;
     int d;
     float sigma;
-    float *nu, *nv, *lii, *dii, *sgn, *wlogq;
+    float *nu, *nv, *lii, *dii, *sgn, *wlogq, *wtgt;
     uint4* gtab; int64_t gtab16;        // fills, in 16-byte units (0 = skip)
     uint4* gfirst; int64_t gfirst16;
     uint4* ubits; int64_t ubits16;
@@ -182,16 +189,26 @@ __global__ __launch_bounds__(64) void prep_kernel(PrepParams p) {
             }
         }
         p.nv[i] = nvv;
-        const float lq = (p.logq && hv) ? p.logq[i] : 0.f;
+        float lq = 0.f;
+        if (p.logq && hv) {
+            if (p.logq_rows > 0) {
+                const int64_t id = p.item_idx[i];
+                lq = (id >= 0 && id < p.logq_rows) ? p.logq[id] : 0.f;
+            } else {
+                lq = p.logq[i];
+            }
+        }
         p.wlogq[i] = -lq;                 // the sweeps read -logq (one fma operand, no negation in the loop)
         if (i < p.Bp) {
             float l = 0.f, dd = 0.f, sg = 0.f;
+            float tg = 0.f;
             if (hu) {
-                sg = mf_sign(p.target[i]);
+                tg = p.target_i64 ? (float)static_cast<const int64_t*>(p.target)[i] : static_cast<const float*>(p.target)[i];
+                sg = mf_sign(tg);
                 dd = mf_half_sqdist(nuu, nvv, dot);
                 l = mf_logit(nuu, nvv, dot, sg, p.sigma, lq);
             }
-            p.nu[i] = nuu; p.lii[i] = l; p.dii[i] = dd; p.sgn[i] = sg;
+            p.nu[i] = nuu; p.lii[i] = l; p.dii[i] = dd; p.sgn[i] = sg; p.wtgt[i] = tg;
         }
     }
     if (i == 0) *p.ticket = 0u;
@@ -563,6 +580,30 @@ static void launch_fwd(int need, dim3 grid, const FwdParams& fp, hipStream_t s) 
     }
 }
 
+// Per-row coefficients of dloss/dL for loss `kind`, WITHOUT the upstream gradient (the backward kernels scale
+// by grad_out[0]):  rowc[0] = a, rowc[1] = b, rowc[2] = coefG, rowc[3] = gdiag  with, for element (i, j),
+//   G'_ij = coefG_i * g((L_ij - a_i) + b_i)   (valid negatives),  G'_ii = gdiag_i,
+//   du_i = sum_j G'_ij (v_j - u_i),  dv_j = sum_i G'_ij (u_i - v_j).
+__device__ __forceinline__ void rowc_row(int kind, float t, float s, float l, float cnt, float mx, float se, float hc,
+                                         float ls, float sigma, float margin, float& a, float& b, float& cg, float& gd) {
+    a = b = cg = gd = 0.f;
+    const float base = sigma * s * fabsf(t);
+    const float den = cnt + 1e-10f;
+    switch (kind) {
+        case MF_ALIGNMENT: gd = -base; break;
+        case MF_CONTRASTIVE: b = s * margin; cg = base / den; break;
+        case MF_ALIGNMENT_CONTRASTIVE: b = s * margin; cg = base / den; gd = -base; break;
+        case MF_INFONCE: {
+            const float m2 = fmaxf(mx, l);
+            const float lse = m2 + __logf(se * __expf(mx - m2) + __expf(l - m2));
+            a = lse; cg = base; gd = base * (__expf(l - lse) - 1.f);
+        } break;
+        case MF_MINE: a = cnt > 0.f ? mx + __logf(se) : 0.f; cg = cnt > 0.f ? base : 0.f; gd = -base; break;
+        case MF_PAIRWISE_HINGE: a = l; b = margin; cg = base / den; gd = -cg * hc; break;
+        case MF_PAIRWISE_LOGISTIC: a = l; b = margin; cg = base / den; gd = -cg * ls; break;
+    }
+}
+
 // The tail of the forward in ONE launch: merge the item-range splits of the row statistics in split
 // order (nsplit = 0: `stats` is already final), evaluate the seven per-row losses, and sum them over
 // the batch in a fixed order: in-block tree, then the last workgroup to finish (ticket) adds the
@@ -572,7 +613,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
                                                      const float* __restrict__ dii, float sigma, int kind_mask,
                                                      float* __restrict__ stats, float* __restrict__ rowloss,
                                                      float* __restrict__ blockpart, unsigned* __restrict__ ticket,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, int rowc_kind, float margin,
+                                                     const float* __restrict__ sgn, float* __restrict__ rowc) {
     __shared__ float sh[MF_NUM_KINDS][256];
     __shared__ bool last;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -618,6 +660,12 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
         o[MF_MINE] = (-l + lse_neg) * w;
         o[MF_PAIRWISE_HINGE] = (acc[ST_H] / den) * w;
         o[MF_PAIRWISE_LOGISTIC] = (acc[ST_LG] / den) * w;
+    }
+    if (rowc_kind >= 0 && i < Bp) {       // the backward's row coefficients of the one trained loss (MF_LOSS_ROWC)
+        float a = 0.f, b = 0.f, cg = 0.f, gd = 0.f;
+        if (i < B) rowc_row(rowc_kind, target[i], sgn[i], lii[i], acc[ST_CNT], acc[ST_MX], acc[ST_SE], acc[ST_HC], acc[ST_LS],
+                            sigma, margin, a, b, cg, gd);
+        rowc[i] = a; rowc[Bp + i] = b; rowc[2 * Bp + i] = cg; rowc[3 * Bp + i] = gd;
     }
     for (int k = 0; k < MF_NUM_KINDS; ++k) {
         if (i < Bp) rowloss[(int64_t)k * Bp + i] = o[k];
@@ -784,35 +832,16 @@ __global__ __launch_bounds__(256) void mask_export_mined_kernel(const int32_t* _
 }
 
 // ------------------------------------------------------------------ backward ---
-// rowc[0] = a, rowc[1] = b, rowc[2] = coefG, rowc[3] = gdiag  with, for element (i, j),
-//   G'_ij = coefG_i * g((L_ij - a_i) + b_i)   (valid negatives),  G'_ii = gdiag_i,
-//   du_i = sum_j G'_ij (v_j - u_i),  dv_j = sum_i G'_ij (u_i - v_j).
 __global__ __launch_bounds__(256) void rowc_kernel(const float* __restrict__ stats, const float* __restrict__ target,
                                                    const float* __restrict__ lii, const float* __restrict__ sgn,
-                                                   const float* __restrict__ grad_out, int64_t B, int64_t Bp, int kind,
-                                                   float sigma, float margin, float* __restrict__ rowc) {
+                                                   int64_t B, int64_t Bp, int kind, float sigma, float margin,
+                                                   float* __restrict__ rowc) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= Bp) return;
     float a = 0.f, b = 0.f, cg = 0.f, gd = 0.f;
-    if (i < B) {
-        const float w = fabsf(target[i]), s = sgn[i], l = lii[i];
-        const float base = grad_out[0] * sigma * s * w;
-        const float cnt = stats[ST_CNT * Bp + i], mx = stats[ST_MX * Bp + i], se = stats[ST_SE * Bp + i];
-        const float den = cnt + 1e-10f;
-        switch (kind) {
-            case MF_ALIGNMENT: gd = -base; break;
-            case MF_CONTRASTIVE: b = s * margin; cg = base / den; break;
-            case MF_ALIGNMENT_CONTRASTIVE: b = s * margin; cg = base / den; gd = -base; break;
-            case MF_INFONCE: {
-                const float m2 = fmaxf(mx, l);
-                const float lse = m2 + __logf(se * __expf(mx - m2) + __expf(l - m2));
-                a = lse; cg = base; gd = base * (__expf(l - lse) - 1.f);
-            } break;
-            case MF_MINE: a = cnt > 0.f ? mx + __logf(se) : 0.f; cg = cnt > 0.f ? base : 0.f; gd = -base; break;
-            case MF_PAIRWISE_HINGE: a = l; b = margin; cg = base / den; gd = -cg * stats[ST_HC * Bp + i]; break;
-            case MF_PAIRWISE_LOGISTIC: a = l; b = margin; cg = base / den; gd = -cg * stats[ST_LS * Bp + i]; break;
-        }
-    }
+    if (i < B)
+        rowc_row(kind, target[i], sgn[i], lii[i], stats[ST_CNT * Bp + i], stats[ST_MX * Bp + i], stats[ST_SE * Bp + i],
+                 stats[ST_HC * Bp + i], stats[ST_LS * Bp + i], sigma, margin, a, b, cg, gd);
     rowc[0 * Bp + i] = a; rowc[1 * Bp + i] = b; rowc[2 * Bp + i] = cg; rowc[3 * Bp + i] = gd;
 }
 
@@ -844,6 +873,7 @@ __device__ __forceinline__ float g_of(int gmode, float x) {
 // every VALU instruction removed from these loops is MFMA time won back.
 struct BwdParams {
     const float *u, *v, *rowc;
+    const float* grad_out;   // device scalar: the row coefficients are scaled by it here
     const float* stash;      // masked logits (forward); stays intact so that a backward can be repeated
     float* gstash;           // G' = dloss/dL blocks: written by the dU sweep, read by the dV sweep
     float* dpart;
@@ -888,7 +918,10 @@ __global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss
     const float* Y = XU ? p.v : p.u;
     const int t0 = blockIdx.x * p.tps, t1 = min(p.YT, t0 + p.tps);
     float xa = 0.f, xb = 0.f, xc = 0.f, xd = 0.f;
-    if (XU) { xa = p.rowc[x]; xb = p.rowc[p.Bp + x]; xc = p.rowc[2 * p.Bp + x]; xd = p.rowc[3 * p.Bp + x]; }
+    if (XU) {
+        const float g = p.grad_out[0];
+        xa = p.rowc[x]; xb = p.rowc[p.Bp + x]; xc = g * p.rowc[2 * p.Bp + x]; xd = g * p.rowc[3 * p.Bp + x];
+    }
     const float xa2 = -xa * 1.44269504088896341f;      // exp(L - a) = exp2(L log2e - a log2e)
     f32x16 dacc[D / 32];
 #pragma unroll
@@ -1042,7 +1075,8 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
 // alignment-only backward: only the diagonal carries gradient
 template <int D>
 __global__ __launch_bounds__(256) void diag_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
-                                                       const float* __restrict__ rowc, int64_t B, int64_t N, int64_t Bp,
+                                                       const float* __restrict__ rowc, const float* __restrict__ grad_out,
+                                                       int64_t B, int64_t N, int64_t Bp,
                                                        float* __restrict__ du, float* __restrict__ dv) {
     constexpr int LPR = D / 4;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1051,7 +1085,7 @@ __global__ __launch_bounds__(256) void diag_bwd_kernel(const float* __restrict__
     if (r >= N) return;
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     if (r < B) {
-        const float gd = rowc[3 * Bp + r];
+        const float gd = grad_out[0] * rowc[3 * Bp + r];
         const f32x4 ui = reinterpret_cast<const f32x4*>(u + r * D)[c];
         const f32x4 vi = reinterpret_cast<const f32x4*>(v + r * D)[c];
         reinterpret_cast<f32x4*>(du + r * D)[c] = gd * (vi - ui);
@@ -1066,14 +1100,16 @@ template <int D>
 __global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                         const float* __restrict__ rowc, const int32_t* __restrict__ sel,
                                                         const int32_t* __restrict__ sel_cnt,
-                                                        const float* __restrict__ sel_L, int64_t B, int64_t Bp,
+                                                        const float* __restrict__ sel_L, const float* __restrict__ grad_out,
+                                                        int64_t B, int64_t Bp,
                                                         int gmode, float* __restrict__ du, float* __restrict__ dv) {
     constexpr int LPR = D / 4;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / LPR;
     const int c = (int)(t % LPR);
     if (i >= B) return;
-    const float a = rowc[i], b = rowc[Bp + i], cg = rowc[2 * Bp + i], gd = rowc[3 * Bp + i];
+    const float go = grad_out[0];
+    const float a = rowc[i], b = rowc[Bp + i], cg = go * rowc[2 * Bp + i], gd = go * rowc[3 * Bp + i];
     const f32x4 ui = reinterpret_cast<const f32x4*>(u + i * D)[c];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int n = sel_cnt[i];
@@ -1169,21 +1205,29 @@ extern "C" int mf_loss_masks(int64_t B, int64_t N, int d, int P, int num_negativ
 }
 
 extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
-                           int kind_mask, const float* u, const float* v, const float* target,
-                           const int64_t* item_idx, const int64_t* pos_idx, const float* logq, void* ws,
-                           size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits, mf_stream_t stream) {
+                           int kind_mask, const float* u, const float* v, const void* target,
+                           const int64_t* item_idx, const int64_t* pos_idx, const float* logq, int64_t logq_rows,
+                           int flags, void* ws, size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits,
+                           mf_stream_t stream) {
     int rc = check_loss_args("mf_loss_fwd", B, N, d, P, num_negatives, u, v, target, ws, ws_bytes);
     if (rc) return rc;
     const bool masks_ready = item_idx == nullptr;       // mf_loss_masks ran on this workspace
     if (!out_losses || (!masks_ready && P > 0 && !pos_idx) || !(kind_mask & 0x7F))
         return mf_set_error(MF_EINVAL, "mf_loss_fwd: bad argument");
+    if (logq && logq_rows > 0 && !item_idx) return mf_set_error(MF_EINVAL, "mf_loss_fwd: a logQ table needs item_idx");
+    int rowc_kind = -1;
+    if (flags & MF_LOSS_ROWC) {
+        if (__builtin_popcount(kind_mask & 0x7F) != 1) return mf_set_error(MF_EINVAL, "mf_loss_fwd: MF_LOSS_ROWC needs exactly one loss kind");
+        rowc_kind = __builtin_ctz(kind_mask & 0x7F);
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     LossWs w = loss_ws(ws, B, N, d, P, num_negatives);
     const int need = need_flags(kind_mask);
     const bool scores_needed = (kind_mask & ~(1 << MF_ALIGNMENT)) != 0 || out_mask_bits;
 
     {
-        PrepParams pp{u, v, target, logq, B, N, w.Bp, w.Np, d, sigma, w.nu, w.nv, w.lii, w.dii, w.sgn, w.logq,
+        PrepParams pp{u, v, target, logq, item_idx, logq_rows, (flags & MF_LOSS_TARGET_I64) ? 1 : 0,
+                      B, N, w.Bp, w.Np, d, sigma, w.nu, w.nv, w.lii, w.dii, w.sgn, w.logq, w.tgt,
                       nullptr, 0, nullptr, 0, nullptr, 0, w.ticket};
         int nb = (int)((w.Np + 63) / 64);
         if (scores_needed && !masks_ready) {
@@ -1225,39 +1269,39 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     } else {
         (void)hipMemsetAsync(w.stats, 0, (size_t)NSTAT * w.Bp * 4, s);
     }
-    finish_kernel<<<dim3((unsigned)(w.Bp / 256 + (w.Bp % 256 ? 1 : 0))), 256, 0, s>>>(w.part, merge_splits, B, w.Bp, target, w.lii, w.dii,
+    finish_kernel<<<dim3((unsigned)(w.Bp / 256 + (w.Bp % 256 ? 1 : 0))), 256, 0, s>>>(w.part, merge_splits, B, w.Bp, w.tgt, w.lii, w.dii,
                                                                                        sigma, kind_mask, w.stats, w.rowloss,
-                                                                                       w.blockpart, w.ticket, out_losses);
+                                                                                       w.blockpart, w.ticket, out_losses,
+                                                                                       rowc_kind, margin, w.sgn, w.rowc);
     return mf_check_launch("mf_loss_fwd");
 }
 
 extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
-                           int kind, const float* u, const float* v, const float* target, const float* logq,
-                           void* ws, size_t ws_bytes, const float* grad_out, float* du, float* dv,
-                           mf_stream_t stream) {
-    int rc = check_loss_args("mf_loss_bwd", B, N, d, P, num_negatives, u, v, target, ws, ws_bytes);
+                           int kind, const float* u, const float* v, int flags, void* ws, size_t ws_bytes,
+                           const float* grad_out, float* du, float* dv, mf_stream_t stream) {
+    int rc = check_loss_args("mf_loss_bwd", B, N, d, P, num_negatives, u, v, ws, ws, ws_bytes);
     if (rc) return rc;
     if (kind < 0 || kind >= MF_NUM_KINDS || !grad_out || !du || !dv)
         return mf_set_error(MF_EINVAL, "mf_loss_bwd: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     LossWs w = loss_ws(ws, B, N, d, P, num_negatives);
-    rowc_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(w.stats, target, w.lii, w.sgn, grad_out, B, w.Bp, kind,
-                                                                     sigma, margin, w.rowc);
+    if (!(flags & MF_LOSS_ROWC))      // else finish_kernel of the forward already wrote them
+        rowc_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(w.stats, w.tgt, w.lii, w.sgn, B, w.Bp, kind, sigma, margin, w.rowc);
     const int gmode = gmode_of(kind);
     if (kind == MF_ALIGNMENT) {
         MF_DISPATCH_D(d, {
             const int64_t nthreads = N * (D / 4);
-            diag_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, B, N, w.Bp, du, dv);
+            diag_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, grad_out, B, N, w.Bp, du, dv);
         });
     } else if (w.mined) {
         (void)hipMemsetAsync(dv, 0, (size_t)N * d * 4, s);
         MF_DISPATCH_D(d, {
             const int64_t nthreads = B * (D / 4);
-            mined_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, w.sel, w.sel_cnt, w.sel_L, B,
+            mined_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, w.sel, w.sel_cnt, w.sel_L, grad_out, B,
                                                                                         w.Bp, gmode, du, dv);
         });
     } else {
-        BwdParams bp{u, v, w.rowc, w.stash, w.gstash, w.dpart, w.rpart, B, N, w.Bp, w.Np, w.NT, 0, 0};
+        BwdParams bp{u, v, w.rowc, grad_out, w.stash, w.gstash, w.dpart, w.rpart, B, N, w.Bp, w.Np, w.NT, 0, 0};
         MF_DISPATCH_D(d, {
             bp.YT = w.NT; bp.tps = w.tps_u;
             MF_TIMED("loss_bwd_du", s, (launch_bwd<D, true>(gmode, dim3((unsigned)w.nsplit_u, (unsigned)(w.BT / w.NW)), bp, s)));

@@ -150,16 +150,18 @@ class MatrixFactorizationLitModule(_Base):
         # positives then sampled negatives, as xfmr_rec/lightning.py:133-134
         item_idx = torch.cat([batch["item"]["idx"], batch["neg_item"]["idx"]])
         item_embed = self(item_idx, tower="item")
-        logq = self.logq[item_idx] if (self.config.use_logq and self.logq is not None) else None
+        # the logQ table is looked up by item_idx inside the kernel (no gather launch)
+        logq_table = self.logq if (self.config.use_logq and self.logq is not None) else None
         cfg = self.config
         if cfg.fused_losses:
             vals = mf_losses.fused_losses(user_embed, item_embed, target, item_idx=item_idx, pos_idx=pos_idx,
                                           num_negatives=cfg.num_negatives, sigma=cfg.sigma, margin=cfg.margin,
-                                          logq=logq)
+                                          logq_table=logq_table,
+                                          train_loss=cfg.train_loss if step_name == "train" else None)
             return {f"{step_name}/{name}": v for name, v in vals.items()}
         return {
             f"{step_name}/{fn.__class__.__name__}": fn(user_embed=user_embed, item_embed=item_embed, target=target,
-                                                       item_idx=item_idx, pos_idx=pos_idx, logq=logq)
+                                                       item_idx=item_idx, pos_idx=pos_idx, logq_table=logq_table)
             for fn in self.loss_fns
         }
 

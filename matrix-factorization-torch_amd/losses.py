@@ -32,7 +32,7 @@ KINDS = (
 MAX_MINED_NEGATIVES = 64
 
 
-def _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq):
+def _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq, logq_table=None):
     u = _lib.dev_f32(user_embed, "user_embed")
     v = _lib.dev_f32(item_embed, "item_embed")
     d = u.shape[1]
@@ -40,7 +40,8 @@ def _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq):
     if dp != d:  # zero columns change no score (mf_numerics.h)
         u = torch.nn.functional.pad(u, (0, dp - d))
         v = torch.nn.functional.pad(v, (0, dp - d))
-    t = _lib.dev_f32(target, "target")
+    # the reference's target is the int64 rating (data/lightning.py:72-76): taken as it is, no conversion kernel
+    t = target.contiguous() if (target.is_cuda and target.dtype == torch.int64) else _lib.dev_f32(target, "target")
     ii = _lib.dev_i64(item_idx, "item_idx")
     if ii.numel() != v.shape[0]:
         msg = f"item_idx should have one id per item row: {ii.numel() = }, {v.shape[0] = }"
@@ -56,12 +57,19 @@ def _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq):
         if p == 0:
             pi = None
     lq = None
+    lq_rows = 0
+    if logq is not None and logq_table is not None:
+        msg = "pass either logq (one value per item row of the batch) or logq_table (looked up by item_idx), not both"
+        raise ValueError(msg)
     if logq is not None:
         lq = _lib.dev_f32(logq, "logq")
         if lq.numel() != v.shape[0]:
             msg = f"logq should have one value per item row: {lq.numel() = }, {v.shape[0] = }"
             raise ValueError(msg)
-    return u, v, t, ii, pi, p, lq, d, dp
+    elif logq_table is not None:
+        lq = _lib.dev_f32(logq_table, "logq_table").reshape(-1)
+        lq_rows = lq.numel()
+    return u, v, t, ii, pi, p, (lq, lq_rows), d, dp
 
 
 class PreparedMasks:
@@ -104,8 +112,8 @@ class _LossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, user_embed, item_embed, target, item_idx, pos_idx, logq, kind_mask, bwd_kind,
-                num_negatives, sigma, margin, prepared=None):
-        u, v, t, ii, pi, p, lq, d, dp = _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq)
+                num_negatives, sigma, margin, prepared=None, logq_table=None, train_kind=None):
+        u, v, t, ii, pi, p, (lq, lq_rows), d, dp = _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq, logq_table)
         b, n = u.shape[0], v.shape[0]
         lib = _lib.lib()
         if prepared is not None:
@@ -114,26 +122,36 @@ class _LossFunction(torch.autograd.Function):
                 raise ValueError(msg)
             torch.cuda.current_stream().wait_event(prepared.event)
             lease, ii_arg = prepared.lease, None     # item_idx = NULL: "the masks are in ws"
+            if lq_rows:                              # (the in-kernel table lookup needs the ids)
+                lq, lq_rows = lq[ii], 0
         else:
             lease, ii_arg = _lib.LeasedWorkspace(lib.mf_loss_ws_bytes(b, n, dp, p, num_negatives), u.device), ii
         ws = lease.tensor
         ctx.lease = lease                            # back to the pool when autograd drops this node
         out = torch.empty(len(KINDS), dtype=torch.float32, device=u.device)      # mf_loss_fwd writes all 7 entries
+        flags = (_lib.LOSS_TARGET_I64 if t.dtype == torch.int64 else 0) | (_lib.LOSS_ROWC if bwd_kind is not None else 0)
         _lib.check(lib.mf_loss_fwd(b, n, dp, p, num_negatives, sigma, margin, kind_mask, _lib.ptr(u), _lib.ptr(v),
-                                   _lib.ptr(t), _lib.ptr(ii_arg), _lib.ptr(pi), _lib.ptr(lq), _lib.ptr(ws), ws.numel(),
-                                   _lib.ptr(out), None, _lib.stream_ptr()))
-        ctx.save_for_backward(u, v, t, lq, ws)
+                                   _lib.ptr(t), _lib.ptr(ii_arg), _lib.ptr(pi), _lib.ptr(lq), lq_rows, flags, _lib.ptr(ws),
+                                   ws.numel(), _lib.ptr(out), None, _lib.stream_ptr()))
+        ctx.save_for_backward(u, v, ws)              # targets and logQ values live on in the workspace
         ctx.meta = (b, n, d, dp, p, num_negatives, sigma, margin, bwd_kind, user_embed.dtype, item_embed.dtype)
+        ctx.train_kind = train_kind
         # one trained loss (``bwd_kind``): hand out the scalar itself, so that autograd needs no
         # select-backward (two fills and a copy per step) between ``loss.backward()`` and this node
         return out if bwd_kind is None else out[bwd_kind]
 
     @staticmethod
     def backward(ctx, grad_out):
-        u, v, t, lq, ws = ctx.saved_tensors
+        u, v, ws = ctx.saved_tensors
         b, n, d, dp, p, k, sigma, margin, bwd_kind, u_dtype, v_dtype = ctx.meta
         # only the train loss is back-propagated (xfmr_rec/lightning.py:192)
-        nz = torch.nonzero(grad_out).flatten().tolist() if bwd_kind is None else [bwd_kind]
+        # (fused call: the trained kind is named up front -- ``train_kind`` -- or found by a host-synchronising scan)
+        if bwd_kind is not None:
+            nz = [bwd_kind]
+        elif ctx.train_kind is not None:
+            nz = [ctx.train_kind]
+        else:
+            nz = torch.nonzero(grad_out).flatten().tolist()
         du = dv = None
         lib = _lib.lib()
         grad_out = grad_out.to(torch.float32).contiguous()          # no-ops for the usual fp32 gradient
@@ -141,16 +159,16 @@ class _LossFunction(torch.autograd.Function):
             g = grad_out.reshape(1) if bwd_kind is not None else grad_out[kind : kind + 1]   # views: no kernel
             du_k = torch.empty_like(u)
             dv_k = torch.empty_like(v)
-            _lib.check(lib.mf_loss_bwd(b, n, dp, p, k, sigma, margin, kind, _lib.ptr(u), _lib.ptr(v), _lib.ptr(t),
-                                       _lib.ptr(lq), _lib.ptr(ws), ws.numel(), _lib.ptr(g), _lib.ptr(du_k),
-                                       _lib.ptr(dv_k), _lib.stream_ptr()))
+            _lib.check(lib.mf_loss_bwd(b, n, dp, p, k, sigma, margin, kind, _lib.ptr(u), _lib.ptr(v),
+                                       _lib.LOSS_ROWC if bwd_kind is not None else 0, _lib.ptr(ws), ws.numel(), _lib.ptr(g),
+                                       _lib.ptr(du_k), _lib.ptr(dv_k), _lib.stream_ptr()))
             du = du_k if du is None else du + du_k
             dv = dv_k if dv is None else dv + dv_k
         if du is None:
             du, dv = torch.zeros_like(u), torch.zeros_like(v)
         if dp != d:
             du, dv = du[:, :d], dv[:, :d]
-        return (du.to(u_dtype), dv.to(v_dtype)) + (None,) * 10
+        return (du.to(u_dtype), dv.to(v_dtype)) + (None,) * 12
 
 
 def check_inputs(user_embed: torch.Tensor, item_embed: torch.Tensor, target: torch.Tensor) -> None:
@@ -169,16 +187,30 @@ def check_inputs(user_embed: torch.Tensor, item_embed: torch.Tensor, target: tor
         raise ValueError(msg)
 
 
+def _check_num_negatives(k: int, n_items: int) -> None:
+    """Mining (0 < num_negatives < N, losses.py:137-141) keeps at most MAX_MINED_NEGATIVES per row on this path."""
+    if 0 < k < n_items and k > MAX_MINED_NEGATIVES:
+        msg = f"semi-hard mining supports num_negatives <= {MAX_MINED_NEGATIVES} (or >= num_items): {k = }"
+        raise NotImplementedError(msg)
+
+
 def fused_losses(user_embed, item_embed, target, *, item_idx, pos_idx, num_negatives=0, sigma=1.0, margin=1.0,
-                 logq=None, kinds=KINDS) -> dict[str, torch.Tensor]:
+                 logq=None, logq_table=None, kinds=KINDS, train_loss: str | None = None) -> dict[str, torch.Tensor]:
     """All requested losses from one sweep over the score tiles.  Every returned value is
-    differentiable; backward runs one HIP backward per loss that receives gradient."""
+    differentiable; backward runs one HIP backward per loss that receives gradient.  ``train_loss`` names the one
+    loss that will be back-propagated (xfmr_rec/lightning.py:192): the others are then constants of the backward,
+    which no longer has to look (with a host sync) for the entries that received gradient."""
     check_inputs(user_embed, item_embed, target)
+    _check_num_negatives(int(num_negatives), item_embed.size(0))
     mask = 0
     for name in kinds:
         mask |= 1 << KINDS.index(name)
+    if train_loss is not None and train_loss not in kinds:
+        msg = f"train_loss must be one of the evaluated kinds: {train_loss = }"
+        raise ValueError(msg)
     out = _LossFunction.apply(user_embed, item_embed, target, item_idx, pos_idx, logq, mask, None,
-                              int(num_negatives), float(sigma), float(margin))
+                              int(num_negatives), float(sigma), float(margin), None, logq_table,
+                              None if train_loss is None else KINDS.index(train_loss))
     return {name: out[KINDS.index(name)] for name in kinds}
 
 
@@ -200,9 +232,12 @@ class EmbeddingLoss(torch.nn.Module, abc.ABC):
 
     def forward(self, user_embed: torch.Tensor, item_embed: torch.Tensor, target: torch.Tensor, *,
                 item_idx: torch.Tensor, pos_idx: torch.Tensor | None, logq: torch.Tensor | None = None,
-                prepared: PreparedMasks | None = None) -> torch.Tensor:
+                prepared: PreparedMasks | None = None, logq_table: torch.Tensor | None = None) -> torch.Tensor:
+        """``logq`` (one value per item row of the batch) or ``logq_table`` (a table over all item rows, looked up by
+        ``item_idx`` inside the kernel) switch on the logQ correction ``L_ij -= logq_j`` (our extension)."""
         self.check_inputs(user_embed, item_embed, target)
-        return self.loss(user_embed, item_embed, target, item_idx=item_idx, pos_idx=pos_idx, logq=logq, prepared=prepared)
+        return self.loss(user_embed, item_embed, target, item_idx=item_idx, pos_idx=pos_idx, logq=logq, prepared=prepared,
+                         logq_table=logq_table)
 
     def prepare_masks(self, item_idx: torch.Tensor, pos_idx: torch.Tensor | None, *, batch_size: int,
                       embedding_dim: int) -> PreparedMasks:
@@ -244,13 +279,13 @@ class EmbeddingLoss(torch.nn.Module, abc.ABC):
         """losses.py:134-162 on a materialised logits matrix (the losses themselves mine on the fly)."""
         return self._mine(logits, negative_masks, semi_hard=True)
 
-    def loss(self, user_embed, item_embed, target, *, item_idx, pos_idx, logq=None, prepared=None) -> torch.Tensor:
+    def loss(self, user_embed, item_embed, target, *, item_idx, pos_idx, logq=None, prepared=None,
+             logq_table=None) -> torch.Tensor:
         k = int(self.num_negatives)
-        if 0 < k < item_embed.size(0) and k > MAX_MINED_NEGATIVES and self.kind != 0:
-            msg = f"semi-hard mining supports num_negatives <= {MAX_MINED_NEGATIVES} (or >= num_items): {k = }"
-            raise NotImplementedError(msg)
+        if self.kind != 0:
+            _check_num_negatives(k, item_embed.size(0))
         return _LossFunction.apply(user_embed, item_embed, target, item_idx, pos_idx, logq, 1 << self.kind, self.kind,
-                                   k, float(self.sigma), float(self.margin), prepared)
+                                   k, float(self.sigma), float(self.margin), prepared, logq_table)
 
 
 class AlignmentLoss(EmbeddingLoss):  # losses.py:249-259
@@ -292,7 +327,7 @@ def negative_mask(user_embed, item_embed, target, *, item_idx, pos_idx, num_nega
     followed by ``semi_hard_mining`` (losses.py:92-162), computed by the HIP path
     (``out_mask_bits`` of ``mf_loss_fwd``).  Diagnostic / test helper."""
     check_inputs(user_embed, item_embed, target)
-    u, v, t, ii, pi, p, lq, d, dp = _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq)
+    u, v, t, ii, pi, p, (lq, lq_rows), d, dp = _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq)
     b, n = u.shape[0], v.shape[0]
     nw = (n + 31) // 32
     lib = _lib.lib()
@@ -300,7 +335,8 @@ def negative_mask(user_embed, item_embed, target, *, item_idx, pos_idx, num_nega
     out = torch.zeros(len(KINDS), dtype=torch.float32, device=u.device)
     bits = torch.zeros(b, nw, dtype=torch.int32, device=u.device)
     _lib.check(lib.mf_loss_fwd(b, n, dp, p, int(num_negatives), float(sigma), 1.0, 1 << 1, _lib.ptr(u), _lib.ptr(v),
-                               _lib.ptr(t), _lib.ptr(ii), _lib.ptr(pi), _lib.ptr(lq), _lib.ptr(ws), ws.numel(),
+                               _lib.ptr(t), _lib.ptr(ii), _lib.ptr(pi), _lib.ptr(lq), lq_rows,
+                               _lib.LOSS_TARGET_I64 if t.dtype == torch.int64 else 0, _lib.ptr(ws), ws.numel(),
                                _lib.ptr(out), _lib.ptr(bits), _lib.stream_ptr()))
     shifts = torch.arange(32, device=u.device, dtype=torch.int32)
     return ((bits[:, :, None] >> shifts) & 1).bool().reshape(b, nw * 32)[:, :n]

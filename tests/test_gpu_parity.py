@@ -192,6 +192,48 @@ def test_fused_losses_equal_individual(mf):
         assert float(fused[kind]) == float(single), kind
 
 
+@pytest.mark.parametrize("k", [0, 4])
+def test_int64_targets_logq_table_and_named_train_loss(mf, k):
+    """The reference hands int64 ratings (data/lightning.py:72-76): taken as they are == their fp32 copy, bit for bit.
+    A logQ TABLE looked up by item_idx inside the kernel == the per-column values gathered by the caller (ids outside
+    the table count as 0).  fused_losses(train_loss=...) back-propagates exactly what the single-loss module does."""
+    t = _random_case(130, 300, 64, 7, seed=91)
+    dev = {name: v.to(DEV) for name, v in t.items()}
+    table = torch.log(torch.rand(200, generator=torch.Generator().manual_seed(3)) * 0.9 + 0.05).to(DEV)   # ids run to ~150
+    short = table[:100]                                     # ids >= 100 fall outside: logq = 0 there
+    fn = mf.losses.InfomationNoiseContrastiveEstimationLoss(num_negatives=k)
+
+    def run(target, **kw):
+        u, v = dev["u"].clone().requires_grad_(), dev["v"].clone().requires_grad_()
+        loss = fn(u, v, target, item_idx=dev["item_idx"], pos_idx=dev["pos_idx"], **kw)
+        loss.backward()
+        return loss.detach(), u.grad, v.grad
+
+    def same(a, b):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        if k == 0:
+            assert torch.equal(a[2], b[2])
+        else:
+            torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-7)
+
+    same(run(dev["target"]), run(dev["target"].float()))
+    same(run(dev["target"], logq_table=table), run(dev["target"], logq=table[dev["item_idx"]]))
+    ids = dev["item_idx"]
+    gathered = torch.where(ids < 100, short[ids.clamp(max=99)], torch.zeros((), device=DEV))
+    same(run(dev["target"], logq_table=short), run(dev["target"], logq=gathered))
+    with pytest.raises(ValueError, match="not both"):
+        fn(dev["u"], dev["v"], dev["target"], item_idx=ids, pos_idx=dev["pos_idx"], logq=gathered, logq_table=table)
+
+    # fused: every loss evaluated, one named as the trained one
+    u, v = dev["u"].clone().requires_grad_(), dev["v"].clone().requires_grad_()
+    vals = mf.losses.fused_losses(u, v, dev["target"], item_idx=ids, pos_idx=dev["pos_idx"], num_negatives=k,
+                                  train_loss="InfomationNoiseContrastiveEstimationLoss")
+    vals["InfomationNoiseContrastiveEstimationLoss"].backward()
+    same((vals["InfomationNoiseContrastiveEstimationLoss"].detach(), u.grad, v.grad), run(dev["target"]))
+    with pytest.raises(NotImplementedError, match="semi-hard mining supports"):
+        mf.losses.fused_losses(dev["u"], dev["v"], dev["target"], item_idx=ids, pos_idx=dev["pos_idx"], num_negatives=100)
+
+
 def test_check_inputs_errors(mf):
     fn = mf.losses.PairwiseHingeLoss()
     u, v = torch.randn(4, 32, device=DEV), torch.randn(8, 32, device=DEV)
