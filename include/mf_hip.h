@@ -56,7 +56,7 @@ const char* mf_last_error(void);
 int mf_version(void);
 
 /* Optional HIP-event timing of the dominant kernels ("loss_fwd_dense",
- * "loss_bwd_du", "loss_bwd_dv", "mining_select", "topk_select", "gather_rows",
+ * "loss_bwd_du", "loss_bwd_dv", "mining_select", "topk_select", "topk_small", "gather_rows",
  * "update_rows"), recorded on the launch stream.  mf_timing_enable(k): 0 = off, k >= 1 = time every
  * k-th launch of each name (an event pair costs a few us of stream time).  mf_timing_get blocks until
  * the recorded spans finished and returns their count (total_ms = summed duration). */
@@ -198,6 +198,19 @@ int mf_topk(const float* q, int64_t Q, const float* items, int64_t N, int d, int
  * catalog) part_*[G,Q,k] into the global top-k with the same order. */
 int mf_topk_merge(const float* part_scores, const int64_t* part_idx, int G, int64_t Q, int k,
                   float* out_scores, int64_t* out_idx, mf_stream_t stream);
+
+/* Small-batch form of mf_topk: Q <= 32 queries (the reference's search takes ONE query per call,
+ * xfmr_rec/data/lightning.py:237-259; recommend, xfmr_rec/lightning.py:76-95).  A matrix-vector scan is
+ * bandwidth-bound, so this path streams a BLOCKED copy of the catalog -- [block of 64 rows][16-byte chunk][row],
+ * built once per index by mf_topk_blocked_build into mf_topk_blocked_bytes(N, d) bytes -- with one row per lane
+ * and the canonical fmaf chain per (query, row): results are bit-identical to mf_topk's (scores, order, rows,
+ * exclusion semantics, tail of -inf / -1).  Two launches, no memset, no scatter. */
+size_t mf_topk_blocked_bytes(int64_t N, int d);
+int mf_topk_blocked_build(const float* items, int64_t N, int d, float* out_blocked, mf_stream_t stream);
+size_t mf_topk_small_ws_bytes(int64_t Q, int64_t N, int d, int k);
+int mf_topk_small(const float* q, int64_t Q, const float* blocked, int64_t N, int d, int k,
+                  const int64_t* excl_off, const int64_t* excl_idx, int64_t idx_base, void* ws,
+                  size_t ws_bytes, float* out_scores, int64_t* out_idx, mf_stream_t stream);
 
 /* Retrieval metrics @k on device, straight from the top-k output.  Replaces the
  * per-example torchmetrics updates of `update_metrics` / `get_metrics` (xfmr_rec/lightning.py:149-187,

@@ -51,6 +51,10 @@ SIGNATURES = {
                                 c_vp, c_vp]),
     "mf_retrieval_metrics": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mf_topk_merge": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "mf_topk_blocked_bytes": (c_sz, [c_i64, c_int]),
+    "mf_topk_blocked_build": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "mf_topk_small_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int]),
+    "mf_topk_small": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp]),
 }
 
 LOSS_TARGET_I64, LOSS_ROWC = 1, 2     # flags of mf_loss_fwd / mf_loss_bwd (include/mf_hip.h)

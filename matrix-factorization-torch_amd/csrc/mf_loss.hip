@@ -914,7 +914,6 @@ __global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss
     const int xt = (int)(x0 >> 5);
     const int64_t nX = XU ? p.B : p.N, nY = XU ? p.N : p.B;
     const int64_t Xp = XU ? p.Bp : p.Np;
-    const float* X = XU ? p.u : p.v;
     const float* Y = XU ? p.v : p.u;
     const int t0 = blockIdx.x * p.tps, t1 = min(p.YT, t0 + p.tps);
     float xa = 0.f, xb = 0.f, xc = 0.f, xd = 0.f;

@@ -1,0 +1,397 @@
+// mf_topk_small.hip -- exact full-catalog top-k for a HANDFUL of queries (Q <= 32, typically 1), gfx950.
+//
+// The reference's retrieval surface is one query per call (ItemProcessor.search,
+// xfmr_rec/data/lightning.py:237-259, reached from recommend, xfmr_rec/lightning.py:76-95).  For one query the
+// scan is a matrix-VECTOR product: 4 N d bytes streamed once, 2 N d flop -- bandwidth-bound, and the MFMA tile
+// engine of mf_topk.hip (32 queries per tile, several launches) is the wrong tool.  Here:
+//
+//   * the index keeps a second, BLOCKED copy of the catalog (built once, mf_topk_blocked_build):
+//     [block of 64 rows][16-byte chunk j][row r] -- so that with lane = row a wave's load of chunk j of its 64
+//     rows is ONE coalesced 1 KiB access straight into registers (no LDS round trip, all 32 .. 64 loads of a
+//     block in flight at once);
+//   * every lane runs the canonical k-ordered fmaf chain (mf_numerics.h: bit-for-bit the MFMA's element) of its
+//     row against the queries, which are wave-uniform and come through the scalar cache as SGPR operands;
+//   * launch 1 leaves, per query, every row's score (4 bytes: < 1 % of the catalog's traffic) and every 64-row
+//     block's best key; it selects nothing -- a selection is a serial 32-step search, and almost no block can
+//     hold one of the k best rows;
+//   * launch 2 (one 1024-thread workgroup per query) picks the k best BLOCK maxima: only those blocks can hold
+//     a row of the top k and the k-th of them bounds the k-th best key from below; their <= 64 k scores are
+//     filtered against that bound and one wave selects, orders and writes the k winners.
+// Exclusion lists (the `movie_id NOT IN (...)` prefilter, data/lightning.py:250-253) are matched per block
+// against the query's id list -- a few hundred ids -- instead of scattering a bitmap first.
+// Results are bit-identical to mf_topk (same chain, same 64-bit keys): tests/test_gpu_parity.py.
+#include "mf_common.h"
+#include "mf_select.h"
+
+static constexpr int SQ_MAXQ = 32;       // queries per call
+static constexpr int SQ_NW = 4;          // waves per workgroup (each takes one 64-row block per pass)
+static constexpr int SQ_MERGE_WAVES = 16;
+
+// ------------------------------------------------------------- blocked catalog ---
+template <int D>
+__global__ __launch_bounds__(256) void blocked_build_kernel(const float* __restrict__ items, int64_t N, int64_t nblocks,
+                                                            float* __restrict__ out) {
+    constexpr int CPR = D / 4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one 16-byte chunk each: t = (b * CPR + j) * 64 + r
+    if (t >= nblocks * CPR * 64) return;
+    const int r = (int)(t & 63);
+    const int j = (int)((t >> 6) % CPR);
+    const int64_t b = (t >> 6) / CPR;
+    const int64_t row = b * 64 + r;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (row < N) x = reinterpret_cast<const f32x4*>(items + row * D)[j];
+    reinterpret_cast<f32x4*>(out)[t] = x;
+}
+
+extern "C" size_t mf_topk_blocked_bytes(int64_t N, int d) {
+    if (N <= 0 || !mf_width_ok(d)) return 0;
+    return (size_t)((N + 63) / 64) * 64 * d * 4;
+}
+
+extern "C" int mf_topk_blocked_build(const float* items, int64_t N, int d, float* out_blocked, mf_stream_t stream) {
+    if (!items || !out_blocked || N <= 0) return mf_set_error(MF_EINVAL, "mf_topk_blocked_build: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t nblocks = (N + 63) / 64;
+    MF_DISPATCH_D(d, {
+        const int64_t chunks = nblocks * (D / 4) * 64;
+        blocked_build_kernel<D><<<dim3((unsigned)((chunks + 255) / 256)), 256, 0, s>>>(items, N, nblocks, out_blocked);
+    });
+    return mf_check_launch("mf_topk_blocked_build");
+}
+
+// ------------------------------------------------------------ wave selection ----
+// Exact top-k of the 64 NV keys a wave holds in registers (0 = empty slot; keys are unique): the k-th largest
+// is found by bit-wise threshold search (32 steps on the rank word; 32 more on the column word only when equal
+// ranks straddle the cut), the winners go, unordered, to dst[0 .. m), m = min(k, #keys) is returned.
+template <int NV>
+__device__ __forceinline__ int sq_wave_topk(const unsigned long long (&v)[NV], int k, unsigned long long* dst) {
+    const int lane = mf_lane();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int have = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) have += __popcll(__ballot(v[j] != 0ull));
+    unsigned long long tau = 1ull;                     // keeps every real key
+    if (have > k) {
+        // bits on which all the keys' rank words agree need no step: an all-ones bit is always accepted, an all-zeros
+        // bit never (the decision of a step does not depend on accepted lower all-ones bits: every key has them)
+        unsigned all_or = 0u, all_and = ~0u;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const unsigned r = (unsigned)(v[j] >> 32);
+            all_or |= r;
+            all_and &= v[j] != 0ull ? r : ~0u;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            all_or |= (unsigned)__shfl_xor((int)all_or, m, 64);
+            all_and &= (unsigned)__shfl_xor((int)all_and, m, 64);
+        }
+        unsigned vary = all_or ^ all_and;
+        unsigned th = all_and;
+        th = __builtin_amdgcn_readfirstlane(th);
+        vary = __builtin_amdgcn_readfirstlane(vary);
+        while (vary) {                                 // largest th with #{rank >= th} >= k, most significant open bit first
+            const int b = 31 - __builtin_clz(vary);
+            vary &= ~(1u << b);
+            const unsigned cnd = th | (1u << b);
+            int cge = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) cge += __popcll(__ballot((unsigned)(v[j] >> 32) >= cnd));
+            if (cge >= k) th = cnd;
+        }
+        int above = 0, equal = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            above += __popcll(__ballot((unsigned)(v[j] >> 32) > th));
+            equal += __popcll(__ballot(v[j] != 0ull && (unsigned)(v[j] >> 32) == th));
+        }
+        const int need = k - above;                    // >= 1 of the keys ranked exactly th
+        unsigned tlo = 0u;
+        if (equal > need) {
+            for (int b = 31; b >= 0; --b) {
+                const unsigned cnd = tlo | (1u << b);
+                int cge = 0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    cge += __popcll(__ballot(v[j] != 0ull && (unsigned)(v[j] >> 32) == th && (unsigned)v[j] >= cnd));
+                if (cge >= need) tlo = cnd;
+            }
+        }
+        tau = ((unsigned long long)th << 32) | tlo;
+    }
+    int pos = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const bool wj = v[j] != 0ull && v[j] >= tau;
+        const unsigned long long m = __ballot(wj);
+        if (wj) dst[pos + __popcll(m & below)] = v[j];
+        pos += __popcll(m);
+    }
+    return pos;
+}
+
+__device__ __forceinline__ unsigned long long sq_wave_or_u64(unsigned long long x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x |= mf_shfl_xor_u64(x, m);
+    return x;
+}
+
+// ------------------------------------------------------------------ the scan ----
+// Launch 1: every wave scores its 64-row block against the queries and leaves, per query, the 64 scores (4 bytes per
+// row and query: under 1 % of the catalog's bytes) and its best key.  No selection here: a selection is a serial
+// 32-step search, and almost none of the ~10^3 blocks can hold one of the k best rows.
+struct SmallParams {
+    const float* blocked;      // [nblocks][D/4][64][4]
+    const float* q;            // [Q][D]
+    int Q, k;
+    int64_t N, nblocks;
+    const int64_t *excl_off, *excl_idx;     // nullable
+    int64_t idx_base;
+    float* scores;             // [Q][nblocks * 64]: the score, or all-ones bits where the row holds no key (excluded, past N)
+    unsigned long long* wmax;  // [Q][nblocks]: best key of every block (0: none)
+};
+static constexpr unsigned SQ_NOKEY = 0xFFFFFFFFu;
+
+// QG queries at a time (compile-time: the accumulators are registers).  The rows of a block stay in registers
+// across the query groups when they fit (d <= 128), else each group re-reads them (L2 / Infinity Cache).  The
+// queries are wave-uniform: they are read by SCALAR loads (constant address space -> s_load_dwordx8 through the
+// scalar cache) and enter the fma as SGPR operands -- no LDS, no vector registers (read by broadcast from LDS the
+// compiler hoisted every fragment: 256 VGPRs, kilobytes of scratch per lane).
+typedef const __attribute__((address_space(4))) float* mf_const_f32;
+
+template <int D, int QG>
+__global__ __launch_bounds__(64 * SQ_NW) void topk_small_scan_kernel(SmallParams p) {
+    constexpr int CPR = D / 4;
+    constexpr int HALF = CPR > 32 ? 32 : CPR;                  // chunks held in registers at once
+    const int lane = mf_lane(), wave = mf_wave_id();
+    const int Qp = (p.Q + QG - 1) / QG * QG;
+    mf_const_f32 qc = (mf_const_f32)p.q;
+
+    for (int64_t blk = (int64_t)blockIdx.x * SQ_NW + wave; blk < p.nblocks; blk += (int64_t)gridDim.x * SQ_NW) {
+        const int64_t row0 = blk * 64;
+        const int64_t row = row0 + lane;
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.blocked) + blk * (int64_t)CPR * 64 + lane;
+        f32x4 rc[HALF];
+        if constexpr (CPR <= 32) {
+#pragma unroll
+            for (int j = 0; j < CPR; ++j) rc[j] = src[(int64_t)j * 64];
+        }
+        for (int q0 = 0; q0 < Qp; q0 += QG) {
+            float acc[QG];
+#pragma unroll
+            for (int qi = 0; qi < QG; ++qi) acc[qi] = 0.f;
+#pragma unroll
+            for (int h0 = 0; h0 < CPR; h0 += HALF) {
+                if constexpr (CPR > 32) {
+#pragma unroll
+                    for (int j = 0; j < HALF; ++j) rc[j] = src[(int64_t)(h0 + j) * 64];
+                }
+#pragma unroll
+                for (int g = 0; g < HALF / 2; ++g) {
+                    const f32x4 a = rc[2 * g], b = rc[2 * g + 1];
+#pragma unroll
+                    for (int qi = 0; qi < QG; ++qi) {
+                        const int qq = q0 + qi < p.Q ? q0 + qi : p.Q - 1;              // padding queries repeat the last one
+                        mf_const_f32 qv = qc + (size_t)qq * D + 4 * (h0 + 2 * g);       // wave-uniform address
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {              // k order of mf_dot_chain
+                            acc[qi] = __builtin_fmaf(a[t], qv[t], acc[qi]);
+                            acc[qi] = __builtin_fmaf(b[t], qv[4 + t], acc[qi]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int qi = 0; qi < QG; ++qi) {
+                const int q = q0 + qi;
+                if (q >= p.Q) break;
+                unsigned long long excl = 0ull;
+                if (p.excl_off) {             // the query's exclusion list against this block's 64 rows
+                    for (int64_t e = p.excl_off[q] + lane; e < p.excl_off[q + 1]; e += 64) {
+                        const int64_t y = p.excl_idx[e] - p.idx_base - row0;
+                        if (y >= 0 && y < 64) excl |= 1ull << y;
+                    }
+                    excl = sq_wave_or_u64(excl);
+                }
+                const bool ok = row < p.N && !((excl >> lane) & 1ull);
+                const unsigned long long key = ok ? mf_key_retrieval(acc[qi], (unsigned)row) : 0ull;
+                p.scores[(size_t)q * p.nblocks * 64 + row] = ok ? acc[qi] : __builtin_bit_cast(float, SQ_NOKEY);
+                const unsigned long long best = mf_wave_max_u64(key);
+                if (lane == 0) p.wmax[(size_t)q * p.nblocks + blk] = best;
+            }
+        }
+    }
+}
+
+// Launch 2, one 1024-thread workgroup per query.  (a) the k best of the block maxima (sixteen waves in parallel, then
+// two merge levels): only those <= k blocks can hold a row of the top k, and the k-th of them is a lower bound of the
+// k-th best key.  (b) their <= 64 k scores are turned back into keys and filtered against that bound.  (c) one wave
+// selects the k best candidates, orders them by rank counting and writes scores / rows.
+template <int KPL>
+__global__ __launch_bounds__(64 * SQ_MERGE_WAVES) void topk_small_select_kernel(const float* __restrict__ scores,
+                                                                               const unsigned long long* __restrict__ wmax,
+                                                                               int64_t nblocks, int k, int64_t idx_base,
+                                                                               float* __restrict__ out_scores,
+                                                                               int64_t* __restrict__ out_idx) {
+    __shared__ unsigned long long win[SQ_MERGE_WAVES][64];
+    __shared__ int win_n[SQ_MERGE_WAVES];
+    __shared__ unsigned long long mid[4][64];
+    __shared__ int mid_n[4];
+    __shared__ unsigned long long top[64];       // the k best block maxima
+    __shared__ unsigned long long cand[64 * 64];
+    __shared__ int cand_n, top_n;
+    __shared__ unsigned long long tau_s;
+    const int lane = mf_lane(), wave = mf_wave_id();
+    const int64_t q = blockIdx.x;
+    const unsigned long long* src = wmax + q * nblocks;
+    if (threadIdx.x == 0) cand_n = 0;
+    // (a) level 0: every wave reduces its batches of 64 KPL block maxima, winners riding along
+    int carry = 0;
+    for (int64_t base = (int64_t)wave * 64 * KPL; base < nblocks; base += (int64_t)SQ_MERGE_WAVES * 64 * KPL) {
+        unsigned long long v[KPL + 1];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const int64_t idx = base + lane + 64 * j;
+            v[j] = idx < nblocks ? src[idx] : 0ull;
+        }
+        v[KPL] = lane < carry ? win[wave][lane] : 0ull;
+        mf_wave_sync();
+        carry = sq_wave_topk<KPL + 1>(v, k, win[wave]);
+    }
+    if (lane == 0) win_n[wave] = carry;
+    __syncthreads();
+    // level 1: waves 0..3 merge four lists each; level 2: wave 0 merges those four
+    if (wave < 4) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v[w] = lane < win_n[4 * wave + w] ? win[4 * wave + w][lane] : 0ull;
+        const int m = sq_wave_topk<4>(v, k, mid[wave]);
+        if (lane == 0) mid_n[wave] = m;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v[w] = lane < mid_n[w] ? mid[w][lane] : 0ull;
+        const int m = sq_wave_topk<4>(v, k, top);
+        mf_wave_sync();
+        // the bound: the smallest of the k winners when there are k of them, else every key passes
+        unsigned long long mn = lane < m ? top[lane] : ~0ull;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            const unsigned long long o = mf_shfl_xor_u64(mn, s);
+            mn = o < mn ? o : mn;
+        }
+        if (lane == 0) { top_n = m; tau_s = m >= k ? mn : 1ull; }
+    }
+    __syncthreads();
+    // (b) the rows of the winning blocks that reach the bound
+    const int m_top = top_n;
+    const unsigned long long tau = tau_s;
+    for (int t = wave; t < m_top; t += SQ_MERGE_WAVES) {
+        const int64_t blk = (int64_t)(mf_key_retrieval_col(top[t]) >> 6);
+        const int64_t row = blk * 64 + lane;
+        const float sc = scores[(size_t)q * nblocks * 64 + row];
+        const unsigned long long key = __builtin_bit_cast(unsigned, sc) == SQ_NOKEY ? 0ull : mf_key_retrieval(sc, (unsigned)row);
+        const bool keep = key != 0ull && key >= tau;
+        const unsigned long long mk = __ballot(keep);
+        int base = 0;
+        if (lane == 0 && mk) base = atomicAdd(&cand_n, __popcll(mk));
+        base = __shfl(base, 0, 64);
+        if (keep) cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = key;
+    }
+    __syncthreads();
+    // (c) final selection by wave 0
+    if (wave != 0) return;
+    const int C = cand_n;
+    int m = 0;
+    if (C <= 64) {
+        const unsigned long long v[1] = {lane < C ? cand[lane] : 0ull};
+        mf_wave_sync();
+        m = sq_wave_topk<1>(v, k, top);
+    } else {
+        int car = 0;
+        for (int base = 0; base < C; base += 64 * 4) {
+            unsigned long long v[5];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = base + lane + 64 * j < C ? cand[base + lane + 64 * j] : 0ull;
+            v[4] = lane < car ? top[lane] : 0ull;
+            mf_wave_sync();
+            car = sq_wave_topk<5>(v, k, top);
+        }
+        m = car;
+    }
+    mf_wave_sync();
+    const unsigned long long mine = lane < m ? top[lane] : 0ull;
+    int r = 0;
+    for (int t = 0; t < m; ++t) r += top[t] > mine ? 1 : 0;
+    if (lane < k) {
+        if (lane < m) {
+            out_scores[q * k + r] = mf_key_retrieval_score(mine);
+            out_idx[q * k + r] = idx_base + (int64_t)mf_key_retrieval_col(mine);
+        } else {                                  // fewer than k rows were eligible: -inf / -1 tail
+            out_scores[q * k + lane] = -INFINITY;
+            out_idx[q * k + lane] = -1;
+        }
+    }
+}
+
+static int small_grid(int64_t nblocks) {
+    const int64_t nwg = (nblocks + SQ_NW - 1) / SQ_NW;
+    return (int)(nwg < 2048 ? nwg : 2048);       // <= 8 workgroups per CU; beyond that the waves loop
+}
+
+struct SmallWs {
+    float* scores;
+    unsigned long long* wmax;
+    size_t total;
+};
+static SmallWs small_ws(void* base, int64_t Q, int64_t nblocks) {
+    MfArena a(base);
+    SmallWs w;
+    w.scores = a.take<float>((size_t)Q * nblocks * 64);
+    w.wmax = a.take<unsigned long long>((size_t)Q * nblocks);
+    w.total = a.used();
+    return w;
+}
+
+extern "C" size_t mf_topk_small_ws_bytes(int64_t Q, int64_t N, int d, int k) {
+    if (Q <= 0 || Q > SQ_MAXQ || N <= 0 || k <= 0 || k > 64 || !mf_width_ok(d)) return 0;
+    return small_ws(nullptr, Q, (N + 63) / 64).total;
+}
+
+template <int D, int QG>
+static void launch_small(const SmallParams& sp, int grid, hipStream_t s) {
+    topk_small_scan_kernel<D, QG><<<dim3((unsigned)grid), 64 * SQ_NW, 0, s>>>(sp);
+}
+
+extern "C" int mf_topk_small(const float* q, int64_t Q, const float* blocked, int64_t N, int d, int k,
+                             const int64_t* excl_off, const int64_t* excl_idx, int64_t idx_base, void* ws,
+                             size_t ws_bytes, float* out_scores, int64_t* out_idx, mf_stream_t stream) {
+    if (!q || !blocked || !out_scores || !out_idx || !ws || Q <= 0 || N <= 0)
+        return mf_set_error(MF_EINVAL, "mf_topk_small: bad argument");
+    if (Q > SQ_MAXQ) return mf_set_error(MF_ENOTSUP, "mf_topk_small: Q = %lld > %d (use mf_topk)", (long long)Q, SQ_MAXQ);
+    if (k <= 0 || k > 64) return mf_set_error(MF_ENOTSUP, "mf_topk_small: k = %d outside 1..64", k);
+    if (!mf_width_ok(d)) return mf_set_error(MF_EINVAL, "mf_topk_small: embedding width %d not in {32,64,128,256}", d);
+    if (N >= (1ll << 31) || idx_base < 0 || idx_base + N > (1ll << 32))
+        return mf_set_error(MF_ENOTSUP, "mf_topk_small: item indices must fit 32 bits");
+    if ((excl_off == nullptr) != (excl_idx == nullptr)) return mf_set_error(MF_EINVAL, "mf_topk_small: excl_off/excl_idx mismatch");
+    if (ws_bytes < mf_topk_small_ws_bytes(Q, N, d, k)) return mf_set_error(MF_ENOSPC, "mf_topk_small: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t nblocks = (N + 63) / 64;
+    const int grid = small_grid(nblocks);
+    SmallWs w = small_ws(ws, Q, nblocks);
+    SmallParams sp{blocked, q, (int)Q, k, N, nblocks, excl_off, excl_idx, idx_base, w.scores, w.wmax};
+    MF_DISPATCH_D(d, {
+        MF_TIMED("topk_small", s, {
+            if (Q == 1) launch_small<D, 1>(sp, grid, s);
+            else if (Q <= 4) launch_small<D, 4>(sp, grid, s);
+            else launch_small<D, 8>(sp, grid, s);
+            if (nblocks <= 64 * SQ_MERGE_WAVES)
+                topk_small_select_kernel<1><<<dim3((unsigned)Q), 64 * SQ_MERGE_WAVES, 0, s>>>(w.scores, w.wmax, nblocks, k, idx_base, out_scores, out_idx);
+            else
+                topk_small_select_kernel<8><<<dim3((unsigned)Q), 64 * SQ_MERGE_WAVES, 0, s>>>(w.scores, w.wmax, nblocks, k, idx_base, out_scores, out_idx);
+        });
+    });
+    return mf_check_launch("mf_topk_small");
+}

@@ -44,15 +44,39 @@ class ItemIndex:
             emb = torch.nn.functional.pad(emb, (0, dp - self.dim))
         self.embeddings = emb.contiguous()
         self.idx_base = int(idx_base)
+        self._blocked: torch.Tensor | None = None      # second copy for the small-batch scan, built on first use
+        self._ws: dict = {}                              # search workspaces, kept between calls
+
+    SMALL_Q = 32       # at most this many queries can take the bandwidth-bound matrix-vector path (mf_topk_small)
+    AUTO_SMALL_Q = 16  # "auto" uses it up to here (measured at N = 62,423, d = 128: 17 / 26 / 40 / 107 us at Q = 1 / 4 / 8 / 32)
+
+    def blocked(self) -> torch.Tensor:
+        """The catalog in the blocked layout of ``mf_topk_small`` (``[64-row block][chunk][row]``), built once."""
+        if self._blocked is None:
+            lib = _lib.lib()
+            n, d = self.embeddings.shape
+            out = torch.empty(lib.mf_topk_blocked_bytes(n, d) // 4, dtype=torch.float32, device=self.embeddings.device)
+            _lib.check(lib.mf_topk_blocked_build(self.embeddings.data_ptr(), n, d, out.data_ptr(), _lib.stream_ptr()))
+            self._blocked = out
+        return self._blocked
+
+    def _workspace(self, key, nbytes: int) -> torch.Tensor:
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = _lib.workspace(nbytes, self.embeddings.device)
+        return ws
 
     @property
     def num_items(self) -> int:
         return self.embeddings.shape[0]
 
     def search(self, queries: torch.Tensor, top_k: int = TOP_K, *, exclude: Sequence[Sequence[int]] | None = None,
-               exclude_csr: tuple[torch.Tensor, torch.Tensor] | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+               exclude_csr: tuple[torch.Tensor, torch.Tensor] | None = None,
+               path: str = "auto") -> tuple[torch.Tensor, torch.Tensor]:
         """``(scores [Q, k] fp32, rows [Q, k] int64)``, best first; ``exclude`` holds GLOBAL
-        item rows per query (or pass a prebuilt device CSR with sorted ids)."""
+        item rows per query (or pass a prebuilt device CSR with sorted ids).  ``path``: "scan" = the
+        matrix-vector kernel (at most ``SMALL_Q`` queries), "tiles" = the MFMA tile engine, "auto" picks by the
+        number of queries; both give the same bits."""
         q = _lib.dev_f32(queries, "queries")
         if q.dim() != 2 or q.shape[1] != self.dim:
             msg = f"queries should be (num_queries, {self.dim}): {tuple(q.shape) = }"
@@ -62,9 +86,22 @@ class ItemIndex:
         nq, n, d = q.shape[0], self.num_items, self.embeddings.shape[1]
         off, ids = exclude_csr if exclude_csr is not None else _csr(exclude, nq, q.device)
         lib = _lib.lib()
-        ws = _lib.workspace(lib.mf_topk_ws_bytes(nq, n, d, top_k), q.device)
         scores = torch.empty(nq, top_k, dtype=torch.float32, device=q.device)
         rows = torch.empty(nq, top_k, dtype=torch.int64, device=q.device)
+        if path not in ("auto", "scan", "tiles"):
+            msg = f"path must be 'auto', 'scan' or 'tiles': {path = }"
+            raise ValueError(msg)
+        if path == "scan" and nq > self.SMALL_Q:
+            msg = f"the scan path takes at most {self.SMALL_Q} queries: {nq = }"
+            raise ValueError(msg)
+        if path == "scan" or (path == "auto" and nq <= self.AUTO_SMALL_Q):
+            # the reference's own shape: one query (or a handful) per call -- bandwidth-bound scan, two launches
+            ws = self._workspace(("small", nq, top_k), lib.mf_topk_small_ws_bytes(nq, n, d, top_k))
+            _lib.check(lib.mf_topk_small(q.data_ptr(), nq, self.blocked().data_ptr(), n, d, top_k, _lib.ptr(off), _lib.ptr(ids),
+                                         self.idx_base, ws.data_ptr(), ws.numel(), scores.data_ptr(), rows.data_ptr(),
+                                         _lib.stream_ptr()))
+            return scores, rows
+        ws = self._workspace(("tile", nq, top_k), lib.mf_topk_ws_bytes(nq, n, d, top_k))
         _lib.check(lib.mf_topk(q.data_ptr(), nq, self.embeddings.data_ptr(), n, d, top_k, _lib.ptr(off), _lib.ptr(ids),
                                self.idx_base, ws.data_ptr(), ws.numel(), scores.data_ptr(), rows.data_ptr(),
                                _lib.stream_ptr()))

@@ -309,21 +309,49 @@ def test_topk_bit_exact(mf, cfg):
     excl = [sorted(set(torch.randint(0, n, (int(torch.randint(0, 60, (1,), generator=g)),), generator=g).tolist()))
             for _ in range(nq)]
     index = mf.retrieval.ItemIndex(items.to(DEV))
-    s, i = index.search(q.to(DEV), k, exclude=excl)
     ws, wi = chain.topk(q.numpy(), items.numpy(), k, excl)
-    assert np.array_equal(i.cpu().numpy(), wi)
-    assert np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    for path in ("tiles", "scan") if nq <= index.SMALL_Q else ("tiles",):     # both kernels, same bits
+        s, i = index.search(q.to(DEV), k, exclude=excl, path=path)
+        assert np.array_equal(i.cpu().numpy(), wi), path
+        assert np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32)), path
+
+
+@pytest.mark.parametrize("cfg", [(1, 62423, 128, 20), (1, 300000, 32, 20), (32, 70000, 64, 64), (5, 1000, 256, 7), (9, 64, 32, 64),
+                                 (2, 1, 128, 3)], ids=lambda c: "x".join(map(str, c)))
+def test_topk_scan_path_equals_tile_path(mf, cfg):
+    """The small-batch matrix-vector scan (mf_topk_small: blocked catalog, one row per lane) against the MFMA tile
+    engine on the same inputs: scores and rows bit for bit -- catalogs of one block, of several passes per workgroup,
+    exclusions, ties, idx_base."""
+    nq, n, d, k = cfg
+    g = torch.Generator().manual_seed(n + nq)
+    q, items = _unit(nq, d, g), _unit(n, d, g)
+    if n > 10:
+        items[10] = items[3]
+    excl = [sorted(set(torch.randint(0, n, (int(torch.randint(0, 300, (1,), generator=g)),), generator=g).tolist()))
+            for _ in range(nq)]
+    excl = [[r + 7 for r in e] for e in excl]             # global rows: the index starts at row 7
+    index = mf.retrieval.ItemIndex(items.to(DEV), idx_base=7)
+    st, it = index.search(q.to(DEV), k, exclude=excl, path="tiles")
+    ss, is_ = index.search(q.to(DEV), k, exclude=excl, path="scan")
+    assert torch.equal(it, is_)
+    assert torch.equal(st.view(torch.int32), ss.view(torch.int32))
+    if n <= 70000:
+        ws, wi = chain.topk(q.numpy(), items.numpy(), k, [[r - 7 for r in e] for e in excl])
+        assert np.array_equal(np.where(is_.cpu().numpy() >= 0, is_.cpu().numpy() - 7, -1), wi)
+    with pytest.raises(ValueError, match="at most"):
+        index.search(torch.zeros(33, d, device=DEV), k, path="scan")
 
 
 def test_topk_degenerate_inputs(mf):
     """All scores equal (zero queries): lowest rows win; fewer than k candidates: -1 padding."""
     items = torch.randn(400, 32)
     index = mf.retrieval.ItemIndex(items.to(DEV))
-    s, i = index.search(torch.zeros(3, 32, device=DEV), 20)
-    assert torch.equal(i.cpu(), torch.arange(20).repeat(3, 1))
     small = mf.retrieval.ItemIndex(items[:6].to(DEV))
-    s, i = small.search(torch.randn(2, 32).to(DEV), 8, exclude=[[0, 1], []])
-    assert (i[0, 4:] == -1).all() and (i[1, 6:] == -1).all() and torch.isinf(s[0, 4:]).all()
+    for path in ("tiles", "scan"):
+        s, i = index.search(torch.zeros(3, 32, device=DEV), 20, path=path)
+        assert torch.equal(i.cpu(), torch.arange(20).repeat(3, 1)), path
+        s, i = small.search(torch.randn(2, 32).to(DEV), 8, exclude=[[0, 1], []], path=path)
+        assert (i[0, 4:] == -1).all() and (i[1, 6:] == -1).all() and torch.isinf(s[0, 4:]).all(), path
 
 
 def test_topk_degenerate_inputs_long_catalog(mf):
@@ -333,17 +361,19 @@ def test_topk_degenerate_inputs_long_catalog(mf):
     items = torch.randn(n, 64)
     index = mf.retrieval.ItemIndex(items.to(DEV))
     excl = [[0, 2, 5], [], list(range(40)), [n - 1]]
-    s, i = index.search(torch.zeros(4, 64, device=DEV), k, exclude=excl)
-    for r, ex in enumerate(excl):
-        want = [j for j in range(n) if j not in set(ex)][:k]
-        assert i[r].cpu().tolist() == want
+    for path in ("tiles", "scan"):
+        s, i = index.search(torch.zeros(4, 64, device=DEV), k, exclude=excl, path=path)
+        for r, ex in enumerate(excl):
+            want = [j for j in range(n) if j not in set(ex)][:k]
+            assert i[r].cpu().tolist() == want, path
     # two distinct score levels: the k best are the rows of the upper level, in row order
     q = torch.zeros(1, 64)
     q[0, 0] = 1.0
     items2 = torch.zeros(n, 64)
     items2[::7, 0] = 1.0
-    s, i = mf.retrieval.ItemIndex(items2.to(DEV)).search(q.to(DEV), k)
-    assert i[0].cpu().tolist() == list(range(0, 7 * k, 7)) and bool((s[0] == 1.0).all())
+    for path in ("tiles", "scan"):
+        s, i = mf.retrieval.ItemIndex(items2.to(DEV)).search(q.to(DEV), k, path=path)
+        assert i[0].cpu().tolist() == list(range(0, 7 * k, 7)) and bool((s[0] == 1.0).all()), path
 
 
 def test_sharded_topk_merge_equals_full(mf):
