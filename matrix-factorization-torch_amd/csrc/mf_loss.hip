@@ -59,6 +59,7 @@ struct LossWs {
     int32_t *cand_cnt, *sel, *sel_cnt;
     unsigned* gtau;
     float* sel_L;
+    long long* dvfix;            // mined backward: exact fixed-point accumulator of dv [N][d]
     size_t total;
 };
 
@@ -120,6 +121,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
         w.sel = a.take<int32_t>((size_t)w.Bp * KSEL_MAX);
         w.sel_cnt = a.take<int32_t>(w.Bp);
         w.sel_L = a.take<float>((size_t)w.Bp * KSEL_MAX);
+        w.dvfix = a.take<long long>((size_t)w.N * d);
         w.gtau = a.take<unsigned>((size_t)w.Bp);
         w.cand_cnt = a.take<int32_t>((size_t)w.Bp);      // right behind gtau: one memset clears both
         w.dpart = nullptr;
@@ -777,46 +779,56 @@ struct MiningPolicy {
     }
 };
 
-// one wave per user: exact ordered top-k of the row's candidate list -> sel[i][0..cnt)
-__global__ __launch_bounds__(64) void mined_merge_kernel(const unsigned long long* __restrict__ cand,
-                                                         const int32_t* __restrict__ cand_cnt, int rowcap, int k,
-                                                         int32_t* __restrict__ sel, int32_t* __restrict__ sel_cnt) {
+// One wave per user: exact ordered top-k of the row's candidate list -> sel[i][0..cnt), then -- same wave, the
+// user's row still in its registers -- the logits of the selected negatives (every item row is read by the whole
+// wave: coalesced 16-byte lanes; the dot is a wave reduction here, not the chain: these logits feed the loss value
+// and its gradient, tolerance 1e-4, not the bit-exact selection) and the row's statistics in selection order.
+struct MinedRowParams {
+    const unsigned long long* cand;
+    const int32_t* cand_cnt;
+    int rowcap, k;
+    const float *u, *v, *nu, *nv, *lii, *sgn, *nlogq;    // nlogq: the workspace's -logq copy
+    int64_t B, Bp;
+    int d;
+    float sigma, margin;
+    int need;
+    int32_t *sel, *sel_cnt;
+    float *sel_L, *stats;
+};
+__global__ __launch_bounds__(64) void mined_rows_kernel(MinedRowParams p) {
     __shared__ unsigned long long win[64], sorted[64];
     const int64_t i = blockIdx.x;
-    const int m = mf_row_topk<8>(cand + i * (int64_t)rowcap, cand_cnt[i], k, win, sorted);
-    const int t = mf_lane();
-    if (t < m) sel[i * KSEL_MAX + t] = (int32_t)mf_key_mining_col(sorted[t]);
-    if (t == 0) sel_cnt[i] = m;
-}
-
-// statistics of the mined negatives (thread per user, selection order)
-__global__ __launch_bounds__(256) void mined_stats_kernel(const float* __restrict__ u, const float* __restrict__ v,
-                                                          const float* __restrict__ nu, const float* __restrict__ nv,
-                                                          const float* __restrict__ lii, const float* __restrict__ sgn,
-                                                          const float* __restrict__ logq,
-                                                          const int32_t* __restrict__ sel,
-                                                          const int32_t* __restrict__ sel_cnt, int64_t B, int64_t Bp,
-                                                          int d, float sigma, float margin, int need,
-                                                          float* __restrict__ sel_L, float* __restrict__ stats) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= Bp) return;
+    const int lane = mf_lane();
     RowStats st;
     stats_init(st);
-    if (i < B) {
-        const int n = sel_cnt[i];
-        const float s_i = sgn[i], l = lii[i], sm = s_i * margin;
-        for (int t = 0; t < n; ++t) {
-            const int64_t j = sel[i * KSEL_MAX + t];
-            const float dot = mf_dot_chain(u + i * d, v + j * d, d);
-            const float L = mf_logit(nu[i], nv[j], dot, s_i, sigma, logq ? -logq[j] : 0.f);     // ws copy holds -logq
-            sel_L[i * KSEL_MAX + t] = L;
-            stats_add(st, need, L, sm, l, margin);
-            if (need & NEED_LSE) lse_merge(st.mx, st.se, L, 1.f);
+    if (i < p.B) {
+        const int m = mf_row_topk<8>(p.cand + i * (int64_t)p.rowcap, p.cand_cnt[i], p.k, win, sorted);
+        if (lane < m) p.sel[i * KSEL_MAX + lane] = (int32_t)mf_key_mining_col(sorted[lane]);
+        if (lane == 0) p.sel_cnt[i] = m;
+        const float s_i = p.sgn[i], l = p.lii[i], sm = s_i * p.margin, nu_i = p.nu[i];
+        const int d4 = p.d / 4;                  // <= 64 chunks of 16 bytes (d <= 256): one per lane
+        f32x4 ur = {0.f, 0.f, 0.f, 0.f};
+        if (lane < d4) ur = reinterpret_cast<const f32x4*>(p.u + i * p.d)[lane];
+        for (int t = 0; t < m; ++t) {
+            const int64_t j = (int64_t)mf_key_mining_col(sorted[t]);
+            float part = 0.f;
+            if (lane < d4) {
+                const f32x4 vr = reinterpret_cast<const f32x4*>(p.v + j * p.d)[lane];
+                part = ur[0] * vr[0] + ur[1] * vr[1] + ur[2] * vr[2] + ur[3] * vr[3];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            const float L = mf_logit(nu_i, p.nv[j], part, s_i, p.sigma, -p.nlogq[j]);
+            if (lane == 0) p.sel_L[i * KSEL_MAX + t] = L;
+            stats_add(st, p.need, L, sm, l, p.margin);
+            if (p.need & NEED_LSE) lse_merge(st.mx, st.se, L, 1.f);
         }
     }
-    float* o = stats + i;
-    o[ST_CNT * Bp] = st.cnt; o[ST_A * Bp] = st.A; o[ST_MX * Bp] = st.mx; o[ST_SE * Bp] = st.se;
-    o[ST_H * Bp] = st.H; o[ST_HC * Bp] = st.Hc; o[ST_LG * Bp] = st.Lg; o[ST_LS * Bp] = st.Ls;
+    if (lane == 0) {
+        float* o = p.stats + i;
+        o[ST_CNT * p.Bp] = st.cnt; o[ST_A * p.Bp] = st.A; o[ST_MX * p.Bp] = st.mx; o[ST_SE * p.Bp] = st.se;
+        o[ST_H * p.Bp] = st.H; o[ST_HC * p.Bp] = st.Hc; o[ST_LG * p.Bp] = st.Lg; o[ST_LS * p.Bp] = st.Ls;
+    }
 }
 
 __global__ __launch_bounds__(256) void mask_export_mined_kernel(const int32_t* __restrict__ sel,
@@ -1094,36 +1106,55 @@ __global__ __launch_bounds__(256) void diag_bwd_kernel(const float* __restrict__
     }
 }
 
-// mined backward: a d/4-lane group per user walks its selected negatives
+// Mined backward.  du_i accumulates in registers, in selection order.  dv_j sums contributions of many users:
+// they are added as 64-bit FIXED-POINT integers (2^-40 units) with integer atomics -- integer addition is
+// associative, so the sum is the same bits whatever order the atomics land in (run-to-run deterministic, unlike
+// the fp32 atomics this replaces), and it is rounded to fp32 once, by dv_fix_to_f32_kernel.  A contribution is
+// exact on the 2^-40 grid down to |x| = 2^-17 and off by <= 2^-41 below; |sum| < 2^23.  Lane c of a 32-lane row
+// group owns the features c, c + 32, ..: one atomic instruction covers 256 contiguous bytes of a row.
+static constexpr float DV_FIX_SCALE = 1099511627776.0f;      // 2^40
+
 template <int D>
 __global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                         const float* __restrict__ rowc, const int32_t* __restrict__ sel,
                                                         const int32_t* __restrict__ sel_cnt,
                                                         const float* __restrict__ sel_L, const float* __restrict__ grad_out,
                                                         int64_t B, int64_t Bp,
-                                                        int gmode, float* __restrict__ du, float* __restrict__ dv) {
-    constexpr int LPR = D / 4;
+                                                        int gmode, float* __restrict__ du, long long* __restrict__ dvfix) {
+    constexpr int LPR = 32, NE = D / LPR;            // lanes per row, features per lane (c, c + 32, ...)
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / LPR;
     const int c = (int)(t % LPR);
     if (i >= B) return;
     const float go = grad_out[0];
     const float a = rowc[i], b = rowc[Bp + i], cg = go * rowc[2 * Bp + i], gd = go * rowc[3 * Bp + i];
-    const f32x4 ui = reinterpret_cast<const f32x4*>(u + i * D)[c];
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float ui[NE], acc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { ui[e] = u[i * D + c + LPR * e]; acc[e] = 0.f; }
     const int n = sel_cnt[i];
     for (int s = -1; s < n; ++s) {
         int64_t j;
         float g;
         if (s < 0) { j = i; g = gd; }
         else { j = sel[i * KSEL_MAX + s]; g = cg * g_of(gmode, (sel_L[i * KSEL_MAX + s] - a) + b); }
-        const f32x4 vj = reinterpret_cast<const f32x4*>(v + j * D)[c];
-        acc += g * (vj - ui);
-        const f32x4 dvj = g * (ui - vj);
-        float* o = dv + j * D + 4 * c;
-        atomicAdd(o + 0, dvj[0]); atomicAdd(o + 1, dvj[1]); atomicAdd(o + 2, dvj[2]); atomicAdd(o + 3, dvj[3]);
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(dvfix) + j * D + c;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const float vj = v[j * D + c + LPR * e];
+            acc[e] += g * (vj - ui[e]);
+            const float dvj = g * (ui[e] - vj);
+            const long long q = (long long)__builtin_rintf(fminf(fmaxf(dvj, -8388607.f), 8388607.f) * DV_FIX_SCALE);
+            atomicAdd(o + LPR * e, (unsigned long long)q);       // two's complement: the unsigned add IS the signed add
+        }
     }
-    reinterpret_cast<f32x4*>(du + i * D)[c] = acc;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) du[i * D + c + LPR * e] = acc[e];
+}
+
+__global__ __launch_bounds__(256) void dv_fix_to_f32_kernel(const long long* __restrict__ dvfix, int64_t n, float* __restrict__ dv) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    dv[t] = (float)((double)dvfix[t] * (1.0 / 1099511627776.0));
 }
 
 // ------------------------------------------------------------------ C ABI ------
@@ -1257,10 +1288,9 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
         SelectCommon sc{u, B, v, N, 0, (int)((N + 31) / 32), w.plan.tpc, w.Bp, num_negatives, w.plan.xw, w.gtau, w.priv, w.cand, w.cand_cnt, w.plan.rowcap};
         (void)hipMemsetAsync(w.gtau, 0, (size_t)((char*)(w.cand_cnt + w.Bp) - (char*)w.gtau), s);
         MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s))); });
-        mined_merge_kernel<<<dim3((unsigned)B), 64, 0, s>>>(w.cand, w.cand_cnt, w.plan.rowcap, num_negatives, w.sel, w.sel_cnt);
-        mined_stats_kernel<<<dim3((unsigned)((w.Bp + 255) / 256)), 256, 0, s>>>(u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.sel,
-                                                                                w.sel_cnt, B, w.Bp, d, sigma, margin, need,
-                                                                                w.sel_L, w.stats);
+        MinedRowParams mr{w.cand, w.cand_cnt, w.plan.rowcap, num_negatives, u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, B, w.Bp, d,
+                          sigma, margin, need, w.sel, w.sel_cnt, w.sel_L, w.stats};
+        mined_rows_kernel<<<dim3((unsigned)w.Bp), 64, 0, s>>>(mr);
         if (out_mask_bits) {
             (void)hipMemsetAsync(out_mask_bits, 0, (size_t)B * ((N + 31) / 32) * 4, s);
             mask_export_mined_kernel<<<dim3((unsigned)((B + 255) / 256)), 256, 0, s>>>(w.sel, w.sel_cnt, B, (int)((N + 31) / 32), out_mask_bits);
@@ -1293,12 +1323,13 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
             diag_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, grad_out, B, N, w.Bp, du, dv);
         });
     } else if (w.mined) {
-        (void)hipMemsetAsync(dv, 0, (size_t)N * d * 4, s);
+        (void)hipMemsetAsync(w.dvfix, 0, (size_t)N * d * 8, s);
         MF_DISPATCH_D(d, {
-            const int64_t nthreads = B * (D / 4);
+            const int64_t nthreads = B * 32;
             mined_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, w.sel, w.sel_cnt, w.sel_L, grad_out, B,
-                                                                                        w.Bp, gmode, du, dv);
+                                                                                        w.Bp, gmode, du, w.dvfix);
         });
+        dv_fix_to_f32_kernel<<<dim3((unsigned)((N * d + 255) / 256)), 256, 0, s>>>(w.dvfix, N * d, dv);
     } else {
         BwdParams bp{u, v, w.rowc, grad_out, w.stash, w.gstash, w.dpart, w.rpart, B, N, w.Bp, w.Np, w.NT, 0, 0};
         MF_DISPATCH_D(d, {

@@ -117,8 +117,9 @@ struct SelectLds {
 //   struct Thr;  static Thr thr_all(), thr_none(), make_thr(unsigned rank_bound)
 //   static bool maybe(P, row, tile, score, e, h, thr)   cheap, CONSERVATIVE test of `rank >= bound` on the raw score:
 //                                                    false only if key() could not pass the exact test
+// (T = 32 -- k in 33..64 -- needs more than 256 registers: compiled for one workgroup per CU instead of spilling)
 template <int D, int T, class Policy>
-__global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_kernel(typename Policy::Params pp, SelectCommon sc) {
+__global__ __launch_bounds__(64 * mf_nw(D), T >= 32 ? 1 : mf_wg_per_cu(D)) void select_kernel(typename Policy::Params pp, SelectCommon sc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = TileGeom<D>;
     using L = SelectLds<D>;
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_kernel(
 // row are distinct elements, so the k-th largest of them (select_bound_kernel) is a valid lower bound
 // of the row's k-th best key; the main pass then starts from it and accepts only a few keys per row.
 template <int D, int T, class Policy>
-__global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void select_seed_kernel(typename Policy::Params pp, SelectCommon sc,
+__global__ __launch_bounds__(64 * mf_nw(D), T >= 32 ? 1 : mf_wg_per_cu(D)) void select_seed_kernel(typename Policy::Params pp, SelectCommon sc,
                                                                             unsigned long long* __restrict__ seeds,
                                                                             int seeds_per_row) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
