@@ -31,16 +31,30 @@ def _step_vs_oracle(mf, *, users, items, d, kind, b, p, optimizer, num_negatives
     opt = m.configure_optimizers()
     loss = m.training_step(mf.data.to_device(batch, DEV), 0)
     loss.backward()
+    # what the backward parked on the tables for the sparse update: (row ids, gradient rows w.r.t. the unit rows)
+    parked = {name: [(i.cpu(), g.cpu()) for i, g, _ in m.towers[name].weight._mf_pending] for name in ("user", "item")}
     opt.step()
 
     item_idx = torch.cat([batch["item"]["idx"], batch["neg_item"]["idx"]])
     u_raw, v_raw = ut[batch["user"]["idx"]].requires_grad_(), it[item_idx].requires_grad_()
     un, vn = oembed.gather(u_raw, torch.arange(b), True), oembed.gather(v_raw, torch.arange(2 * b), True)
+    un.retain_grad()
+    vn.retain_grad()
     lq = m.logq.cpu()[item_idx] if logq else None
     want = ol.loss(kind, un, vn, batch["target"], item_idx=item_idx, pos_idx=batch["user"]["pos_idx"],
                    num_negatives=num_negatives, sigma=1.0, margin=margin, logq=lq)
     want.backward()
     assert abs(float(loss) - float(want)) <= 1e-4 * max(1.0, abs(float(want))), (float(loss), float(want))
+    # the summed gradient of every touched row -- what feeds the update, and for Adam's first step g / (|g| + eps)
+    # the quantity whose last bits decide -- is bounded DIRECTLY, not through the updated tables
+    for name, ids, g_or in (("user", batch["user"]["idx"], un.grad), ("item", item_idx, vn.grad)):
+        (pid, pg), = parked[name]
+        assert torch.equal(pid, ids)
+        torch.testing.assert_close(pg, g_or, rtol=2e-4, atol=2e-6)
+        rows_g, sum_g = oembed.coalesce(pid, pg)
+        rows_o, sum_o = oembed.coalesce(ids, g_or)
+        assert torch.equal(rows_g, rows_o)
+        torch.testing.assert_close(sum_g, sum_o, rtol=2e-4, atol=1e-5)
     for table, ids, g in ((ut, batch["user"]["idx"], u_raw.grad), (it, item_idx, v_raw.grad)):
         if optimizer == "sgd":
             oembed.sgd_update(table, ids, g, 0.05, 0.0)
