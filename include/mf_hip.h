@@ -170,15 +170,19 @@ int mf_mine_logits(const float* logits, int64_t B, int64_t N, int k, int semi_ha
  * mapped through the normalisation Jacobian of the raw row.
  *   sgd : row -= lr * (g + wd * row)
  *   adam: lazy row-wise AdamW (moments of touched rows only, global step for the
- *         bias correction, decoupled weight decay). */
+ *         bias correction, decoupled weight decay).  The step (1-based) comes by value, or --
+ *         step_dev != NULL -- from device memory: a launch captured in a hipGraph freezes its
+ *         by-value arguments, a device counter bumped inside the graph keeps counting.  Either
+ *         way the bias corrections are evaluated on the device: eager and replayed steps agree
+ *         bit for bit. */
 size_t mf_update_ws_bytes(int64_t n, int d);
 int mf_update_sgd(float* table, int64_t n_rows, int d, const int64_t* idx, int64_t n,
                   const float* grad, int normalized, float lr, float weight_decay, void* ws,
                   size_t ws_bytes, mf_stream_t stream);
 int mf_update_adam(float* table, float* exp_avg, float* exp_avg_sq, int64_t n_rows, int d,
                    const int64_t* idx, int64_t n, const float* grad, int normalized, int64_t step,
-                   float lr, float beta1, float beta2, float eps, float weight_decay, void* ws,
-                   size_t ws_bytes, mf_stream_t stream);
+                   const int64_t* step_dev, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, void* ws, size_t ws_bytes, mf_stream_t stream);
 
 /* --------------------------------------------------------------- retrieval ---
  * Replaces `ItemProcessor.search` (xfmr_rec/data/lightning.py:237-259; LanceDB

@@ -321,8 +321,17 @@ extern "C" int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64
 
 // ---------------------------------------------------------- sparse updates ----
 struct AdamHyper {
-    float lr, beta1, beta2, eps, wd, bc1, bc2;
+    float lr, beta1, beta2, eps, wd;
+    long long step;              // global step (1-based) ...
+    const long long* step_dev;   // ... or, when non-NULL, where to read it on the device (hipGraph replays: a captured
+                                 // launch freezes its by-value arguments, a device counter keeps counting)
 };
+// bias corrections 1 - beta^step, evaluated on the device in both modes (so an eager step and a replayed one agree bit for bit)
+__device__ __forceinline__ void adam_bias(const AdamHyper& hp, float& bc1, float& bc2) {
+    const long long st = hp.step_dev ? *hp.step_dev : hp.step;
+    bc1 = (float)(1.0 - pow((double)hp.beta1, (double)st));
+    bc2 = (float)(1.0 - pow((double)hp.beta2, (double)st));
+}
 
 // One d/4-lane group per sorted position.  Runs of equal ids are summed in two
 // deterministic levels so that a very popular row (Zipf: hundreds of duplicates in
@@ -356,10 +365,12 @@ __device__ __forceinline__ void apply_row_update(bool active, int64_t row, int c
         w = w * (1.f - hp.lr * hp.wd);
         m = m * hp.beta1 + (1.f - hp.beta1) * g;
         v = v * hp.beta2 + (1.f - hp.beta2) * g * g;
+        float bc1, bc2;
+        adam_bias(hp, bc1, bc2);
         f32x4 den;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) den[t] = sqrtf(v[t] / hp.bc2) + hp.eps;
-        w = w - (hp.lr / hp.bc1) * m / den;
+        for (int t = 0; t < 4; ++t) den[t] = sqrtf(v[t] / bc2) + hp.eps;
+        w = w - (hp.lr / bc1) * m / den;
         reinterpret_cast<f32x4*>(exp_avg + rr * D)[c] = m;
         reinterpret_cast<f32x4*>(exp_avg_sq + rr * D)[c] = v;
     }
@@ -481,19 +492,17 @@ static int update_common(float* table, float* m, float* v, int64_t n_rows, int d
 extern "C" int mf_update_sgd(float* table, int64_t n_rows, int d, const int64_t* idx, int64_t n,
                              const float* grad, int normalized, float lr, float weight_decay,
                              void* ws, size_t ws_bytes, mf_stream_t stream) {
-    AdamHyper hp{lr, 0.f, 0.f, 0.f, weight_decay, 1.f, 1.f};
+    AdamHyper hp{lr, 0.f, 0.f, 0.f, weight_decay, 1, nullptr};
     return update_common<false>(table, nullptr, nullptr, n_rows, d, idx, n, grad, normalized, hp, ws,
                                 ws_bytes, stream, "mf_update_sgd");
 }
 
 extern "C" int mf_update_adam(float* table, float* exp_avg, float* exp_avg_sq, int64_t n_rows, int d,
                               const int64_t* idx, int64_t n, const float* grad, int normalized,
-                              int64_t step, float lr, float beta1, float beta2, float eps,
+                              int64_t step, const int64_t* step_dev, float lr, float beta1, float beta2, float eps,
                               float weight_decay, void* ws, size_t ws_bytes, mf_stream_t stream) {
-    if (step < 1) return mf_set_error(MF_EINVAL, "mf_update_adam: step must be >= 1");
-    AdamHyper hp{lr, beta1, beta2, eps, weight_decay,
-                 (float)(1.0 - pow((double)beta1, (double)step)),
-                 (float)(1.0 - pow((double)beta2, (double)step))};
+    if (!step_dev && step < 1) return mf_set_error(MF_EINVAL, "mf_update_adam: step must be >= 1");
+    AdamHyper hp{lr, beta1, beta2, eps, weight_decay, (long long)step, reinterpret_cast<const long long*>(step_dev)};
     return update_common<true>(table, exp_avg, exp_avg_sq, n_rows, d, idx, n, grad, normalized, hp, ws,
                                ws_bytes, stream, "mf_update_adam");
 }

@@ -64,7 +64,7 @@ class HipOps:
                                          int(normalized), lr, 0.0, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
         else:
             _lib.check(lib.mf_update_adam(table.data_ptr(), state["m"].data_ptr(), state["v"].data_ptr(), table.shape[0], d,
-                                          ids.data_ptr(), n, grad.data_ptr(), int(normalized), step, lr, 0.9, 0.999, 1e-8,
+                                          ids.data_ptr(), n, grad.data_ptr(), int(normalized), step, None, lr, 0.9, 0.999, 1e-8,
                                           0.01, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
 
     def topk(self, queries, items, k, exclude_csr, idx_base):

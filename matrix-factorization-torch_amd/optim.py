@@ -127,6 +127,17 @@ class RowAdam(_SparseRowOptimizer):
     def __init__(self, params, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.01) -> None:
         super().__init__(params, {"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay})
+        # capturable: the global step lives in device memory and is bumped by a kernel of the step itself, so that a
+        # step captured in a hipGraph (``graph.CapturedStep``) keeps counting when it is replayed -- a by-value
+        # argument would be frozen at capture.  Same bits either way: the bias correction is evaluated on the device.
+        self.capturable = False
+
+    def on_replay(self) -> None:
+        """Called once per graph replay of a captured step: keeps the host-side step counts in line."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if self.state[p] and "step_t" in self.state[p]:
+                    self.state[p]["step"] += 1
 
     def init_state(self) -> None:
         """Allocate the moment tables now instead of inside the first ``step`` (two table-sized allocations and
@@ -158,17 +169,24 @@ class RowAdam(_SparseRowOptimizer):
                     state["step"] = 0
                     state["exp_avg"] = torch.zeros_like(p)
                     state["exp_avg_sq"] = torch.zeros_like(p)
-                state["step"] += 1
+                step_dev = None
+                if self.capturable:
+                    if "step_t" not in state:
+                        state["step_t"] = torch.full((1,), state["step"], dtype=torch.int64, device=p.device)
+                    state["step_t"] += 1                   # a kernel: replayed with the graph
+                    step_dev = state["step_t"].data_ptr()
+                if not (self.capturable and torch.cuda.is_current_stream_capturing()):
+                    state["step"] += 1                     # (a capture runs no kernel: the replays count, via on_replay)
 
-                def job(p=p, pend=pend, group=group, state=state):
+                def job(p=p, pend=pend, group=group, state=state, step_dev=step_dev):
                     ids, g, norm = pend
                     n, d = ids.numel(), p.shape[1]
                     ws = _lib.workspace(lib.mf_update_ws_bytes(n, d), p.device)
                     b1, b2 = group["betas"]
                     _lib.check(lib.mf_update_adam(p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
                                                   p.shape[0], d, ids.data_ptr(), n, g.data_ptr(), int(norm), state["step"],
-                                                  group["lr"], b1, b2, group["eps"], group["weight_decay"], ws.data_ptr(),
-                                                  ws.numel(), _lib.stream_ptr()))
+                                                  step_dev, group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                                                  ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
 
                 jobs.append(job)
                 done.append(p)

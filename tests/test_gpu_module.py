@@ -225,3 +225,57 @@ def test_sharded_classes_on_one_rank_use_the_hip_path(mf):
         assert torch.equal(i1, i2) and torch.equal(s1, s2)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg", [("adam", "PairwiseHingeLoss", 4, 32), ("adam", "InfomationNoiseContrastiveEstimationLoss", 0, 256),
+                                 ("sgd", "PairwiseLogisticLoss", 0, 64)], ids=lambda c: "-".join(map(str, c)))
+def test_captured_step_replays_bit_identically(mf, cfg):
+    """A whole training step (gathers -> loss -> backward -> sparse updates) recorded in a hipGraph and replayed on
+    new batches == the same steps run eagerly, bit for bit: tables, moments and the returned loss.  First case: the
+    reference's default configuration -- PairwiseHingeLoss, num_negatives = 4, BATCH_SIZE = 32
+    (xfmr_rec/lightning.py:38-39, params.py:18)."""
+    opt_name, kind, k, b = cfg
+    users, items, d = 400, 900, 64
+
+    def build():
+        torch.manual_seed(7)
+        towers = mf.models.init_towers(mf.models.ModelConfig(num_users=users, num_items=items, hidden_size=d), device=DEV)
+        opt = (mf.optim.RowAdam(towers.parameters(), lr=0.01) if opt_name == "adam"
+               else mf.optim.SparseSGD(towers.parameters(), lr=0.05))
+        fn = getattr(mf.losses, kind)(num_negatives=k)
+        one = torch.ones((), device=DEV)
+
+        def step(bt):
+            loss = fn(towers["user"](bt["user"]), towers["item"](bt["item"]), bt["target"], item_idx=bt["item"], pos_idx=bt["pos"])
+            loss.backward(one)
+            opt.step()
+            return loss.detach()
+
+        return towers, opt, step
+
+    g = torch.Generator().manual_seed(b)
+    batches = []
+    for _ in range(4):
+        item = torch.randint(1, items, (2 * b,), generator=g)
+        pos = torch.randint(0, items, (b, 6), generator=g)
+        pos[:, 0] = item[:b]
+        batches.append({name: x.to(DEV) for name, x in dict(user=torch.randint(1, users, (b,), generator=g), item=item,
+                                                              target=torch.randint(1, 6, (b,), generator=g), pos=pos).items()})
+    # eager: three steps on batch 0 (what the capture's warm-up does), then batches 1..3
+    towers_e, opt_e, step_e = build()
+    losses_e = [step_e(bt) for bt in [batches[0]] * 3 + batches[1:]]
+    # captured
+    towers_g, opt_g, step_g = build()
+    captured = mf.graph.CapturedStep(step_g, batches[0], optimizers=[opt_g], warmup=3)
+    losses_g = [captured(bt).clone() for bt in batches[1:]]
+    assert captured.replays == 3
+    for name in ("user", "item"):
+        assert torch.equal(towers_g[name].weight, towers_e[name].weight), name
+    for le, lg in zip(losses_e[3:], losses_g):
+        assert torch.equal(le, lg)
+    if opt_name == "adam":
+        for pe, pg in zip(opt_e.param_groups[0]["params"], opt_g.param_groups[0]["params"]):
+            assert torch.equal(opt_e.state[pe]["exp_avg"], opt_g.state[pg]["exp_avg"])
+            assert opt_e.state[pe]["step"] == opt_g.state[pg]["step"] == 6
+    with pytest.raises(ValueError, match="ONE shape"):
+        captured({**batches[1], "user": batches[1]["user"][:-1]})
