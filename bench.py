@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes
+import hashlib
 import importlib
 import json
 import os
@@ -51,6 +52,26 @@ PEAK_HBM_GBS = 8000.0
 TOP_K, POS_PAD = 20, 64
 
 
+def csrc_sha() -> str:
+    """Fingerprint of the kernel sources: PMC traffic figures are only quoted for the sources they were measured on."""
+    h = hashlib.sha256()
+    pkg = ROOT / "matrix-factorization-torch_amd" / "csrc"
+    for f in sorted(list(pkg.glob("*.hip")) + list(pkg.glob("*.h")) + list((ROOT / "include").glob("*.h"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def cpu_model() -> str:
+    try:
+        for line in pathlib.Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +82,7 @@ def parse_args():
     ap.add_argument("--optimizer", choices=("adam", "sgd"), default="adam")
     ap.add_argument("--num-negatives", type=int, default=0, help="0 = all in-batch negatives (sampled softmax)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline legs (no SURVEY 8(d) matrix)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
 
@@ -69,51 +91,55 @@ def zipf_weights(n: int, s: float = 1.0) -> torch.Tensor:
     return 1.0 / torch.arange(1, n + 1, dtype=torch.float64) ** s
 
 
-def make_batches(n_batches: int, batch: int, seed: int, device):
+def make_batches(n_batches: int, batch: int, seed: int, device, *, num_users: int = NUM_USERS, num_items: int = NUM_ITEMS,
+                 pos_pad: int = POS_PAD):
     """MovieLens-shaped id batches: Zipf(1) item popularity, log-normal user activity."""
     g = torch.Generator().manual_seed(seed)
-    item_w = zipf_weights(NUM_ITEMS - 1)
-    user_w = torch.exp(torch.randn(NUM_USERS - 1, generator=g, dtype=torch.float64))
+    item_w = zipf_weights(num_items - 1)
+    user_w = torch.exp(torch.randn(num_users - 1, generator=g, dtype=torch.float64))
     out = []
     for _ in range(n_batches):
         user = torch.multinomial(user_w, batch, replacement=True, generator=g) + 1
         item = torch.multinomial(item_w, batch, replacement=True, generator=g) + 1
-        neg = torch.randint(1, NUM_ITEMS, (batch,), generator=g)
+        neg = torch.randint(1, num_items, (batch,), generator=g)
         target = torch.randint(1, 6, (batch,), generator=g)
-        n_pos = torch.randint(8, POS_PAD + 1, (batch,), generator=g)
-        pos = torch.multinomial(item_w, batch * POS_PAD, replacement=True, generator=g).reshape(batch, POS_PAD) + 1
+        n_pos = torch.randint(min(8, pos_pad), pos_pad + 1, (batch,), generator=g)
+        pos = torch.multinomial(item_w, batch * pos_pad, replacement=True, generator=g).reshape(batch, pos_pad) + 1
         pos[:, 0] = item
-        pos[torch.arange(POS_PAD)[None, :] >= n_pos[:, None]] = 0
+        pos[torch.arange(pos_pad)[None, :] >= n_pos[:, None]] = 0
         out.append({k: v.to(device) for k, v in
                     dict(user=user, item=torch.cat([item, neg]), target=target, pos=pos).items()})
-    counts = torch.bincount(torch.cat([b["item"].cpu() for b in out]), minlength=NUM_ITEMS)
+    counts = torch.bincount(torch.cat([b["item"].cpu() for b in out]), minlength=num_items)
     return out, counts
 
 
-def logq_table(device) -> torch.Tensor:
+def logq_table(device, num_items: int = NUM_ITEMS) -> torch.Tensor:
     """log of the sampling probability of each item row: positives ~ Zipf, negatives ~ uniform."""
-    w = zipf_weights(NUM_ITEMS - 1)
-    p = 0.5 * w / w.sum() + 0.5 / (NUM_ITEMS - 1)
+    w = zipf_weights(num_items - 1)
+    p = 0.5 * w / w.sum() + 0.5 / (num_items - 1)
     return torch.cat([torch.zeros(1, dtype=torch.float64), p.log()]).to(torch.float32).to(device)
 
 
 class Trainer:
     """The reference's training_step shape (xfmr_rec/lightning.py:97-147,189-192) on the HIP path."""
 
-    def __init__(self, mf, device, optimizer: str, num_negatives: int):
-        cfg = mf.models.ModelConfig(num_users=NUM_USERS, num_items=NUM_ITEMS, hidden_size=DIM)
+    def __init__(self, mf, device, optimizer: str, num_negatives: int, *, num_users: int = NUM_USERS,
+                 num_items: int = NUM_ITEMS, dim: int = DIM, loss: str = "InfomationNoiseContrastiveEstimationLoss",
+                 use_logq: bool = True):
+        cfg = mf.models.ModelConfig(num_users=num_users, num_items=num_items, hidden_size=dim)
         torch.manual_seed(0)
         self.towers = mf.models.init_towers(cfg, device=device)
-        self.loss_fn = mf.losses.InfomationNoiseContrastiveEstimationLoss(num_negatives=num_negatives, sigma=1.0)
+        self.loss_fn = getattr(mf.losses, loss)(num_negatives=num_negatives, sigma=1.0)
         params = list(self.towers.parameters())
         self.opt = mf.optim.RowAdam(params, lr=1e-4) if optimizer == "adam" else mf.optim.SparseSGD(params, lr=1e-2)
         if optimizer == "adam":
             self.opt.init_state()              # moment tables allocated here, not inside the first step
-        self.logq = logq_table(device)
+        self.dim, self.num_items, self.device = dim, num_items, device
+        self.logq = logq_table(device, num_items) if use_logq else None
         self.one = torch.ones((), device=device)      # upstream gradient of loss.backward(): no fill kernel per step
 
     def item_matrix(self) -> torch.Tensor:
-        return self.towers["item"](torch.arange(NUM_ITEMS, device=self.logq.device)).detach()
+        return self.towers["item"](torch.arange(self.num_items, device=self.device)).detach()
 
     def user_vectors(self, rows: torch.Tensor) -> torch.Tensor:
         return self.towers["user"](rows).detach()
@@ -121,7 +147,7 @@ class Trainer:
     def step(self, b) -> torch.Tensor:
         # the hit masks depend on the ids only and can be built on a side stream while the towers gather; measured
         # equal (1.1718 vs 1.1732 ms / step: the cross-stream join costs what the overlap saves), so off by default
-        masks = (self.loss_fn.prepare_masks(b["item"], b["pos"], batch_size=b["user"].numel(), embedding_dim=DIM)
+        masks = (self.loss_fn.prepare_masks(b["item"], b["pos"], batch_size=b["user"].numel(), embedding_dim=self.dim)
                  if os.environ.get("MF_BENCH_PREPARE", "0") == "1" else None)
         u = self.towers["user"](b["user"])
         v = self.towers["item"](b["item"])
@@ -133,7 +159,8 @@ class Trainer:
         return loss
 
 
-def spin_up(mf, device, what: str, index=None) -> None:
+def spin_up(mf, device, what: str, index=None, *, dim: int = DIM, loss: str = "InfomationNoiseContrastiveEstimationLoss",
+            num_negatives: int = 0, batch: int = 8192) -> None:
     """Device spin-up on SCRATCH data, queued right in front of a leg's W warm-up steps (no table, optimizer state or
     batch of the benchmark is touched).  Measured (tools/ramp_probe.py, ramp_probe2.py, clock_probe.py): whenever the
     device has idled for a few milliseconds -- the host preparing batches, an allocation, lazy code loading -- the
@@ -144,22 +171,22 @@ def spin_up(mf, device, what: str, index=None) -> None:
     behind them at once: the device never idles between here and the timed region's own synchronize."""
     g = torch.Generator(device="cpu").manual_seed(12345)
     if what == "train":
-        tiny = mf.models.init_towers(mf.models.ModelConfig(num_users=512, num_items=512, hidden_size=DIM), device=device)
+        tiny = mf.models.init_towers(mf.models.ModelConfig(num_users=512, num_items=512, hidden_size=dim), device=device)
         opt = mf.optim.RowAdam(tiny.parameters(), lr=1e-4)
-        fn = mf.losses.InfomationNoiseContrastiveEstimationLoss()
+        fn = getattr(mf.losses, loss)(num_negatives=num_negatives)
         ids = torch.arange(1, 257, device=device)
         item = torch.cat([ids, ids + 200])
         fn(tiny["user"](ids), tiny["item"](item), torch.ones(256, device=device), item_idx=item,
            pos_idx=ids[:, None].repeat(1, POS_PAD), logq=torch.zeros(512, device=device)).backward()
         opt.step()
-        u = torch.nn.functional.normalize(torch.randn(8192, DIM, generator=g), dim=-1).to(device).requires_grad_()
-        v = torch.nn.functional.normalize(torch.randn(16384, DIM, generator=g), dim=-1).to(device).requires_grad_()
-        item = torch.randint(1, NUM_ITEMS, (16384,), generator=g).to(device)
-        pos = torch.randint(0, NUM_ITEMS, (8192, POS_PAD), generator=g).to(device)
-        tgt, lq = torch.ones(8192, device=device), torch.zeros(16384, device=device)
-        work, n = (lambda: fn(u, v, tgt, item_idx=item, pos_idx=pos, logq=lq).backward()), 60   # noqa: E731
+        u = torch.nn.functional.normalize(torch.randn(batch, dim, generator=g), dim=-1).to(device).requires_grad_()
+        v = torch.nn.functional.normalize(torch.randn(2 * batch, dim, generator=g), dim=-1).to(device).requires_grad_()
+        item = torch.randint(1, NUM_ITEMS, (2 * batch,), generator=g).to(device)
+        pos = torch.randint(0, NUM_ITEMS, (batch, POS_PAD), generator=g).to(device)
+        tgt, lq = torch.ones(batch, device=device), torch.zeros(2 * batch, device=device)
+        work, n = (lambda: fn(u, v, tgt, item_idx=item, pos_idx=pos, logq=lq).backward()), max(4, int(60 * 8192 / batch) if batch >= 1024 else 8)   # noqa: E731
     else:
-        q = torch.nn.functional.normalize(torch.randn(1024, DIM, generator=g), dim=-1).to(device)
+        q = torch.nn.functional.normalize(torch.randn(1024, dim, generator=g), dim=-1).to(device)
         work, n = (lambda: index.search(q, TOP_K)), 200   # noqa: E731
     work()
     torch.cuda.synchronize()
@@ -186,10 +213,14 @@ def timed(fn, n_steps: int, dist_on: bool) -> float:
 
 
 def measured_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), or None."""
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r02_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).
+    The file records the fingerprint of the kernel sources it was measured on: a figure of other sources is not
+    quoted (None)."""
     try:
-        data = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())
+        data = json.loads((ROOT / "profiles" / "r02_traffic.json").read_text())
+        if data.get("csrc_sha") != csrc_sha():
+            return None
         return data["kernels"][kernel]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
@@ -201,8 +232,68 @@ def kernel_span(lib, name: str):
     return (tot.value / n if n else None), n
 
 
+TRAIN_KERNELS = ("loss_fwd_dense", "loss_bwd_du", "loss_bwd_dv", "mining_select", "gather_rows", "update_rows")
+
+
+def run_train_leg(mf, lib, device, *, batch: int, steps: int, warmup: int, optimizer: str = "adam", num_negatives: int = 0,
+                  loss: str = "InfomationNoiseContrastiveEstimationLoss", num_users: int = NUM_USERS, num_items: int = NUM_ITEMS,
+                  dim: int = DIM, pos_pad: int = POS_PAD, use_logq: bool = True, spin: bool = True, graph: bool = False,
+                  seed: int = 1000) -> dict:
+    """One single-GPU training leg: fresh tables, `warmup` untimed steps, `steps` timed ones; HIP-event spans of the
+    dominant kernels every TIME_EVERY-th launch.  graph=True: the step is captured in a hipGraph and replayed."""
+    n_batches = min(steps + warmup, 8)
+    batches, _ = make_batches(n_batches, batch, seed=seed, device=device, num_users=num_users, num_items=num_items,
+                              pos_pad=pos_pad)
+    trainer = Trainer(mf, device, optimizer, num_negatives, num_users=num_users, num_items=num_items, dim=dim, loss=loss,
+                      use_logq=use_logq)
+    step = trainer.step
+    if graph:
+        step = mf.graph.CapturedStep(trainer.step, batches[0], optimizers=[trainer.opt], warmup=3)
+    if spin:
+        spin_up(mf, device, "train", dim=dim, loss=loss, num_negatives=num_negatives, batch=batch)
+    for i in range(warmup):
+        step(batches[i % n_batches])
+    lib.mf_timing_reset()
+    if not graph:                                   # (event records inside a replayed graph would time nothing)
+        lib.mf_timing_enable(TIME_EVERY)
+    dt = timed(lambda i: step(batches[(warmup + i) % n_batches]), steps, False)
+    lib.mf_timing_enable(0)
+    spans = {n: kernel_span(lib, n)[0] for n in TRAIN_KERNELS}
+    return {"ms_per_step": dt / steps * 1e3, "pairs_per_s": batch * steps / dt, "spans": {k: v for k, v in spans.items() if v},
+            "trainer": trainer, "batches": batches}
+
+
+def train_roofline(spans: dict, batch: int, dim: int, world: int, optimizer: str):
+    """roofline of the dominant MFMA sweep + achieved HBM rates of the gather / update kernels (SURVEY 8d figures)."""
+    n = 2 * batch
+    flops = 2.0 * batch * n * dim                      # one B x N x d contraction per launch
+    sweeps = {k: spans[k] for k in ("loss_fwd_dense", "loss_bwd_du", "loss_bwd_dv", "mining_select") if spans.get(k)}
+    if not sweeps:
+        return None
+    dom = max(sweeps, key=sweeps.get)
+    ach = flops / (sweeps[dom] * 1e-3) / 1e12
+    out = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+           "traffic": measured_traffic(dom) if (batch, dim, world) == (8192, 128, 1) else None,
+           "avg_ms": round(sweeps[dom], 4),
+           "all_kernels_avg_ms": {k: round(v, 4) for k, v in spans.items()},
+           "all_sweeps_frac": {k: round(flops / (v * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) for k, v in sweeps.items()}}
+    hbm = {}
+    if spans.get("gather_rows"):      # two launches per step (B user rows, 2B item rows): 8 n d bytes each (read + write)
+        gb = 8.0 * (batch + n) * dim / (2 * spans["gather_rows"] * 1e-3) / 1e9
+        hbm["gather_rows"] = {"achieved_GBps": round(gb, 1), "frac_of_8TBps": round(gb / PEAK_HBM_GBS, 4),
+                              "algorithmic_bytes_per_step": int(8 * (batch + n) * dim)}
+    if spans.get("update_rows"):      # two launches per step; SURVEY 8d: 24 d (SGD) / 72 d (row Adam) bytes per pair
+        per_pair = 72 if optimizer == "adam" else 24
+        gb = float(per_pair) * dim * batch / (2 * spans["update_rows"] * 1e-3) / 1e9
+        hbm["update_rows"] = {"achieved_GBps": round(gb, 1), "frac_of_8TBps": round(gb / PEAK_HBM_GBS, 4),
+                              "algorithmic_bytes_per_step": int(per_pair * dim * batch)}
+    out["hbm_kernels"] = hbm
+    return out
+
+
 def cpu_train_baseline(batches, logq, optimizer: str, n_steps: int, num_negatives: int):
-    """The oracle's restatement of the same step (torch CPU, all host cores)."""
+    """The oracle's restatement of the same step (torch CPU, the current thread setting)."""
     from oracle import embed as oembed, losses as ol
 
     torch.manual_seed(0)
@@ -228,6 +319,83 @@ def cpu_train_baseline(batches, logq, optimizer: str, n_steps: int, num_negative
     return time.perf_counter() - t0
 
 
+def cpu_topk_once(q: torch.Tensor, items: torch.Tensor, k: int, excl_rows: torch.Tensor, excl_cols: torch.Tensor):
+    """All-core brute force: one matmul, one masked fill (the exclusion lists as two index vectors), one topk."""
+    s = q @ items.T
+    s[excl_rows, excl_cols] = float("-inf")
+    return torch.topk(s, k, dim=1)
+
+
+def cpu_baselines(args, batches, queries, items, pieces) -> dict:
+    """CPU baseline on the host cores of this box (rank 0, N = 1): the oracle's restatement of the SAME workload, on a
+    bounded sample.  The thread count is swept on a reduced sample first (oversubscribing a 256-thread host is slower
+    than 32 .. 64 threads) and the best setting runs the full-size sample."""
+    b = batches[0]["user"].numel()
+    cores = os.cpu_count() or 1
+    cands = sorted({t for t in (8, 16, 32, 64, 128, cores) if t <= cores})
+    small = [{k: (v[:2048] if k != "item" else torch.cat([v[:2048], v[b: b + 2048]])) for k, v in bt.items()} for bt in batches[:1]]
+    lq = logq_table("cpu")
+    sweep = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        cpu_train_baseline(small, lq, args.optimizer, 1, args.num_negatives)          # warm
+        sweep[t] = cpu_train_baseline(small, lq, args.optimizer, 1, args.num_negatives)
+    best_t = min(sweep, key=sweep.get)
+    torch.set_num_threads(best_t)
+    dt_cpu = cpu_train_baseline(batches[: args.cpu_steps], lq, args.optimizer, args.cpu_steps, args.num_negatives)
+    # top-k
+    qn = queries.shape[0]
+    rows = torch.cat([torch.full((p.numel(),), r, dtype=torch.int64) for r, p in enumerate(pieces)])
+    cols = torch.cat(pieces)
+    tk = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        cpu_topk_once(queries, items, TOP_K, rows, cols)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            cpu_topk_once(queries, items, TOP_K, rows, cols)
+        tk[t] = (time.perf_counter() - t0) / 3
+    best_k = min(tk, key=tk.get)
+    return {"value": round(b * args.cpu_steps / dt_cpu, 1), "unit": "pairs/s", "cores": best_t, "kind": "port",
+            "cpu_model": cpu_model(), "host_threads_available": cores,
+            "thread_sweep_s_per_reduced_step": {str(t): round(v, 3) for t, v in sweep.items()},
+            "sample": f"{args.cpu_steps} steps of the same workload (B={b}, N={2 * b}, d={DIM}, InfoNCE+logQ, "
+                      f"{args.optimizer}) by oracle/ on torch CPU at the best thread count of a sweep over {cands} "
+                      f"(swept on B=2048); top-k: 3 batches of Q={qn} per thread count, best kept",
+            "topk_value": round(qn / tk[best_k], 1), "topk_unit": "queries/s", "topk_cores": best_k,
+            "topk_thread_sweep_ms": {str(t): round(v * 1e3, 1) for t, v in tk.items()}}
+
+
+def topk_small_leg(mf, lib, index, device, dim: int, rank: int) -> dict:
+    """Q = 1: the reference's own retrieval shape (one query per call, data/lightning.py:237-259).  Device time of a
+    call (both launches) from HIP events; bandwidth = catalog bytes / time against HBM."""
+    g = torch.Generator().manual_seed(99 + rank)
+    out = {}
+    for q in (1, 8):
+        queries = torch.nn.functional.normalize(torch.randn(q, dim, generator=g), dim=-1).to(device)
+        lens = torch.randint(20, 300, (q,), generator=g)
+        off = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).to(device)
+        ids = torch.randint(1, index.num_items, (int(lens.sum()),), generator=g).to(device)
+        for _ in range(50):
+            index.search(queries, TOP_K, exclude_csr=(off, ids))
+        torch.cuda.synchronize()
+        lib.mf_timing_reset()
+        lib.mf_timing_enable(1)
+        reps = 300
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            index.search(queries, TOP_K, exclude_csr=(off, ids))
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / reps
+        lib.mf_timing_enable(0)
+        us = kernel_span(lib, "topk_small")[0] * 1e3
+        gbs = index.num_items * dim * 4 / (us * 1e-6) / 1e9
+        out[f"q{q}"] = {"latency_us": round(us, 2), "wall_us_per_call": round(wall * 1e6, 1), "queries_per_s": round(q / wall, 1),
+                        "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK_HBM_GBS, 4), "frac_of_6.3TBps_achievable": round(gbs / 6300.0, 4),
+                        "kernels": "topk_small_scan_kernel + topk_small_select_kernel", "bound": "hbm"}
+    return out
+
+
 def main() -> None:
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -245,50 +413,48 @@ def main() -> None:
     mf = importlib.import_module("matrix-factorization-torch_amd")
     lib = mf._lib.lib()
     B, Q, K, W = args.batch, args.queries, args.steps, args.warmup
+    extras = {}
 
     # ------------------------------------------------------------------ training leg --
-    n_batches = min(K + W, 8)
-    batches, _ = make_batches(n_batches, B, seed=1000 + rank, device=device)
+    cold_ms = None
     if dist_on:
+        n_batches = min(K + W, 8)
+        batches, _ = make_batches(n_batches, B, seed=1000 + rank, device=device)
         trainer = mf.distributed.ShardedTrainer(mf, device, args.optimizer, args.num_negatives,
                                                 num_users=NUM_USERS, num_items=NUM_ITEMS, dim=DIM, logq=logq_table(device))
         span_u = trainer.user_hi - trainer.user_lo          # pairs are partitioned by user shard
         for b in batches:
             b["user"] = trainer.user_lo + b["user"] % span_u
-    else:
-        trainer = Trainer(mf, device, args.optimizer, args.num_negatives)
-    if dist_on:      # the sharded step prefetches the exchange plan of the batch after it (ids are known ahead)
+        # the sharded step prefetches the exchange plan of the batch after it (ids are known ahead)
         run_step = lambda j: trainer.step(batches[j % n_batches], next_b=batches[(j + 1) % n_batches])  # noqa: E731
-    else:
-        run_step = lambda j: trainer.step(batches[j % n_batches])  # noqa: E731
-    if dist_on:      # everything that would stall the first sharded step happens before the spin-up: RCCL's lazy
+        # everything that would stall the first sharded step happens before the spin-up: RCCL's lazy
         # initialisation (first collective) and the first batch's exchange plan (a host sync)
         warm = torch.zeros(world, dtype=torch.int64, device=device)
         torch.distributed.all_to_all_single(torch.empty_like(warm), warm)
         trainer.prefetch(batches[0])
         torch.cuda.synchronize()
-    spin_up(mf, device, "train")
-    for i in range(W):
-        run_step(i)
-    lib.mf_timing_reset()
-    lib.mf_timing_enable(TIME_EVERY)
-    dt_train = timed(lambda i: run_step(W + i), K, dist_on)
-    lib.mf_timing_enable(0)
+        spin_up(mf, device, "train")
+        for i in range(W):
+            run_step(i)
+        lib.mf_timing_reset()
+        lib.mf_timing_enable(TIME_EVERY)
+        dt_train = timed(lambda i: run_step(W + i), K, dist_on)
+        lib.mf_timing_enable(0)
+        spans = {n: kernel_span(lib, n)[0] for n in TRAIN_KERNELS}
+        spans = {k: v for k, v in spans.items() if v}
+    else:
+        # cold first: what a step costs right after the device has idled (no spin-up; DESIGN.md 4, "post-idle ramp")
+        time.sleep(0.05)
+        cold = run_train_leg(mf, lib, device, batch=B, steps=min(K, 20), warmup=min(W, 3), optimizer=args.optimizer,
+                             num_negatives=args.num_negatives, spin=False)
+        cold_ms = cold["ms_per_step"]
+        del cold
+        leg = run_train_leg(mf, lib, device, batch=B, steps=K, warmup=W, optimizer=args.optimizer,
+                            num_negatives=args.num_negatives, spin=True)
+        dt_train, spans, trainer, batches = leg["ms_per_step"] * K / 1e3, leg["spans"], leg["trainer"], leg["batches"]
     pairs_per_s = world * B * K / dt_train
     N = 2 * B
-    spans = {n: kernel_span(lib, n)[0] for n in ("loss_fwd_dense", "loss_bwd_du", "loss_bwd_dv", "mining_select",
-                                                 "gather_rows", "update_rows")}
-    dense = {n: spans[n] for n in ("loss_fwd_dense", "loss_bwd_du", "loss_bwd_dv") if spans[n]}
-    train_roof = None
-    if dense:
-        dom = max(dense, key=dense.get)
-        flops = 2.0 * B * N * DIM                      # one B x N x d contraction per launch
-        ach = flops / (dense[dom] * 1e-3) / 1e12
-        train_roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                      "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                      "traffic": measured_traffic(dom) if (B, DIM, world) == (8192, 128, 1) else None,
-                      "avg_ms": round(dense[dom], 4),
-                      "all_kernels_avg_ms": {k: round(v, 4) for k, v in spans.items() if v}}
+    train_roof = train_roofline(spans, B, DIM, world, args.optimizer)
 
     # ----------------------------------------------------------------- retrieval leg --
     with torch.no_grad():
@@ -302,6 +468,7 @@ def main() -> None:
         pieces.append(torch.unique(torch.multinomial(item_w, n, replacement=True, generator=g) + 1))
         offs.append(offs[-1] + pieces[-1].numel())
     csr = (torch.tensor(offs, dtype=torch.int64, device=device), torch.cat(pieces).to(device))
+    index = None
     if dist_on:
         searcher = mf.distributed.ShardedIndex(trainer.item_shard(), trainer.item_offset(), NUM_ITEMS, stride=trainer.item_stride())
         run_topk = lambda i: searcher.search(queries, TOP_K, exclude_csr=csr)   # noqa: E731
@@ -331,27 +498,44 @@ def main() -> None:
                      "traffic": measured_traffic("topk_select") if (Q, DIM, world) == (1024, 128, 1) else None,
                      "avg_ms": round(span, 4)}
 
+    # ------------------------------------------------- SURVEY 8(d) matrix (N = 1 only) ----
+    if not dist_on and not args.no_extras:
+        def brief(leg, batch, dim, optimizer="adam"):
+            roof = train_roofline(leg["spans"], batch, dim, 1, optimizer)
+            return {"ms_per_step": round(leg["ms_per_step"], 4), "pairs_per_s": round(leg["pairs_per_s"], 1),
+                    "roofline": None if roof is None else {k: roof[k] for k in ("kernel", "achieved", "frac", "avg_ms", "all_sweeps_frac", "hbm_kernels")}}
+
+        extras["q_small"] = topk_small_leg(mf, lib, index, device, DIM, rank)
+        del index
+        # the reference's DEFAULT training configuration (xfmr_rec/lightning.py:38-39): PairwiseHingeLoss, num_negatives = 4
+        leg = run_train_leg(mf, lib, device, batch=B, steps=40, warmup=5, loss="PairwiseHingeLoss", num_negatives=4, use_logq=False)
+        extras["mined"] = {"workload": "C3 shape, PairwiseHingeLoss, num_negatives=4 (reference default loss), row-adam",
+                           **brief(leg, B, DIM)}
+        del leg
+        # config C2: MovieLens-1M shape, d = 64, in-batch sampled softmax
+        leg = run_train_leg(mf, lib, device, batch=B, steps=40, warmup=5, num_users=6041, num_items=3884, dim=64, use_logq=False)
+        extras["c2_ml1m_d64"] = {"workload": "C2: MovieLens-1M shape (6,040 x 3,883), d=64, InfoNCE, row-adam", **brief(leg, B, 64)}
+        del leg
+        # positive lists of 1024 ids per user (SURVEY 8d stress: hits_kernel leaves its LDS table for global atomics)
+        leg = run_train_leg(mf, lib, device, batch=B, steps=20, warmup=3, pos_pad=1024)
+        extras["pos_pad_1024"] = {"workload": "C3 shape, InfoNCE + logQ, P = 1024 padded positives per user", **brief(leg, B, DIM)}
+        del leg
+        # small batches: eager against one hipGraph replay per step
+        for name, bsz, kw in (("b1024", 1024, {}), ("b32", 32, {}),
+                              ("b32_reference_default", 32, {"loss": "PairwiseHingeLoss", "num_negatives": 4, "use_logq": False})):
+            eager = run_train_leg(mf, lib, device, batch=bsz, steps=200, warmup=20, spin=False, **kw)
+            graphed = run_train_leg(mf, lib, device, batch=bsz, steps=200, warmup=20, spin=False, graph=True, **kw)
+            extras[name] = {"workload": f"C3 shape, B = {bsz}, " + (kw.get("loss", "InfoNCE + logQ")) + ", row-adam",
+                            "eager_ms_per_step": round(eager["ms_per_step"], 4), "graph_ms_per_step": round(graphed["ms_per_step"], 4),
+                            "eager_pairs_per_s": round(eager["pairs_per_s"], 1), "graph_pairs_per_s": round(graphed["pairs_per_s"], 1)}
+            del eager, graphed
+        torch.cuda.empty_cache()
+
     # --------------------------------------------------------------------- CPU leg ----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import retrieval as oretr
-
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
-        cb = [{k: v.cpu() for k, v in b.items()} for b in batches[: args.cpu_steps]]
-        dt_cpu = cpu_train_baseline(cb, logq_table("cpu"), args.optimizer, args.cpu_steps, args.num_negatives)
-        qc, ic = queries.cpu(), items.cpu()
-        excl = [p.tolist() for p in pieces]
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            oretr.topk_fast(qc, ic, TOP_K, excl)
-        dt_cpu_topk = (time.perf_counter() - t0) / reps
-        cpu = {"value": round(B * args.cpu_steps / dt_cpu, 1), "unit": "pairs/s", "cores": torch.get_num_threads(),
-               "kind": "port",
-               "sample": f"{args.cpu_steps} steps of the same workload (B={B}, N={N}, d={DIM}, InfoNCE+logQ, "
-                         f"{args.optimizer}) by oracle/ on torch CPU; top-k: {reps} batches of Q={Q}",
-               "topk_value": round(Q / dt_cpu_topk, 1), "topk_unit": "queries/s"}
+    if rank == 0 and world == 1 and not dist_on and not args.no_cpu_baseline:
+        cb = [{k: v.cpu() for k, v in b.items()} for b in batches[: max(args.cpu_steps, 1)]]
+        cpu = cpu_baselines(args, cb, queries.cpu(), items.cpu(), pieces)
 
     if rank == 0:
         line = {
@@ -363,9 +547,11 @@ def main() -> None:
                                    f"num_negatives={args.num_negatives}, row-{args.optimizer} update",
                        "batch_per_gpu": B, "items_per_step": N, "pos_pad": POS_PAD,
                        "parallelism": f"dp{world}" + (" + item rows sharded" if dist_on else "")},
+            "cold_ms_per_step": None if cold_ms is None else round(cold_ms, 4),
             "roofline": train_roof,
             "topk": {"value": round(qps, 1), "unit": "queries/s", "ms_per_step": round(dt_topk / K * 1e3, 4),
                      "queries_per_gpu": Q, "k": TOP_K, "catalog_rows": NUM_ITEMS, "roofline": topk_roof},
+            "extras": extras,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
