@@ -240,6 +240,26 @@ int mf_sample_batch(const int64_t* pair_user, const int64_t* pair_item, const fl
                     int64_t start, int64_t B, int P, int64_t* out_user, int64_t* out_item, float* out_target,
                     int64_t* out_pos, mf_stream_t stream);
 
+/* ----------------------------------------------------------- sharded path ---
+ * The reference has no collective; these serve the row-sharded design of distributed.py.
+ * mf_init_rows fills a shard on its own device: local row l = global row row_start + l * row_stride of a
+ * virtual [rows, d] table of std-scaled normal variates that are a pure function of (seed, global row,
+ * column) -- no host copy of the whole table, values independent of the number of ranks.
+ * mf_comm_*: RCCL (opened lazily) called on the CALLER'S stream: an exchange is a node between two kernels,
+ * not a cross-stream join.  Bootstrap: rank 0 gets 128 bytes from mf_comm_unique_id, every rank receives
+ * them by any side channel and calls mf_comm_create (a collective).  mf_comm_all_to_all_rows is a direct
+ * all-to-all of row blocks (grouped send / recv: point-to-point xGMI links, no ring) with the per-peer row
+ * counts on the host; mf_comm_all_gather the fixed-size gather of the retrieval queries. */
+int mf_init_rows(float* table, int64_t n_local, int d, int64_t row_start, int64_t row_stride, uint64_t seed,
+                 float std, mf_stream_t stream);
+int mf_comm_unique_id(void* out128);
+int mf_comm_create(int world, int rank, const void* id128, void** out_comm);
+int mf_comm_destroy(void* comm);
+int mf_comm_world(void* comm);
+int mf_comm_all_to_all_rows(void* comm, const void* send, const int64_t* send_rows_host, void* recv,
+                            const int64_t* recv_rows_host, int64_t row_bytes, mf_stream_t stream);
+int mf_comm_all_gather(void* comm, const void* send, void* recv, int64_t bytes, mf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,13 @@ SIGNATURES = {
                                 c_vp, c_vp]),
     "mf_retrieval_metrics": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mf_topk_merge": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "mf_init_rows": (c_int, [c_vp, c_i64, c_int, c_i64, c_i64, ctypes.c_uint64, c_f32, c_vp]),
+    "mf_comm_unique_id": (c_int, [c_vp]),
+    "mf_comm_create": (c_int, [c_int, c_int, c_vp, ctypes.POINTER(c_vp)]),
+    "mf_comm_destroy": (c_int, [c_vp]),
+    "mf_comm_world": (c_int, [c_vp]),
+    "mf_comm_all_to_all_rows": (c_int, [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64), c_i64, c_vp]),
+    "mf_comm_all_gather": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mf_topk_blocked_bytes": (c_sz, [c_i64, c_int]),
     "mf_topk_blocked_build": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "mf_topk_small_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int]),

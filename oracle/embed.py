@@ -86,6 +86,26 @@ def adam_update(table, m, v, idx, grad, *, step: int, lr: float, beta1: float = 
     v[uniq] = vv
 
 
+def init_rows(n_local: int, d: int, row_start: int, row_stride: int, seed: int, std: float) -> torch.Tensor:
+    """Shard initialisation of the sharded path (``mf_init_rows``, csrc/mf_comm.hip; our spec): local row l is global row
+    ``row_start + l * row_stride`` of a virtual table whose element (row, col) is ``std`` times a normal variate that is a
+    pure function of (seed, row, col): SplitMix64 of ``seed + (row * d + col) * golden gamma``, two 24-bit uniforms,
+    Box-Muller.  numpy restatement (uint64 wrap-around arithmetic)."""
+    import numpy as np
+
+    rows = np.uint64(row_start) + np.arange(n_local, dtype=np.uint64) * np.uint64(row_stride)
+    idx = rows[:, None] * np.uint64(d) + np.arange(d, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u1 = ((z >> np.uint64(40)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    u2 = (((z >> np.uint64(16)) & np.uint64(0xFFFFFF)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    out = np.float32(std) * np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)
+    return torch.from_numpy(out.astype(np.float32))
+
+
 def logq_from_counts(counts: torch.Tensor) -> torch.Tensor:
     """log of the empirical sampling probability of each item (Yi et al. 2019; the
     README cites it, README.md:29-30, but the reference never implements it)."""

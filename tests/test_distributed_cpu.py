@@ -18,25 +18,46 @@ from oracle import chain, embed as oembed, losses as ol, retrieval as oretr
 class OracleOps:
     """Local compute by the CPU oracle (test infrastructure standing in for HipOps)."""
 
-    def gather(self, table, ids, normalize):
-        return oembed.gather(table, ids, normalize)
+    def init_rows(self, n_local, d, row_start, row_stride, seed, std, device):
+        return oembed.init_rows(n_local, d, row_start, row_stride, seed, std)
 
-    def loss_and_grads(self, kind, u, v, target, item_idx, pos_idx, logq, num_negatives, sigma, margin):
+    def gather(self, table, ids, normalize, want_inv=False):
+        rows = table[ids]
+        if not normalize:
+            return (rows, torch.ones(ids.numel())) if want_inv else rows
+        inv = 1.0 / rows.norm(dim=-1).clamp_min(1e-12)
+        return (rows * inv[:, None], inv) if want_inv else rows * inv[:, None]
+
+    def hash_buckets(self, ids, num_hashes, seed, num_buckets):
+        return oembed.hash_buckets(ids, num_hashes, seed, num_buckets).reshape(-1)
+
+    def bloom_forward(self, bucket_rows, num_hashes):
+        n = bucket_rows.shape[0] // num_hashes
+        raw = bucket_rows.view(n, num_hashes, -1).sum(dim=1)
+        inv = 1.0 / raw.norm(dim=-1).clamp_min(1e-12)
+        return raw * inv[:, None], inv
+
+    def bloom_backward(self, unit, inv, grad, num_hashes):
+        graw = (grad - unit * (grad * unit).sum(-1, keepdim=True)) * inv[:, None]
+        return graw.repeat_interleave(num_hashes, dim=0)
+
+    def loss_and_grads(self, kind, u, v, target, item_idx, pos_idx, logq_table, num_negatives, sigma, margin):
         u = u.detach().clone().requires_grad_()
         v = v.detach().clone().requires_grad_()
         loss = ol.loss(kind, u, v, target, item_idx=item_idx, pos_idx=pos_idx, num_negatives=num_negatives, sigma=sigma,
-                       margin=margin, logq=logq)
+                       margin=margin, logq=None if logq_table is None else logq_table[item_idx])
         loss.backward()
         return loss.detach(), u.grad, v.grad
 
-    def update(self, optimizer, table, state, ids, grad, normalized, step, lr):
+    def update(self, optimizer, table, state, ids, grad, normalized, step, hyper):
         if ids.numel() == 0:
             return
         g = oembed.normalize_backward(table[ids], grad) if normalized else grad
         if optimizer == "sgd":
-            oembed.sgd_update(table, ids, g, lr)
+            oembed.sgd_update(table, ids, g, hyper["lr"], hyper["weight_decay"])
         else:
-            oembed.adam_update(table, state["m"], state["v"], ids, g, step=step, lr=lr, weight_decay=0.01)
+            oembed.adam_update(table, state["m"], state["v"], ids, g, step=step, lr=hyper["lr"], beta1=hyper["betas"][0],
+                               beta2=hyper["betas"][1], eps=hyper["eps"], weight_decay=hyper["weight_decay"])
 
     def topk(self, queries, items, k, exclude_csr, idx_base):
         excl = None
@@ -95,45 +116,121 @@ def _train_case(rank: int, world: int, out_dir: str) -> None:
     for opt in ("sgd", "adam"):
         tr = mfd.ShardedTrainer(mf, "cpu", opt, 0, num_users=N_USERS, num_items=N_ITEMS, dim=DIM, ops=OracleOps(), lr=0.05,
                                 kind="PairwiseLogisticLoss")
+        assert isinstance(tr.comm, mfd.TorchComm)
         b = _batch(rank, world, mfd)
         tr.prefetch(b)                                   # the plan built ahead of time is the one the step uses
-        assert b["item"].data_ptr() in tr._plans
+        assert tr._key(b) in tr._plans
+        # a plan is bound to the very tensors it was built from: a batch that merely looks alike gets its own
+        other = {k: v.clone() for k, v in b.items()}
+        assert tr._key(other) not in tr._plans
         loss = tr.step(b, next_b=b)
-        assert list(tr._plans) == [b["item"].data_ptr()]  # consumed, and the next one prefetched
+        assert list(tr._plans) == [tr._key(b)]           # consumed, and the next one prefetched
         torch.save({"user": tr.user_table, "item": tr.item_table, "loss": loss}, f"{out_dir}/{opt}_{rank}.pt")
+        # a prefetched plan that is never consumed (skipped batch, epoch end) is dropped, not matched to a later batch
+        tr.prefetch(other)
+        for _ in range(3):
+            tr.step(_batch(rank, world, mfd))
+        assert tr._key(other) not in tr._plans
 
 
-def test_sharded_training_step_matches_single_process(tmp_path):
-    """After one step the concatenated shards equal one process applying every rank's gradients
-    (computed from the same pre-step tables) in a single sparse update per table."""
+def _check_train(tmp_path, world: int) -> None:
     mf = importlib.import_module("matrix-factorization-torch_amd")
     mfd = mf.distributed
-    _run("_train_case", tmp_path)
+    std = 1.0 / DIM**0.5
     for opt in ("sgd", "adam"):
-        g = torch.Generator().manual_seed(0)
-        ut = torch.randn(N_USERS, DIM, generator=g) / DIM**0.5
-        it = torch.randn(N_ITEMS, DIM, generator=g) / DIM**0.5
+        ut = oembed.init_rows(N_USERS, DIM, 0, 1, 0, std)          # the virtual tables every shard was cut from
+        it = oembed.init_rows(N_ITEMS, DIM, 0, 1, 1, std)
         ut0, it0 = ut.clone(), it.clone()
         ops = OracleOps()
+        hyper = mfd.optimizer_hyper(opt, 0.05)
         u_ids, u_g, i_ids, i_g, losses = [], [], [], [], []
-        for r in range(2):
-            b = _batch(r, 2, mfd)
+        for r in range(world):
+            b = _batch(r, world, mfd)
             loss, du, dv = ops.loss_and_grads("PairwiseLogisticLoss", oembed.gather(ut0, b["user"], True),
                                               oembed.gather(it0, b["item"], True), b["target"], b["item"], b["pos"], None,
                                               0, 1.0, 1.0)
             u_ids.append(b["user"]); u_g.append(du); i_ids.append(b["item"]); i_g.append(dv); losses.append(loss)
         st = {"m": torch.zeros_like(ut), "v": torch.zeros_like(ut)}
-        ops.update(opt, ut, st, torch.cat(u_ids), torch.cat(u_g), True, 1, 0.05)
+        ops.update(opt, ut, st, torch.cat(u_ids), torch.cat(u_g), True, 1, hyper)
         st = {"m": torch.zeros_like(it), "v": torch.zeros_like(it)}
-        ops.update(opt, it, st, torch.cat(i_ids), torch.cat(i_g), True, 1, 0.05)
-        got = [torch.load(f"{tmp_path}/{opt}_{r}.pt") for r in range(2)]
+        ops.update(opt, it, st, torch.cat(i_ids), torch.cat(i_g), True, 1, hyper)
+        got = [torch.load(f"{tmp_path}/{opt}_{r}.pt") for r in range(world)]
         torch.testing.assert_close(torch.cat([x["user"] for x in got]), ut, rtol=1e-5, atol=1e-6)
         items = torch.empty_like(it)
-        for r in range(2):
-            items[r::2] = got[r]["item"]              # item rows are dealt round-robin
+        for r in range(world):
+            items[r::world] = got[r]["item"]              # item rows are dealt round-robin
         torch.testing.assert_close(items, it, rtol=1e-5, atol=1e-6)
-        for r in range(2):
+        for r in range(world):
             torch.testing.assert_close(got[r]["loss"], losses[r])
+
+
+def test_sharded_training_step_matches_single_process(tmp_path):
+    """After one step the concatenated shards equal one process applying every rank's gradients
+    (computed from the same pre-step tables) in a single sparse update per table."""
+    _run("_train_case", tmp_path)
+    _check_train(tmp_path, 2)
+
+
+def test_sharded_training_step_world_4(tmp_path):
+    _run("_train_case", tmp_path, world=4)
+    _check_train(tmp_path, 4)
+
+
+# hash / bloom towers (BASELINE config 5 shape: ids far beyond the table height, d = 256 there; 2 hashes)
+HB_U, HB_I, HD, HH = 23, 57, 32, 2
+
+
+def _hashed_batch(rank: int):
+    g = torch.Generator().manual_seed(300 + rank)
+    item = torch.randint(0, 100_000_000, (2 * B,), generator=g)
+    item[B: B + 3] = item[:3]                         # negatives colliding with positives
+    pos = torch.randint(0, 100_000_000, (B, P), generator=g)
+    pos[:, 0] = item[:B]
+    return {"user": torch.randint(0, 10_000_000, (B,), generator=g), "item": item,
+            "target": torch.randint(1, 6, (B,), generator=g), "pos": pos}
+
+
+def _hashed_case(rank: int, world: int, out_dir: str) -> None:
+    mf = importlib.import_module("matrix-factorization-torch_amd")
+    tr = mf.distributed.ShardedTrainer(mf, "cpu", "sgd", 0, num_users=HB_U, num_items=HB_I, dim=HD, ops=OracleOps(), lr=0.05,
+                                       num_hashes=HH, hash_seed=3)
+    b = _hashed_batch(rank)
+    loss = tr.step(b, next_b=b)
+    torch.save({"user": tr.user_table, "item": tr.item_table, "loss": loss}, f"{out_dir}/hashed_{rank}.pt")
+
+
+def test_sharded_hashed_towers_match_single_process(tmp_path):
+    """Config 5's structure on two ranks: both bucket tables dealt round-robin, every id's bucket rows fetched from
+    their owners, summed, normalised; bucket-row gradients pushed back and applied once per owner -- equal to one process
+    doing the same step on the whole bucket tables."""
+    world = 2
+    _run("_hashed_case", tmp_path, world=world)
+    std = 1.0 / (HD * HH) ** 0.5
+    tu, ti = oembed.init_rows(HB_U, HD, 0, 1, 0, std), oembed.init_rows(HB_I, HD, 0, 1, 1, std)
+    tu0, ti0 = tu.clone(), ti.clone()
+    ub_all, ug_all, ib_all, ig_all, losses = [], [], [], [], []
+    for r in range(world):
+        b = _hashed_batch(r)
+        bu, bi = oembed.hash_buckets(b["user"], HH, 3, HB_U), oembed.hash_buckets(b["item"], HH, 4, HB_I)
+        raw_u = (tu0[bu[:, 0]] + tu0[bu[:, 1]]).requires_grad_()
+        raw_i = (ti0[bi[:, 0]] + ti0[bi[:, 1]]).requires_grad_()
+        un = raw_u / raw_u.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        vn = raw_i / raw_i.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        loss = ol.loss("InfomationNoiseContrastiveEstimationLoss", un, vn, b["target"], item_idx=b["item"], pos_idx=b["pos"])
+        loss.backward()
+        losses.append(loss.detach())
+        ub_all.append(bu.reshape(-1)); ug_all.append(raw_u.grad.repeat_interleave(HH, dim=0))
+        ib_all.append(bi.reshape(-1)); ig_all.append(raw_i.grad.repeat_interleave(HH, dim=0))
+    oembed.sgd_update(tu, torch.cat(ub_all), torch.cat(ug_all), 0.05, 0.0)
+    oembed.sgd_update(ti, torch.cat(ib_all), torch.cat(ig_all), 0.05, 0.0)
+    got = [torch.load(f"{tmp_path}/hashed_{r}.pt") for r in range(world)]
+    for name, want in (("user", tu), ("item", ti)):
+        full = torch.empty_like(want)
+        for r in range(world):
+            full[r::world] = got[r][name]
+        torch.testing.assert_close(full, want, rtol=1e-5, atol=1e-6)
+    for r in range(world):
+        torch.testing.assert_close(got[r]["loss"], losses[r], rtol=1e-5, atol=1e-6)
 
 
 def _topk_case(rank: int, world: int, out_dir: str) -> None:

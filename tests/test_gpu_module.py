@@ -219,10 +219,38 @@ def test_sharded_classes_on_one_rank_use_the_hip_path(mf):
         assert float(got) == float(want)
         torch.testing.assert_close(tr.item_table, towers["item"].weight.detach(), rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(tr.user_table, towers["user"].weight.detach(), rtol=1e-6, atol=1e-7)
+        assert isinstance(tr.comm, mf.distributed.RcclComm)           # the exchanges ran through mf_comm_* on the compute stream
         q = tr.user_vectors(torch.arange(1, 9, device=DEV))
         s1, i1 = mf.distributed.ShardedIndex(tr.item_shard(), tr.item_offset(), ni, stride=tr.item_stride()).search(q, 10)
         s2, i2 = mf.retrieval.ItemIndex(tr.item_shard()).search(q, 10)
         assert torch.equal(i1, i2) and torch.equal(s1, s2)
+        # shards are generated on the device: the counter-based generator against its numpy restatement
+        from oracle import embed as oembed
+
+        for start, stride, n_loc in ((0, 1, 300), (3, 8, 41)):
+            got = mf.distributed.HipOps(mf).init_rows(n_loc, d, start, stride, 5, 0.125, DEV)
+            torch.testing.assert_close(got.cpu(), oembed.init_rows(n_loc, d, start, stride, 5, 0.125), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(tr.user_table.cpu() * 0 + mf.distributed.HipOps(mf).init_rows(nu, d, 0, 1, 0, 1 / d**0.5, DEV).cpu(),
+                                   oembed.init_rows(nu, d, 0, 1, 0, 1 / d**0.5), rtol=1e-5, atol=1e-6)
+        # hash / bloom towers through the sharded step (one rank: every bucket row is "remote" to itself) ==
+        # the single-GPU HashEmbeddingTower step on the same bucket tables
+        bu, bi, nh = 700, 1900, 2
+        trh = mf.distributed.ShardedTrainer(mf, DEV, "sgd", 0, num_users=bu, num_items=bi, dim=d, lr=0.1, num_hashes=nh, hash_seed=3)
+        towers = mf.models.init_towers(mf.models.ModelConfig(num_users=bu, num_items=bi, hidden_size=d, num_hashes=nh, hash_seed=3),
+                                       device=DEV)
+        with torch.no_grad():
+            towers["user"].weight.copy_(trh.user_table)
+            towers["item"].weight.copy_(trh.item_table)
+        hb = {"user": torch.randint(0, 10_000_000, (b,), generator=g).to(DEV), "item": torch.randint(0, 100_000_000, (2 * b,), generator=g).to(DEV),
+              "target": batch["target"], "pos": torch.randint(0, 100_000_000, (b, 5), generator=g).to(DEV)}
+        opt = mf.optim.SparseSGD(towers.parameters(), lr=0.1)
+        want = fn(towers["user"](hb["user"]), towers["item"](hb["item"]), hb["target"], item_idx=hb["item"], pos_idx=hb["pos"])
+        want.backward()
+        opt.step()
+        got = trh.step(hb)
+        torch.testing.assert_close(got, want.detach(), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(trh.item_table, towers["item"].weight.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(trh.user_table, towers["user"].weight.detach(), rtol=1e-5, atol=1e-6)
     finally:
         dist.destroy_process_group()
 
