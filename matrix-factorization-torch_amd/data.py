@@ -9,9 +9,13 @@ prepare.py:85) and ``neg_item.idx[B]`` uniform negatives (:344-354).  The towers
 are embedding tables, so ``user`` carries ``idx`` (``user_rn``) where the reference
 carries ``text``.
 
-The reference's ETL (polars / parquet / LanceDB, prepare.py, load.py:78-141) is out of
-scope; :class:`SyntheticInteractions` produces MovieLens-*shaped*
-batches (no MovieLens files are available offline) for tests and benchmarks.
+The reference's text ETL (polars / parquet / LanceDB, prepare.py, load.py:78-141) is out of
+scope; its ids-only core is here: :func:`split_ratings` (the per-user temporal
+80/20 split and the val / test user split, prepare.py:160-194), :class:`InteractionTable` (train
+pairs, per-user train positives, the 4-week rolling history of every rating, prepare.py:229-243, and
+the evaluation sets of ``process_users``, :272-310) and :class:`DeviceInteractionSampler` (the batch
+producer on the GPU).  :class:`SyntheticInteractions` produces MovieLens-*shaped* batches (no MovieLens
+files are available offline) for tests and benchmarks.
 """
 from __future__ import annotations
 
@@ -108,30 +112,187 @@ class SyntheticInteractions:
             yield self.batch()
 
 
+FOUR_WEEKS = 4 * 7 * 24 * 3600       # polars "4w", in the seconds of a MovieLens timestamp
+
+
+def _segment_layout(keys_sorted: torch.Tensor):
+    """(segment id of every position, first position of every segment, length of every segment) of a sorted key vector."""
+    n = keys_sorted.numel()
+    new = torch.ones(n, dtype=torch.bool, device=keys_sorted.device)
+    new[1:] = keys_sorted[1:] != keys_sorted[:-1]
+    seg = torch.cumsum(new.to(torch.int64), 0) - 1
+    start = torch.nonzero(new).flatten()
+    length = torch.diff(torch.cat([start, torch.tensor([n], device=start.device)]))
+    return seg, start, length
+
+
+def _rank_min(values_sorted: torch.Tensor, group_start_of_pos: torch.Tensor) -> torch.Tensor:
+    """polars ``rank("min")`` (1-based; ties share the lowest rank) of values that are sorted inside their groups:
+    position of the first element of the tie run, relative to its group's first position."""
+    n = values_sorted.numel()
+    pos = torch.arange(n, device=values_sorted.device)
+    run_new = torch.ones(n, dtype=torch.bool, device=values_sorted.device)
+    run_new[1:] = (values_sorted[1:] != values_sorted[:-1]) | (group_start_of_pos[1:] != group_start_of_pos[:-1])
+    run_start = torch.cummax(torch.where(run_new, pos, torch.zeros_like(pos)), 0).values
+    return run_start - group_start_of_pos + 1
+
+
+def split_ratings(user: torch.Tensor, timestamp: torch.Tensor, *, train_prop: float = 0.8, val_prop: float = 0.2):
+    """``train_test_split`` of the reference (xfmr_rec/data/prepare.py:160-194) on id / time vectors: per user the first
+    ``train_prop`` of its ratings IN TIME are train (``p = (rank_min(datetime) - 1) / count < train_prop``); of the users
+    that own non-train ratings, those with the largest ``val_prop`` share of such ratings (``(rank_min(len) - 1) /
+    n_users >= 1 - val_prop``) are validation users, the others test users.  Returns bool vectors
+    ``is_train, is_val, is_test`` aligned with the input."""
+    n = user.numel()
+    o1 = torch.argsort(timestamp, stable=True)
+    order = o1[torch.argsort(user[o1], stable=True)]                 # by (user, time), ties in input order
+    su, st = user[order], timestamp[order]
+    seg, start, length = _segment_layout(su)
+    rank = _rank_min(st, start[seg])
+    p = (rank - 1).to(torch.float64) / length[seg].to(torch.float64)
+    train_sorted = p < train_prop
+    is_train = torch.empty(n, dtype=torch.bool, device=user.device)
+    is_train[order] = train_sorted
+    # users_split: over the users with at least one non-train rating
+    nontrain = torch.zeros(start.numel(), dtype=torch.int64, device=user.device)
+    nontrain.index_add_(0, seg, (~train_sorted).to(torch.int64))
+    has = nontrain > 0
+    lens = nontrain[has]
+    lo = torch.argsort(lens, stable=True)
+    r = _rank_min(lens[lo], torch.zeros_like(lens))
+    pv = torch.empty(lens.numel(), dtype=torch.float64, device=user.device)
+    pv[lo] = (r - 1).to(torch.float64) / max(lens.numel(), 1)
+    val_user = torch.zeros(start.numel(), dtype=torch.bool, device=user.device)
+    val_user[has] = pv >= 1.0 - val_prop
+    val_sorted = (~train_sorted) & val_user[seg]
+    is_val = torch.empty_like(is_train)
+    is_val[order] = val_sorted
+    return is_train, is_val, (~is_train) & (~is_val)
+
+
+class InteractionTable:
+    """The ids-only interaction tables a training / evaluation run needs, built once from the ratings
+    (``user``, ``item`` -- the 1-based ``movie_rn`` -- , ``rating``, ``timestamp`` in seconds), all torch ops (the tensors
+    may live on the GPU).  Follows ``prepare_movielens`` (prepare.py:313-325) for everything that is not text:
+
+    * ``is_train / is_val / is_test`` -- :func:`split_ratings`;
+    * ``pair_user / pair_item / pair_target`` -- the train ratings (``ratings.parquet`` filtered by ``is_train``,
+      data/lightning.py:344-354), sorted by (user, time);
+    * ``pos_off / pos_items`` -- every user's train items in time order: the ``target`` of a train row
+      (``gather_history``, prepare.py:236-241) whose item rows become ``pos_idx`` (``UserProcessor.process``,
+      data/lightning.py:274-280);
+    * ``history_lo / history_hi`` -- per rating (in (user, time) order, ``order`` maps back to the input): its rolling
+      4-week history is ``sorted_item[history_lo : history_hi]`` -- the user's ratings with ``t - 4w < t' < t``
+      (``rolling("datetime", period="4w", closed="none")``, prepare.py:230-234);
+    * ``eval_sets(split)`` -- per user of the split (``process_users``, :272-310): ``history`` = its train items
+      (excluded from retrieval), ``target`` = its non-train items with their ratings."""
+
+    def __init__(self, user, item, rating, timestamp, *, train_prop: float = 0.8, val_prop: float = 0.2) -> None:
+        user, item = torch.as_tensor(user, dtype=torch.int64), torch.as_tensor(item, dtype=torch.int64)
+        timestamp = torch.as_tensor(timestamp, dtype=torch.int64).to(user.device)
+        rating = torch.as_tensor(rating).to(user.device)
+        self.is_train, self.is_val, self.is_test = split_ratings(user, timestamp, train_prop=train_prop, val_prop=val_prop)
+        o1 = torch.argsort(timestamp, stable=True)
+        self.order = o1[torch.argsort(user[o1], stable=True)]
+        su, st = user[self.order], timestamp[self.order]
+        self.sorted_user, self.sorted_item, self.sorted_time = su, item[self.order], st
+        self.sorted_rating = rating[self.order]
+        self.sorted_train = self.is_train[self.order]
+        self.sorted_val, self.sorted_test = self.is_val[self.order], self.is_test[self.order]
+        self.num_user_rows = int(user.max()) + 1
+        # rolling 4-week window of every rating: a slice of the (user, time)-sorted rows.  One composite key orders
+        # (user, time) pairs; its offset form turns "t - 4w < t' < t inside the same user" into two searchsorted calls.
+        span = int(st.max() - st.min()) + FOUR_WEEKS + 2
+        key = su * span + (st - st.min())
+        self.history_lo = torch.searchsorted(key, key - FOUR_WEEKS, right=True)        # first t' > t - 4w ...
+        seg, start, _ = _segment_layout(su)
+        self.history_lo = torch.maximum(self.history_lo, start[seg])                   # ... of the same user
+        self.history_hi = torch.searchsorted(key, key, right=False)                    # first t' >= t
+        # train pairs and per-user positives
+        tr = self.sorted_train
+        self.pair_user, self.pair_item = su[tr], self.sorted_item[tr]
+        self.pair_target = self.sorted_rating[tr].to(torch.float32)
+        counts = torch.bincount(self.pair_user, minlength=self.num_user_rows)
+        self.pos_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=user.device), torch.cumsum(counts, 0)])
+        self.pos_items = self.pair_item
+
+    def eval_sets(self, split: str):
+        """``(users, history_csr, target_csr)`` of ``split`` in {"val", "test"}: ``users`` ascending; ``history_csr`` =
+        (offsets, train item rows) to exclude; ``target_csr`` = (offsets, item rows, ratings) to retrieve -- the shapes
+        ``MatrixFactorizationLitModule.update_metrics`` consumes."""
+        flag = {"val": self.sorted_val, "test": self.sorted_test}[split]
+        users = torch.unique(self.sorted_user[flag])
+        dev = users.device
+        is_eval_user = torch.zeros(self.num_user_rows, dtype=torch.bool, device=dev)
+        is_eval_user[users] = True
+        slot = torch.full((self.num_user_rows,), -1, dtype=torch.int64, device=dev)
+        slot[users] = torch.arange(users.numel(), device=dev)
+
+        def csr(mask):
+            rows = slot[self.sorted_user[mask]]                       # already grouped by user, ascending
+            off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(torch.bincount(rows, minlength=users.numel()), 0)])
+            return off, mask
+
+        h_off, h_mask = csr(self.sorted_train & is_eval_user[self.sorted_user])
+        t_off, t_mask = csr((~self.sorted_train) & is_eval_user[self.sorted_user])
+        return (users, (h_off, self.sorted_item[h_mask]),
+                (t_off, self.sorted_item[t_mask], self.sorted_rating[t_mask].to(torch.float32)))
+
+    def sampler(self, *, num_items: int, batch_size: int = BATCH_SIZE, seed: int = 0, device="cuda", pos_pad: int | None = None,
+                user_range: tuple[int, int] | None = None) -> "DeviceInteractionSampler":
+        return DeviceInteractionSampler(self.pair_user, self.pair_item, self.pair_target, self.pos_off, self.pos_items,
+                                        num_items=num_items, batch_size=batch_size, pos_pad=pos_pad, seed=seed, device=device,
+                                        user_range=user_range)
+
+
 class DeviceInteractionSampler:
     """The training batches, produced on the GPU from HBM-resident interactions (``mf_sample_batch``):
     the counterpart of ``InteractionProcessor.get_batch_data`` (xfmr_rec/data/lightning.py:311-363) for
     id-only towers.  ``pair_user / pair_item / pair_target``: one entry per rating; the positive list
     of user u is ``pos_items[pos_off[u] : pos_off[u + 1]]`` (``UserProcessor.process``, :274-280).
     ``batch(step)`` is example positions ``step * batch_size ...`` of a stream that is reshuffled
-    every epoch; the same (seed, step) always gives the same batch."""
+    every epoch; the same (seed, step) always gives the same batch.
+
+    ``pos_pad`` = width of ``pos_idx``.  The reference passes ALL of a user's targets and pads to the longest list of
+    the batch (data/lightning.py:275-279, load.py:38-55): ``None`` (default) sizes it to the longest list of the data,
+    so no positive is ever dropped; a smaller explicit value would silently turn positives into negatives and is
+    refused unless ``truncate_positives=True`` says that this is wanted.  ``user_range=(lo, hi)`` keeps only the pairs
+    of users ``lo <= u < hi``: the per-rank stream of a user-sharded job (``distributed.ShardedTrainer`` partitions
+    the training pairs by user shard)."""
 
     def __init__(self, pair_user, pair_item, pair_target, pos_off, pos_items, *, num_items: int,
-                 batch_size: int = BATCH_SIZE, pos_pad: int = 64, seed: int = 0, device="cuda") -> None:
+                 batch_size: int = BATCH_SIZE, pos_pad: int | None = None, seed: int = 0, device="cuda",
+                 user_range: tuple[int, int] | None = None, truncate_positives: bool = False) -> None:
         from . import _lib
 
         self._lib = _lib
         i64 = lambda t: torch.as_tensor(t, dtype=torch.int64).to(device).contiguous()  # noqa: E731
         self.pair_user, self.pair_item = i64(pair_user), i64(pair_item)
         self.pair_target = torch.as_tensor(pair_target, dtype=torch.float32).to(device).contiguous()
+        if user_range is not None:
+            keep = (self.pair_user >= user_range[0]) & (self.pair_user < user_range[1])
+            self.pair_user, self.pair_item, self.pair_target = (self.pair_user[keep].contiguous(), self.pair_item[keep].contiguous(),
+                                                                self.pair_target[keep].contiguous())
         self.pos_off, self.pos_items = i64(pos_off), i64(pos_items)
         if self.pos_items.numel() == 0:
             self.pos_items = torch.zeros(1, dtype=torch.int64, device=device)
-        self.num_items, self.batch_size, self.pos_pad, self.seed = int(num_items), int(batch_size), int(pos_pad), int(seed)
         n = self.pair_user.numel()
         if not (self.pair_item.numel() == n == self.pair_target.numel()) or n == 0:
             msg = "pair_user, pair_item and pair_target must have the same, non-zero length"
             raise ValueError(msg)
+        # one-time checks on the data (host syncs at construction, none per batch)
+        if int(self.pair_user.min()) < 0 or int(self.pair_user.max()) + 1 >= self.pos_off.numel():
+            msg = f"every user id needs a row in pos_off: {int(self.pair_user.max()) = }, {self.pos_off.numel() = }"
+            raise ValueError(msg)
+        longest = int((self.pos_off[1:] - self.pos_off[:-1]).max()) if self.pos_off.numel() > 1 else 0
+        if pos_pad is None:
+            pos_pad = max(longest, 1)
+        elif longest > pos_pad and not truncate_positives:
+            msg = (f"pos_pad = {pos_pad} would drop positives (longest list: {longest}); the dropped items would enter the "
+                   "losses as negatives.  Pass pos_pad=None (sized from the data) or truncate_positives=True")
+            raise ValueError(msg)
+        self.longest_positive_list = longest
+        self.num_items, self.batch_size, self.pos_pad, self.seed = int(num_items), int(batch_size), int(pos_pad), int(seed)
 
     @property
     def steps_per_epoch(self) -> int:

@@ -52,3 +52,41 @@ def sample_batch(pair_user, pair_item, pair_target, pos_off, pos_items, num_item
         own = pos_items[int(pos_off[u]): int(pos_off[u + 1])][:pad]
         pos[r, : len(own)] = torch.as_tensor(own, dtype=torch.int64)
     return (torch.tensor(user), torch.tensor(item + neg), torch.tensor(target, dtype=torch.float32), pos)
+
+
+# ---- ids-only ETL (spec of data.split_ratings / data.InteractionTable): plain Python following the polars expressions of
+# ---- xfmr_rec/data/prepare.py:160-194 (train_test_split) and :229-243 (gather_history) line by line
+def _rank_min(values):
+    """polars rank("min"): 1 + number of strictly smaller values."""
+    return [1 + sum(1 for w in values if w < v) for v in values]
+
+
+def split_ratings(user, timestamp, train_prop: float = 0.8, val_prop: float = 0.2):
+    n = len(user)
+    by_user: dict[int, list[int]] = {}
+    for r in range(n):
+        by_user.setdefault(int(user[r]), []).append(r)
+    is_train = [False] * n
+    for rows in by_user.values():
+        ranks = _rank_min([int(timestamp[r]) for r in rows])
+        for r, rk in zip(rows, ranks):
+            is_train[r] = (rk - 1) / len(rows) < train_prop                      # prepare.py:170-176
+    nontrain = {u: sum(1 for r in rows if not is_train[r]) for u, rows in by_user.items()}
+    nontrain = {u: c for u, c in nontrain.items() if c > 0}                      # filter(~is_train).group_by(user).len()
+    us = list(nontrain)
+    ranks = _rank_min([nontrain[u] for u in us])
+    val_user = {u: (rk - 1) / len(us) >= 1 - val_prop for u, rk in zip(us, ranks)}   # :181-184
+    is_val = [(not is_train[r]) and val_user.get(int(user[r]), False) for r in range(n)]
+    is_test = [(not is_train[r]) and not is_val[r] for r in range(n)]
+    return is_train, is_val, is_test
+
+
+def rolling_history(user, item, timestamp, period: int):
+    """history of rating r: items of the same user with t - period < t' < t (closed="none"), in time order."""
+    n = len(user)
+    out = []
+    for r in range(n):
+        rows = [q for q in range(n) if int(user[q]) == int(user[r]) and int(timestamp[r]) - period < int(timestamp[q]) < int(timestamp[r])]
+        rows.sort(key=lambda q: (int(timestamp[q]), q))
+        out.append([int(item[q]) for q in rows])
+    return out

@@ -628,8 +628,26 @@ def test_device_batch_producer_matches_oracle_and_feeds_the_module(mf):
     lists = [sorted(set(pi[pu == u].tolist())) for u in range(n_users)]       # a user's positives = its rated items
     off = torch.tensor([0] + list(np.cumsum([len(x) for x in lists])))
     items = torch.tensor([i for x in lists for i in x], dtype=torch.int64)
+    longest = max(len(x) for x in lists)
+    assert longest > 10
+    with pytest.raises(ValueError, match="would drop positives"):        # the reference passes ALL targets (data/lightning.py:275-279)
+        mf.data.DeviceInteractionSampler(pu, pi, pt, off, items, num_items=n_items, batch_size=64, pos_pad=10, device=DEV)
+    with pytest.raises(ValueError, match="needs a row in pos_off"):
+        mf.data.DeviceInteractionSampler(pu, pi, pt, off[:50], items, num_items=n_items, batch_size=64, device=DEV)
+    full = mf.data.DeviceInteractionSampler(pu, pi, pt, off, items, num_items=n_items, batch_size=64, seed=77, device=DEV)
+    assert full.pos_pad == longest                                          # sized from the data: nothing is dropped
+    fb = full.batch(3)
+    for r, u in enumerate(fb["user"]["idx"].cpu().tolist()):
+        assert [x for x in fb["user"]["pos_idx"][r].cpu().tolist() if x] == lists[u]
+    # the per-rank stream of a user-sharded job: only pairs of users lo <= u < hi, each exactly once per epoch
+    mine = mf.data.DeviceInteractionSampler(pu, pi, pt, off, items, num_items=n_items, batch_size=32, seed=5, device=DEV,
+                                            user_range=(50, 120))
+    n_mine = int(((pu >= 50) & (pu < 120)).sum())
+    got_u = torch.cat([mine.batch(s_)["user"]["idx"] for s_ in range(mine.steps_per_epoch)])[:n_mine].cpu()
+    assert int(got_u.min()) >= 50 and int(got_u.max()) < 120
+    assert torch.equal(torch.sort(got_u).values, torch.sort(pu[(pu >= 50) & (pu < 120)]).values)
     sampler = mf.data.DeviceInteractionSampler(pu, pi, pt, off, items, num_items=n_items, batch_size=64, pos_pad=10, seed=77,
-                                               device=DEV)
+                                               device=DEV, truncate_positives=True)
     seen = []
     for step in (0, 5, 23, 24):                              # 23 -> 24 crosses the epoch boundary (1500 / 64 = 23.4)
         b = sampler.batch(step)

@@ -131,3 +131,47 @@ def test_oracle_epoch_permutation_is_a_bijection():
         for epoch in (0, 1):
             assert sorted(odata.feistel_perm(x, n, epoch, 9) for x in range(n)) == list(range(n))
     assert [odata.feistel_perm(x, 100, 0, 9) for x in range(100)] != [odata.feistel_perm(x, 100, 1, 9) for x in range(100)]
+
+
+def test_interaction_table_split_and_histories_match_the_reference_semantics():
+    """data.split_ratings / InteractionTable against a plain-Python restatement of the reference's polars expressions
+    (train_test_split, prepare.py:160-194; gather_history's rolling 4-week window, :229-243; process_users' per-user
+    history / target, :272-310) on ratings with timestamp ties, single-rating users and bursts inside one window."""
+    import importlib
+
+    from oracle import data as odata
+
+    mf_data = importlib.import_module("matrix-factorization-torch_amd.data")
+    g = torch.Generator().manual_seed(0)
+    n_users, n_items, n = 23, 40, 400
+    user = torch.randint(1, n_users, (n,), generator=g)
+    user[:3] = torch.tensor([20, 21, 22])                           # three users with a single rating
+    user[user >= 20] = torch.where(torch.arange(n)[user >= 20] < 3, user[user >= 20], torch.tensor(1))
+    item = torch.randint(1, n_items, (n,), generator=g)
+    rating = torch.randint(1, 6, (n,), generator=g)
+    ts = 978_300_000 + torch.randint(0, 20 * 7 * 24 * 3600, (n,), generator=g)
+    ts[50:60] = ts[50]                                              # ties in time (also across users)
+    ts[100:140] = ts[100] + torch.arange(40) * 3600                 # a burst inside one 4-week window
+    tab = mf_data.InteractionTable(user, item, rating, ts)
+    want_train, want_val, want_test = odata.split_ratings(user.tolist(), ts.tolist())
+    assert tab.is_train.tolist() == want_train and tab.is_val.tolist() == want_val and tab.is_test.tolist() == want_test
+    assert 0.7 < sum(want_train) / n < 0.9 and any(want_val) and any(want_test)
+    # rolling history of every rating (as sets: the reference's window has no order among equal timestamps)
+    hist = odata.rolling_history(user.tolist(), item.tolist(), ts.tolist(), mf_data.FOUR_WEEKS)
+    order = tab.order.tolist()
+    for pos, r in enumerate(order):
+        got = tab.sorted_item[int(tab.history_lo[pos]): int(tab.history_hi[pos])].tolist()
+        assert sorted(got) == sorted(hist[r]), (pos, r)
+    # train pairs + positives: a user's pos list = its train items
+    for u in range(n_users):
+        mine = sorted(int(item[r]) for r in range(n) if int(user[r]) == u and want_train[r])
+        assert sorted(tab.pos_items[int(tab.pos_off[u]): int(tab.pos_off[u + 1])].tolist()) == mine
+    assert tab.pair_user.numel() == sum(want_train)
+    # evaluation sets (process_users): history = train items, target = non-train items + ratings, per val / test user
+    for split, flags in (("val", want_val), ("test", want_test)):
+        users, (h_off, h_items), (t_off, t_items, t_rating) = tab.eval_sets(split)
+        assert users.tolist() == sorted({int(user[r]) for r in range(n) if flags[r]})
+        for s_, u in enumerate(users.tolist()):
+            assert sorted(h_items[int(h_off[s_]): int(h_off[s_ + 1])].tolist()) == sorted(int(item[r]) for r in range(n) if int(user[r]) == u and want_train[r])
+            tg = sorted((int(item[r]), float(rating[r])) for r in range(n) if int(user[r]) == u and not want_train[r])
+            assert sorted(zip(t_items[int(t_off[s_]): int(t_off[s_ + 1])].tolist(), t_rating[int(t_off[s_]): int(t_off[s_ + 1])].tolist())) == tg
