@@ -15,6 +15,7 @@
 // alignment/contrastive/infonce/mine :164-246, pairwise :324-359, reduction
 // `(loss * target.abs()).sum()`.  Formulas: SURVEY.md Appendix A.
 #include <cfloat>
+#include <type_traits>
 
 #include "mf_common.h"
 #include "mf_select.h"
@@ -375,6 +376,9 @@ struct FwdParams {
     int64_t B, N, Bp;
     int NT, tps, need;
     float sigma, margin;
+    // side inputs of a tile as ONE buffer: byte offsets of maskW / nv / logq from aux_base, and the span covered
+    const char* aux_base;
+    uint32_t aux_mask, aux_nv, aux_lq, aux_bytes;
 };
 
 struct RowStats {
@@ -416,19 +420,29 @@ __device__ __forceinline__ void stats_add(RowStats& s, int need, float L, float 
     }
 }
 
-// Workgroup = 4 waves x 32 users; item tiles arrive through the LDS ring of
-// mf_stream.h together with their mask words, norms and logQ (a separate 4-deep ring
-// of 1 KiB side-input slots).  The loop is software-pipelined inside each wave: the 64
-// MFMAs of tile t+1 are issued in the same basic block as the (branch-free) statistics
-// of tile t, so the matrix pipe and the VALU overlap without relying on a second wave.
+// Workgroup = 4 waves x 32 users; item tiles arrive through a 2-slot LDS ring filled by LDS-DMA, together with
+// their mask words, norms and -logQ (a separate 4-deep ring of side-input slots).  The loop is software-pipelined
+// inside each wave: the 64 MFMAs of tile t+1 are issued in the same basic block as the (branch-free) statistics of
+// tile t, and the DMA pieces of tile t+2 -- into the slot tile t just left -- go out one per MFMA group, so the
+// matrix pipe, the VALU and the memory instructions overlap without relying on a second wave.  The tile loop is
+// unrolled by the two slots: every LDS address is lane base + immediate, and the two accumulator sets swap roles
+// by name (no register copies at the loop edge).
 template <int D>
 struct FwdLds {
     using G = TileGeom<D>;
-    // [0, NW x 128): per-wave mask words; then NW x 128 B staged by the waves: nv (wave 0), logq (wave 1), copies
-    static constexpr int AUX_NV = G::NW * 128, AUX_LQ = AUX_NV + 128, AUXB = 2 * G::NW * 128;
-    static constexpr int AUX0 = 3 * G::TILEB;           // 4 side-input slots after the 3 tile slots
+    // side inputs: one 1-KiB DMA per wave and tile -- lanes 0..7 the wave's 32 mask words, 8..15 the tile's item
+    // norms, 16..23 its -logq (every wave keeps its own copy: no cross-wave dependency), the other lanes zeros
+    static constexpr int AUX_NV = 128, AUX_LQ = 256, AUXW = 1024, AUXB = G::NW * AUXW;
+    static constexpr int AUX0 = 2 * G::TILEB;           // 4 side-input slots after the 2 tile slots
     static constexpr int BYTES = AUX0 + 4 * AUXB;
-    static constexpr int NDMA = G::PPW + 2;             // DMA instructions per wave per stage (+ 4 stash stores per tile)
+    static constexpr int NG = D / 8;                    // MFMA groups per tile
+    static constexpr int LASTG = G::PPW;                // group of a stage's last DMA (tile pieces, then the side inputs)
+    // stash stores of a tile (issued behind logit slices 3, 7, 11, 15 of 32) that are YOUNGER than the stage's last
+    // DMA: `s_waitcnt vmcnt(KEEP)` at the next tile's top then proves every DMA of the stage has landed
+    // (a group issues its DMA before its slices, so a store of group LASTG itself is already younger)
+    static constexpr int store_group(int s) { return s * NG / 32; }
+    static constexpr int KEEP = (store_group(3) >= LASTG) + (store_group(7) >= LASTG) + (store_group(11) >= LASTG) + (store_group(15) >= LASTG);
+    static_assert(LASTG < NG, "a stage's DMAs must fit the tile's MFMA groups");
 };
 
 template <int NEED>
@@ -471,13 +485,37 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void loss_fwd_dense
 
     TileSrc<D> tsrc;
     mf_tile_src_init<D>(tsrc, p.v, p.N, (int64_t)t0 * 32);
-    auto stage = [&](int t) {
-        const int k = t - t0;
-        const int64_t j0 = (int64_t)t * 32;
-        mf_stage_tile<D>(smem + (k % 3) * G::TILEB, t * 32, tsrc);
-        char* aux = smem + L::AUX0 + (k & 3) * L::AUXB;
-        mf_stage_small(aux + wave * 128, p.maskW + (int64_t)t * p.Bp + i0 + wave * 32, 128);
-        mf_stage_small(aux + L::AUX_NV + wave * 128, (wave == 1 ? p.logq : p.nv) + j0, 128);   // 512: nv, 640: logq (zeros if none)
+    // side inputs: per-lane byte offset into the aux buffer, advanced by a per-lane stride from stage to stage
+    // (stages are issued in tile order t0, t0 + 1, ...); lanes 24.. stay out of range and bring zeros
+    mf_rsrc_t arsrc;
+    uint32_t aoff, astep;
+    {
+        const int part = lane >> 3, l8 = lane & 7;
+        aoff = part == 0 ? p.aux_mask + (uint32_t)(((int64_t)t0 * p.Bp + i0 + wave * 32) * 4) + l8 * 16
+             : part == 1 ? p.aux_nv + (uint32_t)t0 * 128u + l8 * 16
+             : part == 2 ? p.aux_lq + (uint32_t)t0 * 128u + l8 * 16 : MF_SRD_DEAD;
+        astep = part == 0 ? (uint32_t)p.Bp * 4u : part <= 2 ? 128u : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.aux_base), 0, (int)p.aux_bytes, 0x00020000);
+#else
+        (void)arsrc; (void)aoff;
+#endif
+    }
+    // one memory instruction of the stage of tile t (into tile slot `slot`): j < PPW a tile piece, j = PPW the side inputs
+    auto stage_piece = [&](int t, int slot, int j, bool live) {
+        if (j < G::PPW) {
+            mf_stage_tile_piece<D>(smem + slot * G::TILEB, t * 32, j, tsrc, live);
+        } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (mf_lds_ptr)(smem + L::AUX0 + ((t - t0) & 3) * L::AUXB + wave * L::AUXW), 16,
+                                                     (int)aoff, live ? 0 : (int)MF_SRD_DEAD, 0, 0);
+#endif
+            aoff += astep;
+        }
+    };
+    auto stage = [&](int t, int slot) {
+#pragma unroll
+        for (int j = 0; j <= L::LASTG; ++j) stage_piece(t, slot, j, true);
     };
     // The statistics of one tile, cut in 32 slices so they can be threaded between the MFMAs of
     // the next tile: slices 0..15 turn score e into logit e (and stash it), slices 16..31 fold
@@ -486,14 +524,12 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void loss_fwd_dense
     float tmax = -FLT_MAX, nmx = -FLT_MAX, nmx2 = 0.f;
     uint32_t mw = 0u;
     f32x4 nv4 = {0.f, 0.f, 0.f, 0.f}, lq4 = {0.f, 0.f, 0.f, 0.f};
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int te = t0;                                 // tile the slices work on
-    auto slice = [&](int sidx) {
-        const char* aux = smem + L::AUX0 + ((te - t0) & 3) * L::AUXB;
+    auto slice = [&](int sidx, int te, const f32x16& acc) {
+        const char* aux = smem + L::AUX0 + ((te - t0) & 3) * L::AUXB + wave * L::AUXW;
         if (sidx < 16) {
             const int e = sidx, q = e >> 2, r = e & 3;
             if (e == 0) {
-                mw = reinterpret_cast<const uint32_t*>(aux)[wave * 32 + c];
+                mw = reinterpret_cast<const uint32_t*>(aux)[c];
                 tmax = -FLT_MAX;
                 // valid negatives among this lane's 16 rows of the tile (rows (e&3) + 8 (e>>2) + 4 h)
                 st.cnt += (float)(16 - __builtin_popcount(mw & (h ? 0xF0F0F0F0u : 0x0F0F0F0Fu)));
@@ -526,28 +562,43 @@ __global__ __launch_bounds__(64 * mf_nw(D), mf_wg_per_cu(D)) void loss_fwd_dense
             if (NEED & NEED_LSE) st.se += __builtin_amdgcn_exp2f(__builtin_fmaf(Lg[e], 1.44269504088896341f, nmx2));
         }
     };
+    // one iteration: wait for tile tj + 1 (slot NS), then its 64 MFMAs into `nxt`, interleaved with the slices of tile
+    // tj on `cur` and -- MODE 1: always, 2: if it exists, 0: never -- the stage of tile tj + 2 into the slot tile tj has left
+    auto iterate = [&](int tj, auto cs_tag, auto mode_tag, const f32x16& cur, f32x16& nxt) {
+        constexpr int CS = decltype(cs_tag)::value, NS = CS ^ 1, MODE = decltype(mode_tag)::value;
+        // every DMA of the stage of tile tj + 1 is older than the KEEP youngest stores
+        if (tj == t0) mf_wait_vmcnt<0>(); else mf_wait_vmcnt<L::KEEP>();
+        mf_block_barrier();
+        const bool live = MODE == 1 || tj + 2 < t1;
+        nxt = mf_tile_scores_interleaved<D, 32, (40 * 32 / D)>(
+            smem + NS * G::TILEB, xf, [&](int sidx) { slice(sidx, tj, cur); },
+            [&](int g) { if (MODE != 0 && g <= L::LASTG) stage_piece(tj + 2, CS, g, live); });
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
 
     if (t0 < t1) {
-        stage(t0);
-        if (t0 + 1 < t1) stage(t0 + 1);
-        if (t0 + 1 < t1) mf_wait_vmcnt<L::NDMA>(); else mf_wait_vmcnt<0>();
+        stage(t0, 0);
+        if (t0 + 1 < t1) stage(t0 + 1, 1);
+        // tile t0: its stage's DMAs are the older ones
+        if (t0 + 1 < t1) mf_wait_vmcnt<L::LASTG + 1>(); else mf_wait_vmcnt<0>();
         mf_block_barrier();
-        if (t0 + 2 < t1) stage(t0 + 2);
-        acc = mf_tile_scores_interleaved<D, 32, (40 * 32 / D)>(smem, xf, [](int) {});
-        for (int tj = t0; tj + 1 < t1; ++tj) {
-            // queue, oldest first: [DMA(tj+1)] [stores(tj-2)] [DMA(tj+2)] [stores(tj-1)]
-            if (tj + 2 >= t1) mf_wait_vmcnt<0>();
-            else if (tj == t0) mf_wait_vmcnt<L::NDMA>();
-            else mf_wait_vmcnt<L::NDMA + 4>();
-            mf_block_barrier();
-            if (tj + 3 < t1) stage(tj + 3);
-            te = tj;
-            const f32x16 acc_n = mf_tile_scores_interleaved<D, 32, (40 * 32 / D)>(smem + ((tj + 1 - t0) % 3) * G::TILEB, xf, slice);
-            acc = acc_n;
+        f32x16 accA = mf_tile_scores_interleaved<D, 32, (40 * 32 / D)>(smem, xf, [](int) {}), accB;
+        int tj = t0;
+        for (; tj + 2 < t1; tj += 2) {      // two tiles per trip: slots and accumulators swap roles by name
+            iterate(tj, I0{}, I1{}, accA, accB);
+            iterate(tj + 1, I1{}, I2{}, accB, accA);
         }
-        te = t1 - 1;
+        if (tj + 1 < t1) {                  // tiles tj (scores in accA) and tj + 1 remain
+            iterate(tj, I0{}, I0{}, accA, accB);
 #pragma unroll
-        for (int sidx = 0; sidx < 32; ++sidx) slice(sidx);
+            for (int sidx = 0; sidx < 32; ++sidx) slice(sidx, tj + 1, accB);
+        } else {                            // tile tj remains
+#pragma unroll
+            for (int sidx = 0; sidx < 32; ++sidx) slice(sidx, tj, accA);
+        }
+        mf_wait_vmcnt<0>();                 // nothing of this workgroup may still be on its way into LDS when it ends
     }
     // the row's other half of the columns lives in lane ^ 32
     {
@@ -1276,6 +1327,16 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     int merge_splits = 0;
     if (scores_needed && !w.mined) {
         FwdParams fp{u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.part, w.stash, B, N, w.Bp, w.NT, w.tps_f, need, sigma, margin};
+        {   // the three side inputs live in the workspace: one descriptor over their span
+            const char *pm = (const char*)w.maskW, *pn = (const char*)w.nv, *pl = (const char*)logq_p;
+            const char* lo = pm < pn ? (pm < pl ? pm : pl) : (pn < pl ? pn : pl);
+            const char *em = pm + (size_t)w.NT * w.Bp * 4, *en = pn + (size_t)w.NT * 128, *el = pl + (size_t)w.NT * 128;
+            const char* hi = em > en ? (em > el ? em : el) : (en > el ? en : el);
+            if ((size_t)(hi - lo) > MF_SRD_MAX_BYTES || (size_t)w.tps_f * 32 * d * 4 > MF_SRD_MAX_BYTES)
+                return mf_set_error(MF_EINVAL, "mf_loss_fwd: batch x catalog too large for one sweep (mask words beyond 4 GiB)");
+            fp.aux_base = lo; fp.aux_mask = (uint32_t)(pm - lo); fp.aux_nv = (uint32_t)(pn - lo); fp.aux_lq = (uint32_t)(pl - lo);
+            fp.aux_bytes = (uint32_t)(hi - lo);
+        }
         MF_DISPATCH_D(d, {
             dim3 grid((unsigned)w.nsplit_f, (unsigned)(w.BT / w.NW));
             MF_TIMED("loss_fwd_dense", s, (launch_fwd<D>(need, grid, fp, s)));

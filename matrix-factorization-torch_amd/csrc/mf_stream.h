@@ -81,6 +81,9 @@ struct TileSrc {
     int wave_pb;        // LDS byte offset of this wave's first piece inside a tile image (wave-uniform)
     int row0;
 };
+// A descriptor never covers more than MF_SRD_MAX_BYTES, so the scalar offset MF_SRD_DEAD (+ any lane offset of
+// a tile image) is out of range without wrapping 32 bits: a load issued with it fetches nothing and writes zeros.
+constexpr unsigned MF_SRD_MAX_BYTES = 0xFFF00000u, MF_SRD_DEAD = 0xFFF00000u;
 template <int D>
 __device__ __forceinline__ void mf_tile_src_init(TileSrc<D>& ts, const float* __restrict__ Y, int64_t nY, int64_t row0) {
     using G = TileGeom<D>;
@@ -88,7 +91,7 @@ __device__ __forceinline__ void mf_tile_src_init(TileSrc<D>& ts, const float* __
     const int wave = mf_wave_id();
     // row0 / nY derive from kernel arguments and blockIdx only: the descriptor is provably wave-uniform (no waterfall loop)
     int64_t bytes = (nY - row0) * (int64_t)G::ROWB;
-    bytes = bytes < 0 ? 0 : (bytes > 0xFFFFF000ll ? 0xFFFFF000ll : bytes);
+    bytes = bytes < 0 ? 0 : (bytes > (int64_t)MF_SRD_MAX_BYTES ? (int64_t)MF_SRD_MAX_BYTES : bytes);
 #if defined(__HIP_DEVICE_COMPILE__)
     ts.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Y + row0 * D), 0, (int)(unsigned)bytes, 0x00020000);
 #endif
@@ -106,13 +109,13 @@ __device__ __forceinline__ void mf_tile_src_init(TileSrc<D>& ts, const float* __
 
 // DMA piece q (0 .. PPW-1) of this wave's share of the tile of rows y0 .. y0+31 into `lds_tile`
 template <int D>
-__device__ __forceinline__ void mf_stage_tile_piece(char* lds_tile, int y0, int q, const TileSrc<D>& ts) {
+__device__ __forceinline__ void mf_stage_tile_piece(char* lds_tile, int y0, int q, const TileSrc<D>& ts, bool live = true) {
     using G = TileGeom<D>;
     const bool active = mf_lane() * 16 < G::PIECEB;                            // (fewer than 64 lanes per piece only for short tiles)
 #ifdef MF_ABL_SAMETILE      // A/B knob: always stage the first tile (cache-resident) -- wrong results, measures the memory side
     y0 = ts.row0;
 #endif
-    const int soff = (y0 - ts.row0) * G::ROWB;
+    const int soff = live ? (y0 - ts.row0) * G::ROWB : (int)MF_SRD_DEAD;      // (a scalar select: no branch)
 #if defined(__HIP_DEVICE_COMPILE__)
     if (active)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ts.rsrc, (mf_lds_ptr)(lds_tile + ts.wave_pb + q * G::PIECEB), 16, (int)ts.off[q], soff, 0, 0);
@@ -193,8 +196,8 @@ __device__ __forceinline__ void mf_lds_frag(RowFrag<D>& f, const char* lds_tile)
 // sit between the MFMAs in program order.  `slice(s)`, s = 0 .. NSLICE-1, is that work, cut in
 // NSLICE pieces; VPM = VALU/SALU instructions to place behind each MFMA.  sched_barrier /
 // sched_group_barrier pin the interleave (hipcc otherwise clusters the MFMAs).
-template <int D, int NSLICE, int VPM, class Slice>
-__device__ __forceinline__ f32x16 mf_tile_scores_interleaved(const char* lds_tile, const RowFrag<D>& x, Slice&& slice) {
+template <int D, int NSLICE, int VPM, class Slice, class Hook>
+__device__ __forceinline__ f32x16 mf_tile_scores_interleaved(const char* lds_tile, const RowFrag<D>& x, Slice&& slice, Hook&& hook) {
     using G = TileGeom<D>;
     constexpr int NG = D / 8;
     static_assert(NSLICE % NG == 0 || NG % NSLICE == 0, "slices and MFMA groups must nest");
@@ -213,6 +216,7 @@ __device__ __forceinline__ f32x16 mf_tile_scores_interleaved(const char* lds_til
         const f32x4 a = a_next;
         a_next = a_next2;
         if (g + 2 < NG) a_next2 = *reinterpret_cast<const f32x4*>(rowp + (((2 * (g + 2) + h) ^ sw) << 4));
+        hook(g);                  // (memory instructions of the software pipeline: one per MFMA group)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], x.v[g][t], acc, 0, 0, 0);
         const int s_end = (g + 1) * NSLICE / NG;
@@ -230,6 +234,10 @@ __device__ __forceinline__ f32x16 mf_tile_scores_interleaved(const char* lds_til
     }
     (void)s_done;
     return acc;
+}
+template <int D, int NSLICE, int VPM, class Slice>
+__device__ __forceinline__ f32x16 mf_tile_scores_interleaved(const char* lds_tile, const RowFrag<D>& x, Slice&& slice) {
+    return mf_tile_scores_interleaved<D, NSLICE, VPM>(lds_tile, x, slice, [](int) {});
 }
 
 // Transposed operand of the backward: lane c gets the D/32 consecutive floats
