@@ -290,6 +290,62 @@ def test_sparse_update_matches_oracle(mf, d, normalize, opt):
         torch.testing.assert_close(tower.weight.detach().cpu(), ref, rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("case", ["zipf", "one_row_overflows_its_bucket", "legacy_packed", "legacy_generic", "tiny"])
+def test_sparse_update_paths(mf, case):
+    """The one-launch update (batch-sized id lists: one workgroup per id bucket, LDS sort), its global-memory
+    fallback for a bucket that does not fit LDS, and the multi-launch path of longer lists, all against the
+    oracle's coalesced row-Adam; out-of-range ids are skipped and no other row is written."""
+    lib = mf._lib.lib()
+    g = torch.Generator().manual_seed(11)
+    d = 64
+    if case == "zipf":
+        rows, n = 60_000, 16384
+        w = 1.0 / torch.arange(1, rows + 1, dtype=torch.float64)
+        idx = torch.multinomial(w, n, replacement=True, generator=g)
+    elif case == "one_row_overflows_its_bucket":
+        rows, n = 60_000, 16384
+        idx = torch.randint(0, rows, (n,), generator=g)
+        idx[torch.randperm(n, generator=g)[:9000]] = 4242          # > 8192 keys in one bucket
+    elif case == "legacy_packed":
+        rows, n = 1000, 70_000
+        idx = torch.randint(0, rows, (n,), generator=g)
+    elif case == "legacy_generic":
+        rows, n = 5_000_000, 70_000
+        idx = torch.randint(0, rows, (n,), generator=g)
+        idx[100:180] = idx[7]
+    else:
+        rows, n = 50, 3
+        idx = torch.tensor([7, 7, 9])
+    if n > 3:
+        idx[1], idx[2] = -1, rows + 9                     # out of range: ignored
+    grad = torch.randn(n, d, generator=g)
+    valid = (idx >= 0) & (idx < rows)
+    touched = torch.unique(idx[valid])
+    init = torch.randn(touched.numel(), d, generator=g)
+    table = torch.zeros(rows, d, device=DEV)
+    table[touched.to(DEV)] = init.to(DEV)
+    em, ev = torch.zeros_like(table), torch.zeros_like(table)
+    ws = mf._lib.workspace(lib.mf_update_ws_bytes(n, d), DEV)
+    gi, gg = idx.to(DEV), grad.to(DEV)
+    small, sm, sv = init.clone(), torch.zeros_like(init), torch.zeros_like(init)
+    remap = torch.searchsorted(touched, idx[valid])
+    for step in (1, 2):
+        mf._lib.check(lib.mf_update_adam(table.data_ptr(), em.data_ptr(), ev.data_ptr(), rows, d, gi.data_ptr(), n, gg.data_ptr(), 0,
+                                         step, None, 0.05, 0.9, 0.999, 1e-8, 0.01, ws.data_ptr(), ws.numel(), None))
+        oembed.adam_update(small, sm, sv, remap, grad[valid], step=step, lr=0.05, weight_decay=0.01)
+        # sums of thousands of gradient rows: the order of the additions differs from the oracle's index_add
+        torch.testing.assert_close(table[touched.to(DEV)].cpu(), small, rtol=2e-4, atol=2e-5)
+    assert int(torch.count_nonzero(table.abs().sum(dim=1))) == touched.numel()   # nothing else was written
+    # the same call on the same inputs is bit-reproducible
+    t2 = torch.zeros(rows, d, device=DEV)
+    t2[touched.to(DEV)] = init.to(DEV)
+    m2, v2 = torch.zeros_like(t2), torch.zeros_like(t2)
+    for step in (1, 2):
+        mf._lib.check(lib.mf_update_adam(t2.data_ptr(), m2.data_ptr(), v2.data_ptr(), rows, d, gi.data_ptr(), n, gg.data_ptr(), 0,
+                                         step, None, 0.05, 0.9, 0.999, 1e-8, 0.01, ws.data_ptr(), ws.numel(), None))
+    assert torch.equal(t2, table)
+
+
 # --------------------------------------------------------------------- retrieval ---
 @pytest.mark.parametrize("cfg", [(50, 5000, 64, 20), (1, 3883, 64, 20), (33, 1000, 128, 5), (7, 300, 32, 64), (40, 2500, 256, 32),
                                  (150, 20000, 128, 64), (300, 9000, 256, 40), (1030, 4100, 32, 1)],
@@ -494,8 +550,8 @@ def test_public_mask_and_mining_helpers_match_reference(mf, path):
 
 
 def test_sparse_update_generic_sort_path_and_out_of_range_ids(mf):
-    """A table too tall for the packed (id, position) sort word takes the 64-bit rank sort; ids outside
-    the table are skipped (never written), the rest matches the oracle's coalesced update."""
+    """Ids outside the table are skipped (never written), the rest matches the oracle's coalesced update (a table
+    too tall for a 32-bit id; the multi-launch sorts are covered by test_sparse_update_paths)."""
     lib = mf._lib.lib()
     rows, d, n = 5_000_000, 32, 700                      # (rows + 1) << 10 > 2^32
     g = torch.Generator().manual_seed(5)
