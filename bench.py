@@ -146,7 +146,9 @@ class Trainer:
 
     def step(self, b) -> torch.Tensor:
         # the hit masks depend on the ids only and can be built on a side stream while the towers gather; measured
-        # equal (1.1718 vs 1.1732 ms / step: the cross-stream join costs what the overlap saves), so off by default
+        # equal (1.1718 vs 1.1732 ms / step: the cross-stream join costs what the overlap saves), so off by default.
+        # (Building the NEXT batch's masks at the start of a step -- a whole step of slack -- also measured equal,
+        # 1.0085 vs 1.0088 ms: kernels of a second stream do not slip in beside the sweeps, they queue.)
         masks = (self.loss_fn.prepare_masks(b["item"], b["pos"], batch_size=b["user"].numel(), embedding_dim=self.dim)
                  if os.environ.get("MF_BENCH_PREPARE", "0") == "1" else None)
         u = self.towers["user"](b["user"])

@@ -116,7 +116,8 @@ int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64_t* sorted_
  *   correction L_ij -= logq_j: one value per column, logq[N], when logq_rows = 0, else a
  *   table of logq_rows values looked up by the batch ids, logq_j = logq[item_idx[j]],
  *   ids outside the table counting as 0 -- which needs item_idx != NULL).
- * flags: MF_LOSS_TARGET_I64 (target is int64), MF_LOSS_ROWC (kind_mask has ONE bit set and that
+ * flags: MF_LOSS_TARGET_I64 (target is int64), MF_LOSS_MASKS_READY (mf_loss_masks already ran on this workspace for
+ *   these ids: same as item_idx = NULL, but the ids stay available to a logQ table lookup), MF_LOSS_ROWC (kind_mask has ONE bit set and that
  *   loss will be differentiated: the forward's tail also prepares the backward's per-row
  *   coefficients, and mf_loss_bwd is then called with MF_LOSS_ROWC too and skips that launch).
  * kind_mask selects which losses to evaluate in the one pass (bit k = kind k);
@@ -135,7 +136,7 @@ int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64_t* sorted_
 size_t mf_loss_ws_bytes(int64_t B, int64_t N, int d, int P, int num_negatives);
 int mf_loss_masks(int64_t B, int64_t N, int d, int P, int num_negatives, const int64_t* item_idx,
                   const int64_t* pos_idx, void* ws, size_t ws_bytes, mf_stream_t stream);
-enum { MF_LOSS_TARGET_I64 = 1, MF_LOSS_ROWC = 2 };
+enum { MF_LOSS_TARGET_I64 = 1, MF_LOSS_ROWC = 2, MF_LOSS_MASKS_READY = 4 };
 int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
                 int kind_mask, const float* u, const float* v, const void* target,
                 const int64_t* item_idx, const int64_t* pos_idx, const float* logq, int64_t logq_rows,

@@ -64,7 +64,7 @@ SIGNATURES = {
     "mf_topk_small": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp]),
 }
 
-LOSS_TARGET_I64, LOSS_ROWC = 1, 2     # flags of mf_loss_fwd / mf_loss_bwd (include/mf_hip.h)
+LOSS_TARGET_I64, LOSS_ROWC, LOSS_MASKS_READY = 1, 2, 4     # flags of mf_loss_fwd / mf_loss_bwd (include/mf_hip.h)
 
 _lib: ctypes.CDLL | None = None
 

@@ -1292,7 +1292,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
                            mf_stream_t stream) {
     int rc = check_loss_args("mf_loss_fwd", B, N, d, P, num_negatives, u, v, target, ws, ws_bytes);
     if (rc) return rc;
-    const bool masks_ready = item_idx == nullptr;       // mf_loss_masks ran on this workspace
+    const bool masks_ready = item_idx == nullptr || (flags & MF_LOSS_MASKS_READY);       // mf_loss_masks ran on this workspace
     if (!out_losses || (!masks_ready && P > 0 && !pos_idx) || !(kind_mask & 0x7F))
         return mf_set_error(MF_EINVAL, "mf_loss_fwd: bad argument");
     if (logq && logq_rows > 0 && !item_idx) return mf_set_error(MF_EINVAL, "mf_loss_fwd: a logQ table needs item_idx");

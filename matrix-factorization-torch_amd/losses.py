@@ -121,15 +121,13 @@ class _LossFunction(torch.autograd.Function):
                 msg = "prepared masks belong to another batch / shape"
                 raise ValueError(msg)
             torch.cuda.current_stream().wait_event(prepared.event)
-            lease, ii_arg = prepared.lease, None     # item_idx = NULL: "the masks are in ws"
-            if lq_rows:                              # (the in-kernel table lookup needs the ids)
-                lq, lq_rows = lq[ii], 0
+            lease, ii_arg, ready = prepared.lease, ii, _lib.LOSS_MASKS_READY    # "the masks are in ws"
         else:
-            lease, ii_arg = _lib.LeasedWorkspace(lib.mf_loss_ws_bytes(b, n, dp, p, num_negatives), u.device), ii
+            lease, ii_arg, ready = _lib.LeasedWorkspace(lib.mf_loss_ws_bytes(b, n, dp, p, num_negatives), u.device), ii, 0
         ws = lease.tensor
         ctx.lease = lease                            # back to the pool when autograd drops this node
         out = torch.empty(len(KINDS), dtype=torch.float32, device=u.device)      # mf_loss_fwd writes all 7 entries
-        flags = (_lib.LOSS_TARGET_I64 if t.dtype == torch.int64 else 0) | (_lib.LOSS_ROWC if bwd_kind is not None else 0)
+        flags = (_lib.LOSS_TARGET_I64 if t.dtype == torch.int64 else 0) | (_lib.LOSS_ROWC if bwd_kind is not None else 0) | ready
         _lib.check(lib.mf_loss_fwd(b, n, dp, p, num_negatives, sigma, margin, kind_mask, _lib.ptr(u), _lib.ptr(v),
                                    _lib.ptr(t), _lib.ptr(ii_arg), _lib.ptr(pi), _lib.ptr(lq), lq_rows, flags, _lib.ptr(ws),
                                    ws.numel(), _lib.ptr(out), None, _lib.stream_ptr()))
