@@ -54,7 +54,7 @@ struct LossWs {
     int32_t *colslot, *gfirst, *colfirst;
     uint32_t* ubits;
     uint32_t* maskW;
-    float *part, *stats, *rowloss, *rowc, *dpart, *rpart, *stash, *gstash, *blockpart;
+    float *part, *stats, *rowloss, *rowc, *dpart, *rpart, *dpart_v, *rpart_v, *stash, *gstash, *blockpart;
     unsigned* ticket;
     unsigned long long *cand, *priv, *seeds;
     int32_t *cand_cnt, *sel, *sel_cnt;
@@ -113,7 +113,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.stats = a.take<float>((size_t)NSTAT * w.Bp);
     w.rowloss = a.take<float>((size_t)MF_NUM_KINDS * w.Bp);
     w.rowc = a.take<float>((size_t)4 * w.Bp);
-    w.blockpart = a.take<float>((size_t)MF_NUM_KINDS * (w.Bp / 256 + 1));
+    w.blockpart = a.take<float>((size_t)MF_NUM_KINDS * (w.Bp / 64 + 1));
     w.ticket = a.take<unsigned>(4);
     if (w.mined) {
         w.cand = a.take<unsigned long long>((size_t)w.Bp * w.plan.rowcap);
@@ -127,11 +127,12 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
         w.cand_cnt = a.take<int32_t>((size_t)w.Bp);      // right behind gtau: one memset clears both
         w.dpart = nullptr;
     } else {
-        size_t rows = (size_t)w.nsplit_u * w.Bp;
-        size_t rows_v = (size_t)w.nsplit_v * w.Np;
-        if (rows_v > rows) rows = rows_v;
+        // the two backward sweeps keep their split partials apart: ONE launch adds up both after the second sweep
+        const size_t rows = (size_t)w.nsplit_u * w.Bp, rows_v = (size_t)w.nsplit_v * w.Np;
         w.dpart = a.take<float>(rows * d);
         w.rpart = a.take<float>(rows);
+        w.dpart_v = a.take<float>(rows_v * d);
+        w.rpart_v = a.take<float>(rows_v);
         w.stash = a.take<float>((size_t)w.Bp * w.Np);
         w.gstash = a.take<float>((size_t)w.Bp * w.Np);
     }
@@ -661,29 +662,27 @@ __device__ __forceinline__ void rowc_row(int kind, float t, float s, float l, fl
 // order (nsplit = 0: `stats` is already final), evaluate the seven per-row losses, and sum them over
 // the batch in a fixed order: in-block tree, then the last workgroup to finish (ticket) adds the
 // block sums in block order -- deterministic, no second launch.
-__global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ part, int nsplit, int64_t B, int64_t Bp,
+__global__ __launch_bounds__(64) void finish_kernel(const float* __restrict__ part, int nsplit, int64_t B, int64_t Bp,
                                                      const float* __restrict__ target, const float* __restrict__ lii,
                                                      const float* __restrict__ dii, float sigma, int kind_mask,
                                                      float* __restrict__ stats, float* __restrict__ rowloss,
                                                      float* __restrict__ blockpart, unsigned* __restrict__ ticket,
                                                      float* __restrict__ out, int rowc_kind, float margin,
                                                      const float* __restrict__ sgn, float* __restrict__ rowc) {
-    __shared__ float sh[MF_NUM_KINDS][256];
-    __shared__ bool last;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     float acc[NSTAT];
     if (i < Bp) {
         if (nsplit > 0) {
             for (int s = 0; s < NSTAT; ++s) acc[s] = part[(int64_t)s * Bp + i];
-            for (int sp0 = 1; sp0 < nsplit; sp0 += 4) {             // four splits' loads in flight, merged in order
-                float q[4][NSTAT];
+            for (int sp0 = 1; sp0 < nsplit; sp0 += 7) {             // seven splits' loads in flight, merged in order
+                float q[7][NSTAT];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 7; ++j)
 #pragma unroll
                     for (int s = 0; s < NSTAT; ++s)
                         q[j][s] = sp0 + j < nsplit ? part[((int64_t)(sp0 + j) * NSTAT + s) * Bp + i] : 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 7; ++j) {
                     if (sp0 + j >= nsplit) break;
                     lse_merge(acc[ST_MX], acc[ST_SE], q[j][ST_MX], q[j][ST_SE]);
                     acc[ST_CNT] += q[j][ST_CNT]; acc[ST_A] += q[j][ST_A]; acc[ST_H] += q[j][ST_H];
@@ -720,31 +719,27 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
                             sigma, margin, a, b, cg, gd);
         rowc[i] = a; rowc[Bp + i] = b; rowc[2 * Bp + i] = cg; rowc[3 * Bp + i] = gd;
     }
+    // one wave per workgroup: the block sum is a fixed xor tree over the lanes (no LDS, no barrier)
+    const int lane = mf_lane();
     for (int k = 0; k < MF_NUM_KINDS; ++k) {
         if (i < Bp) rowloss[(int64_t)k * Bp + i] = o[k];
-        sh[k][threadIdx.x] = o[k];
+        float v = o[k];
+        for (int w = 32; w > 0; w >>= 1) v += __shfl_xor(v, w, 64);
+        if (lane == 0) blockpart[(int64_t)k * gridDim.x + blockIdx.x] = v;
     }
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st)
-            for (int k = 0; k < MF_NUM_KINDS; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x < MF_NUM_KINDS) blockpart[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = sh[threadIdx.x][0];
     __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    __syncthreads();
+    int last = 0;
+    if (lane == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    last = __shfl(last, 0, 64);
     if (last) {
-        // wave k (two passes for 7 kinds on 4 waves) adds the block sums of loss kind k: lane-strided
-        // partial sums, then a fixed xor tree -- the same order on every run
+        // the last workgroup adds the block sums of every loss kind: lane-strided partial sums, then a fixed
+        // xor tree -- the same order on every run
         __threadfence();
-        const int lane = mf_lane();
-        for (int k = (int)(threadIdx.x >> 6); k < MF_NUM_KINDS; k += 4) {
+        for (int k = 0; k < MF_NUM_KINDS; ++k) {
             float tot = 0.f;
             const volatile float* bp = blockpart + (int64_t)k * gridDim.x;
             for (unsigned b = lane; b < gridDim.x; b += 64) tot += bp[b];
-            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+            for (int w = 32; w > 0; w >>= 1) tot += __shfl_xor(tot, w, 64);
             if (lane == 0) out[k] = ((kind_mask >> k) & 1) ? tot : 0.f;   // every entry is written
         }
     }
@@ -934,6 +929,9 @@ __device__ __forceinline__ float g_of(int gmode, float x) {
 // and has no per-element arithmetic at all: on gfx950 fp32 MFMA and VALU share the SIMD's FP32
 // lanes (a VALU op costs ~2 cycles of MFMA throughput, a transcendental ~17 -- measured), so
 // every VALU instruction removed from these loops is MFMA time won back.
+// (Folding the split sum into these kernels -- the workgroup that reaches an X block's ticket last adds the
+// partials -- was measured and dropped: 64..128 last workgroups reading 8 x 64 KiB each is far less parallel than
+// the separate sum_parts launch; dU 0.287 -> 0.489 ms.)
 struct BwdParams {
     const float *u, *v, *rowc;
     const float* grad_out;   // device scalar: the row coefficients are scaled by it here
@@ -1116,22 +1114,29 @@ __global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss
     }
 }
 
-// out[r] = sum over splits (in split order) of dpart[s][r]  -  (sum over splits of rpart[s][r]) * X[r]
-__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ dpart, const float* __restrict__ rpart,
-                                                        const float* __restrict__ X, int nsplit, int64_t rows,
-                                                        int64_t rows_p, int d, float* __restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one float4 each
+// out[r] = sum over splits (in split order) of dpart[s][r]  -  (sum over splits of rpart[s][r]) * X[r],
+// for the rows of dU (workgroups [0, nb_a)) and of dV (the rest) in one launch
+struct SumJob {
+    const float *dpart, *rpart, *X;
+    int nsplit;
+    int64_t rows, rows_p;
+    float* out;
+};
+__global__ __launch_bounds__(256) void sum_parts_kernel(SumJob ja, SumJob jb, int d, int nb_a) {
+    const bool first = (int)blockIdx.x < nb_a;
+    const SumJob& j = first ? ja : jb;
+    const int64_t t = (int64_t)(blockIdx.x - (first ? 0 : nb_a)) * 256 + threadIdx.x;   // one float4 each
     const int64_t per_row = d / 4;
-    if (t >= rows * per_row) return;
+    if (t >= j.rows * per_row) return;
     const int64_t r = t / per_row, cidx = t % per_row;
-    f32x4 acc = reinterpret_cast<const f32x4*>(dpart + r * d)[cidx];
-    float rs = rpart[r];
-    for (int s = 1; s < nsplit; ++s) {
-        acc += reinterpret_cast<const f32x4*>(dpart + ((int64_t)s * rows_p + r) * d)[cidx];
-        rs += rpart[(int64_t)s * rows_p + r];
+    f32x4 acc = reinterpret_cast<const f32x4*>(j.dpart + r * d)[cidx];
+    float rs = j.rpart[r];
+    for (int s = 1; s < j.nsplit; ++s) {
+        acc += reinterpret_cast<const f32x4*>(j.dpart + ((int64_t)s * j.rows_p + r) * d)[cidx];
+        rs += j.rpart[(int64_t)s * j.rows_p + r];
     }
-    const f32x4 xr = reinterpret_cast<const f32x4*>(X + r * d)[cidx];
-    reinterpret_cast<f32x4*>(out + r * d)[cidx] = acc - rs * xr;
+    const f32x4 xr = reinterpret_cast<const f32x4*>(j.X + r * d)[cidx];
+    reinterpret_cast<f32x4*>(j.out + r * d)[cidx] = acc - rs * xr;
 }
 
 // alignment-only backward: only the diagonal carries gradient
@@ -1359,7 +1364,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     } else {
         (void)hipMemsetAsync(w.stats, 0, (size_t)NSTAT * w.Bp * 4, s);
     }
-    finish_kernel<<<dim3((unsigned)(w.Bp / 256 + (w.Bp % 256 ? 1 : 0))), 256, 0, s>>>(w.part, merge_splits, B, w.Bp, w.tgt, w.lii, w.dii,
+    finish_kernel<<<dim3((unsigned)((w.Bp + 63) / 64)), 64, 0, s>>>(w.part, merge_splits, B, w.Bp, w.tgt, w.lii, w.dii,
                                                                                        sigma, kind_mask, w.stats, w.rowloss,
                                                                                        w.blockpart, w.ticket, out_losses,
                                                                                        rowc_kind, margin, w.sgn, w.rowc);
@@ -1396,10 +1401,11 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
         MF_DISPATCH_D(d, {
             bp.YT = w.NT; bp.tps = w.tps_u;
             MF_TIMED("loss_bwd_du", s, (launch_bwd<D, true>(gmode, dim3((unsigned)w.nsplit_u, (unsigned)(w.BT / w.NW)), bp, s)));
-            sum_parts_kernel<<<dim3((unsigned)((B * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.rpart, u, w.nsplit_u, B, w.Bp, D, du);
-            bp.YT = w.BT; bp.tps = w.tps_v;
+            bp.YT = w.BT; bp.tps = w.tps_v; bp.dpart = w.dpart_v; bp.rpart = w.rpart_v;
             MF_TIMED("loss_bwd_dv", s, (launch_bwd<D, false>(G_EXP, dim3((unsigned)w.nsplit_v, (unsigned)(w.NT / w.NW)), bp, s)));
-            sum_parts_kernel<<<dim3((unsigned)((N * (D / 4) + 255) / 256)), 256, 0, s>>>(w.dpart, w.rpart, v, w.nsplit_v, N, w.Np, D, dv);
+            const SumJob ja{w.dpart, w.rpart, u, w.nsplit_u, B, w.Bp, du}, jb{w.dpart_v, w.rpart_v, v, w.nsplit_v, N, w.Np, dv};
+            const int nb_a = (int)((B * (D / 4) + 255) / 256), nb_b = (int)((N * (D / 4) + 255) / 256);
+            sum_parts_kernel<<<dim3((unsigned)(nb_a + nb_b)), 256, 0, s>>>(ja, jb, D, nb_a);
         });
     }
     return mf_check_launch("mf_loss_bwd");
