@@ -47,6 +47,8 @@ if str(ROOT) not in sys.path:
 NUM_USERS, NUM_ITEMS, DIM = 162_541, 62_423, 128       # ML-25M shape
 TIME_EVERY = int(os.environ.get("MF_BENCH_TIME_EVERY", "4"))   # HIP-event pairs around every 4th launch of each timed kernel, inside the timed region
                     # (an event pair costs ~6 us of stream time around the kernel it brackets)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md)
+LDS_DMA_CHIP_GBS = 6400.0          # measured chip-wide LDS-DMA fill rate (MI355X_MICROARCH.md, 'ldsdma-fill')
 PEAK_F32_MFMA_TFLOPS = 157.3                            # MI355X_MICROARCH.md, fp32 matrix
 PEAK_HBM_GBS = 8000.0
 TOP_K, POS_PAD = 20, 64
@@ -486,11 +488,27 @@ def main() -> None:
     lib.mf_timing_enable(0)
     qps = world * Q * K / dt_topk
     span, _n = kernel_span(lib, "topk_select")
+    span_bf, _nb = kernel_span(lib, "topk_bf3")
     topk_roof = None
-    if span:
-        # per launch every rank scores (world * Q) queries against its N / world rows
-        n_local = items.shape[0] if not dist_on else trainer.item_shard().shape[0]
-        flops = 2.0 * (world * Q) * n_local * DIM
+    # per launch every rank scores (world * Q) queries against its N / world rows
+    n_local = items.shape[0] if not dist_on else trainer.item_shard().shape[0]
+    flops = 2.0 * (world * Q) * n_local * DIM
+    if span_bf:
+        # the many-query path (mf_topk_bf3): two bf16 MFMA scans (2 x the algorithmic flops, at the bf16 rate) of a
+        # bf16 copy of the catalog, staged through LDS once per block of 128 queries and scan, then exact fp32
+        # rescoring of a few dozen rows per query.  `achieved` counts the ALGORITHMIC 2 Q N d only; one event pair
+        # spans the four launches.  The scans are bound by the LDS-DMA rate, not by the matrix pipe: both are shown.
+        ach = flops / (span_bf * 1e-3) / 1e12
+        staged = 2.0 * ((world * Q + 127) // 128) * n_local * DIM * 2
+        topk_roof = {"kernel": "bf3_scan_kernel x2 + bf3_bound_kernel + bf3_final_kernel", "bound": "mfma", "achieved": round(ach, 2),
+                     "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                     "traffic": measured_traffic("topk_bf3") if (Q, DIM, world) == (1024, 128, 1) else None,
+                     "avg_ms": round(span_bf, 4), "mfma_dtype": "bf16 (fp32 accumulate), exact fp32 rescoring",
+                     "executed_mfma_frac": round(2 * ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                     "of_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                     "lds_dma": {"staged_GB_per_call": round(staged / 1e9, 4), "achieved_GBps": round(staged / (span_bf * 1e-3) / 1e9, 1),
+                                 "chip_rate_GBps": LDS_DMA_CHIP_GBS, "frac": round(staged / (span_bf * 1e-3) / 1e9 / LDS_DMA_CHIP_GBS, 4)}}
+    elif span:
         ach = flops / (span * 1e-3) / 1e12
         # one event pair spans the selection of a call: seeding pass over 1/8 of the catalog (which adds 1/8
         # to the flops actually issued; `achieved` counts the ALGORITHMIC 2 Q N d only), bound, main pass

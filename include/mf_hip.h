@@ -217,6 +217,20 @@ int mf_topk_small(const float* q, int64_t Q, const float* blocked, int64_t N, in
                   const int64_t* excl_off, const int64_t* excl_idx, int64_t idx_base, void* ws,
                   size_t ws_bytes, float* out_scores, int64_t* out_idx, mf_stream_t stream);
 
+/* Many-query form of mf_topk (Q >= ~64, d in {64, 128, 256}): the catalog is scanned TWICE with bf16 operands
+ * (v_mfma_f32_32x32x16_bf16: 16x the fp32 MFMA rate, half the bytes) -- once for per-query bounds, once for the rows
+ * above them -- and only those few dozen rows per query are scored with the canonical fp32 fmaf chain.  A rigorous
+ * bound on the bf16 error (csrc/mf_topk_bf3.hip) makes the candidate set a superset of the true top k, so scores,
+ * order, rows, exclusion semantics and the -inf / -1 tail are IDENTICAL to mf_topk's (finite inputs).  `index`:
+ * mf_topk_bf3_index_bytes(N, d) bytes filled once per catalog by mf_topk_bf3_build (bf16 rows + the largest row
+ * norm); `items` are the same fp32 rows mf_topk takes. */
+size_t mf_topk_bf3_index_bytes(int64_t N, int d);
+int mf_topk_bf3_build(const float* items, int64_t N, int d, void* index, size_t index_bytes, mf_stream_t stream);
+size_t mf_topk_bf3_ws_bytes(int64_t Q, int64_t N, int d, int k);
+int mf_topk_bf3(const float* q, int64_t Q, const float* items, const void* index, int64_t N, int d, int k,
+                const int64_t* excl_off, const int64_t* excl_idx, int64_t idx_base, void* ws, size_t ws_bytes,
+                float* out_scores, int64_t* out_idx, mf_stream_t stream);
+
 /* Retrieval metrics @k on device, straight from the top-k output.  Replaces the
  * per-example torchmetrics updates of `update_metrics` / `get_metrics` (xfmr_rec/lightning.py:149-187,
  * :289-306: RetrievalNormalizedDCG / Recall / Precision / MAP / HitRate / MRR, top_k = 20).

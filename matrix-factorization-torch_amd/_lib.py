@@ -62,6 +62,10 @@ SIGNATURES = {
     "mf_topk_blocked_build": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "mf_topk_small_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int]),
     "mf_topk_small": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "mf_topk_bf3_index_bytes": (c_sz, [c_i64, c_int]),
+    "mf_topk_bf3_build": (c_int, [c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
+    "mf_topk_bf3_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int]),
+    "mf_topk_bf3": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp]),
 }
 
 LOSS_TARGET_I64, LOSS_ROWC, LOSS_MASKS_READY = 1, 2, 4     # flags of mf_loss_fwd / mf_loss_bwd (include/mf_hip.h)

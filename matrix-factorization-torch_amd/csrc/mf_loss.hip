@@ -735,12 +735,22 @@ __global__ __launch_bounds__(64) void finish_kernel(const float* __restrict__ pa
         // the last workgroup adds the block sums of every loss kind: lane-strided partial sums, then a fixed
         // xor tree -- the same order on every run
         __threadfence();
+        float tot[MF_NUM_KINDS];
+#pragma unroll
+        for (int k = 0; k < MF_NUM_KINDS; ++k) tot[k] = 0.f;
+        for (unsigned b = lane; b < gridDim.x; b += 64) {       // the seven kinds' loads of a round are in flight together
+            float v[MF_NUM_KINDS];
+#pragma unroll
+            for (int k = 0; k < MF_NUM_KINDS; ++k)
+                v[k] = __hip_atomic_load(blockpart + (int64_t)k * gridDim.x + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < MF_NUM_KINDS; ++k) tot[k] += v[k];
+        }
+#pragma unroll
         for (int k = 0; k < MF_NUM_KINDS; ++k) {
-            float tot = 0.f;
-            const volatile float* bp = blockpart + (int64_t)k * gridDim.x;
-            for (unsigned b = lane; b < gridDim.x; b += 64) tot += bp[b];
-            for (int w = 32; w > 0; w >>= 1) tot += __shfl_xor(tot, w, 64);
-            if (lane == 0) out[k] = ((kind_mask >> k) & 1) ? tot : 0.f;   // every entry is written
+            float t = tot[k];
+            for (int w = 32; w > 0; w >>= 1) t += __shfl_xor(t, w, 64);
+            if (lane == 0) out[k] = ((kind_mask >> k) & 1) ? t : 0.f;   // every entry is written
         }
     }
 }

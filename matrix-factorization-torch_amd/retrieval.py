@@ -45,6 +45,7 @@ class ItemIndex:
         self.embeddings = emb.contiguous()
         self.idx_base = int(idx_base)
         self._blocked: torch.Tensor | None = None      # second copy for the small-batch scan, built on first use
+        self._bf16: torch.Tensor | None = None         # bf16 copy + largest row norm for the prefilter path, built on first use
         self._ws: dict = {}                              # search workspaces, kept between calls
 
     SMALL_Q = 32       # at most this many queries can take the bandwidth-bound matrix-vector path (mf_topk_small)
@@ -59,6 +60,19 @@ class ItemIndex:
             _lib.check(lib.mf_topk_blocked_build(self.embeddings.data_ptr(), n, d, out.data_ptr(), _lib.stream_ptr()))
             self._blocked = out
         return self._blocked
+
+    BF16_MIN_Q = 64    # "auto" takes the bf16-prefilter path from here (and d >= 64, N >= BF16_MIN_N)
+    BF16_MIN_N = 8192
+
+    def bf16_index(self) -> torch.Tensor:
+        """bf16 rows + the largest row norm, the prefilter index of ``mf_topk_bf3``; built once."""
+        if self._bf16 is None:
+            lib = _lib.lib()
+            n, d = self.embeddings.shape
+            out = torch.empty(lib.mf_topk_bf3_index_bytes(n, d), dtype=torch.uint8, device=self.embeddings.device)
+            _lib.check(lib.mf_topk_bf3_build(self.embeddings.data_ptr(), n, d, out.data_ptr(), out.numel(), _lib.stream_ptr()))
+            self._bf16 = out
+        return self._bf16
 
     def _workspace(self, key, nbytes: int) -> torch.Tensor:
         ws = self._ws.get(key)
@@ -75,8 +89,9 @@ class ItemIndex:
                path: str = "auto") -> tuple[torch.Tensor, torch.Tensor]:
         """``(scores [Q, k] fp32, rows [Q, k] int64)``, best first; ``exclude`` holds GLOBAL
         item rows per query (or pass a prebuilt device CSR with sorted ids).  ``path``: "scan" = the
-        matrix-vector kernel (at most ``SMALL_Q`` queries), "tiles" = the MFMA tile engine, "auto" picks by the
-        number of queries; both give the same bits."""
+        matrix-vector kernel (at most ``SMALL_Q`` queries), "tiles" = the fp32 MFMA tile engine, "bf16" = two bf16
+        MFMA scans that pick the few dozen rows per query worth an exact fp32 score (d >= 64), "auto" picks by the
+        number of queries; all three give the same bits."""
         q = _lib.dev_f32(queries, "queries")
         if q.dim() != 2 or q.shape[1] != self.dim:
             msg = f"queries should be (num_queries, {self.dim}): {tuple(q.shape) = }"
@@ -88,8 +103,11 @@ class ItemIndex:
         lib = _lib.lib()
         scores = torch.empty(nq, top_k, dtype=torch.float32, device=q.device)
         rows = torch.empty(nq, top_k, dtype=torch.int64, device=q.device)
-        if path not in ("auto", "scan", "tiles"):
-            msg = f"path must be 'auto', 'scan' or 'tiles': {path = }"
+        if path not in ("auto", "scan", "tiles", "bf16"):
+            msg = f"path must be 'auto', 'scan', 'tiles' or 'bf16': {path = }"
+            raise ValueError(msg)
+        if path == "bf16" and d < 64:
+            msg = f"the bf16 path needs an embedding width of at least 64: {d = }"
             raise ValueError(msg)
         if path == "scan" and nq > self.SMALL_Q:
             msg = f"the scan path takes at most {self.SMALL_Q} queries: {nq = }"
@@ -100,6 +118,12 @@ class ItemIndex:
             _lib.check(lib.mf_topk_small(q.data_ptr(), nq, self.blocked().data_ptr(), n, d, top_k, _lib.ptr(off), _lib.ptr(ids),
                                          self.idx_base, ws.data_ptr(), ws.numel(), scores.data_ptr(), rows.data_ptr(),
                                          _lib.stream_ptr()))
+            return scores, rows
+        if path == "bf16" or (path == "auto" and nq >= self.BF16_MIN_Q and n >= self.BF16_MIN_N and d >= 64):
+            ws = self._workspace(("bf16", nq, top_k), lib.mf_topk_bf3_ws_bytes(nq, n, d, top_k))
+            _lib.check(lib.mf_topk_bf3(q.data_ptr(), nq, self.embeddings.data_ptr(), self.bf16_index().data_ptr(), n, d, top_k,
+                                       _lib.ptr(off), _lib.ptr(ids), self.idx_base, ws.data_ptr(), ws.numel(), scores.data_ptr(),
+                                       rows.data_ptr(), _lib.stream_ptr()))
             return scores, rows
         ws = self._workspace(("tile", nq, top_k), lib.mf_topk_ws_bytes(nq, n, d, top_k))
         _lib.check(lib.mf_topk(q.data_ptr(), nq, self.embeddings.data_ptr(), n, d, top_k, _lib.ptr(off), _lib.ptr(ids),

@@ -359,10 +359,57 @@ def test_topk_bit_exact(mf, cfg):
             for _ in range(nq)]
     index = mf.retrieval.ItemIndex(items.to(DEV))
     ws, wi = chain.topk(q.numpy(), items.numpy(), k, excl)
-    for path in ("tiles", "scan") if nq <= index.SMALL_Q else ("tiles",):     # both kernels, same bits
+    paths = ("tiles", "scan") if nq <= index.SMALL_Q else ("tiles",)
+    for path in paths + (("bf16",) if d >= 64 else ()):                       # every kernel, same bits
         s, i = index.search(q.to(DEV), k, exclude=excl, path=path)
         assert np.array_equal(i.cpu().numpy(), wi), path
         assert np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32)), path
+
+
+@pytest.mark.parametrize("case", ["random_1024", "zero_query_and_duplicates", "best_rows_in_one_group", "near_ties", "unnormalised",
+                                  "few_rows", "d64_excl", "d256"])
+def test_topk_bf16_prefilter_equals_tile_path(mf, case):
+    """mf_topk_bf3 (two bf16 MFMA scans + exact rescoring of the rows above a rigorous bound) against the fp32 tile
+    engine, bit for bit: random unit rows at the bench's shape, inputs that defeat the prefilter (a zero query --
+    every row ties; thousands of copies of one row; the best rows packed into one 128-row group: all answered by the
+    in-kernel exact scan), scores closer than the bf16 error, rows of very different norms, tiny catalogs,
+    exclusions and idx_base."""
+    g = torch.Generator().manual_seed(len(case))
+    nq, n, d, k, base = 200, 20000, 128, 20, 0
+    excl = None
+    if case == "random_1024":
+        nq, n = 1024, 62423
+    elif case == "few_rows":
+        nq, n, k = 70, 45, 20
+    elif case == "d64_excl":
+        nq, n, d, k, base = 130, 30000, 64, 64, 11
+    elif case == "d256":
+        nq, n, d, k = 100, 9000, 256, 10
+    q, items = _unit(nq, d, g), _unit(n, d, g)
+    if case == "zero_query_and_duplicates":
+        q[3] = 0.0
+        items[5000:9000] = items[17]                        # 4,000 copies: all tie with row 17
+        q[4] = items[17]
+    elif case == "best_rows_in_one_group":
+        items[256:384] = q[0] + 0.05 * torch.randn(128, d, generator=g)      # the 128 best rows of query 0 share a group
+    elif case == "near_ties":
+        items[1000:1040] = q[1] + 1e-4 * torch.randn(40, d, generator=g)     # 40 scores within ~1e-5 of each other
+    elif case == "unnormalised":
+        items *= torch.exp(2.0 * torch.randn(n, 1, generator=g))
+        q *= torch.exp(torch.randn(nq, 1, generator=g))
+    elif case == "d64_excl":
+        excl = [sorted(set((torch.randint(0, n, (int(torch.randint(0, 400, (1,), generator=g)),), generator=g) + base).tolist()))
+                for _ in range(nq)]
+    index = mf.retrieval.ItemIndex(items.to(DEV), idx_base=base)
+    st, it = index.search(q.to(DEV), k, exclude=excl, path="tiles")
+    sb, ib = index.search(q.to(DEV), k, exclude=excl, path="bf16")
+    assert torch.equal(it, ib)
+    assert torch.equal(st.view(torch.int32), sb.view(torch.int32))
+    if case == "random_1024":                               # what "auto" picks at this shape
+        sa, ia = index.search(q.to(DEV), k)
+        assert torch.equal(ia, it) and torch.equal(sa.view(torch.int32), st.view(torch.int32))
+    with pytest.raises(ValueError, match="at least 64"):
+        mf.retrieval.ItemIndex(torch.zeros(100, 32, device=DEV)).search(torch.zeros(2, 32, device=DEV), 5, path="bf16")
 
 
 @pytest.mark.parametrize("cfg", [(1, 62423, 128, 20), (1, 300000, 32, 20), (32, 70000, 64, 64), (5, 1000, 256, 7), (9, 64, 32, 64),
