@@ -24,6 +24,8 @@
 // than BF3_CAND in all: a zero query, thousands of duplicate rows, a catalog whose best rows all sit in one group)
 // is answered by the same wave scanning the whole catalog with the exact chain: slow, but exact.
 // Two scans of a catalog HALF the size of the fp32 one, 1/16 of the matrix time each: DMA-bound, not MFMA-bound.
+#include <cstdlib>
+
 #include "mf_common.h"
 #include "mf_select.h"
 
@@ -33,7 +35,6 @@ static constexpr int BF3_NS = 4;            // ring slots (units of ST tiles); N
 static constexpr int BF3_GROUP = 4;         // tiles per maxima group (128 rows)
 static constexpr int BF3_LIST = 16;         // rows per lane-private list (per chunk, query, lane half)
 static constexpr int BF3_CAND = 1024;       // candidates rescored per query
-static constexpr int BF3_MAXV = 32;         // group maxima per lane in the bound kernel (64 x 32 per query)
 
 __device__ __forceinline__ unsigned short bf3_round(float x) {
     const __bf16 b = (__bf16)x;
@@ -100,15 +101,18 @@ struct Bf3Plan {
     int upc, nchunk;    // units per chunk (workgroup), chunks
     int gpc;            // maxima groups per chunk
     int nvals;          // group maxima per query: nchunk * gpc * 2
-    int64_t Qp;         // queries padded to 128
-    int gy;             // query blocks (128 queries)
+    int XT;             // 32-query tiles per wave (1 or 2): a workgroup scans for 128 XT queries
+    int64_t Qp;         // queries padded to 128 XT
+    int gy;             // query blocks
 };
 static Bf3Plan bf3_plan(int64_t Q, int64_t N, int d) {
     Bf3Plan p{};
     p.NT = (int)((N + 31) / 32);
     p.ST = d >= 256 ? 1 : 2;                                   // 16 KiB per unit
-    p.Qp = (Q + 127) / 128 * 128;
-    p.gy = (int)(p.Qp / 128);
+    // every block of queries stages the whole catalog through LDS: twice the queries per workgroup, half the traffic
+    p.XT = (Q > 256 && d <= 128) ? 2 : 1;
+    p.Qp = (Q + 128 * p.XT - 1) / (128 * p.XT) * (128 * p.XT);
+    p.gy = (int)(p.Qp / (128 * p.XT));
     const int units = (p.NT + p.ST - 1) / p.ST;
     int want = (512 + p.gy - 1) / p.gy;                        // two workgroups per CU
     if (want > 128) want = 128;
@@ -130,7 +134,7 @@ struct Bf3Ws {
     float* thr;             // [Qp]
     uint32_t* lists;        // [nchunk][Qp][2][BF3_LIST] catalog rows
     int32_t* lcnt;          // [nchunk][Qp][2]
-    uint32_t* exclW;        // [NT][Qp]
+    uint32_t* exclW;        // [Qp][NT]: bit r of word t = row 32 t + r is excluded for the query
     size_t total;
 };
 static Bf3Ws bf3_ws(void* base, int64_t Q, int64_t N, int d) {
@@ -141,7 +145,7 @@ static Bf3Ws bf3_ws(void* base, int64_t Q, int64_t N, int d) {
     w.thr = a.take<float>((size_t)w.plan.Qp);
     w.lists = a.take<uint32_t>((size_t)w.plan.nchunk * w.plan.Qp * 2 * BF3_LIST);
     w.lcnt = a.take<int32_t>((size_t)w.plan.nchunk * w.plan.Qp * 2);
-    w.exclW = a.take<uint32_t>((size_t)w.plan.NT * w.plan.Qp);
+    w.exclW = a.take<uint32_t>((size_t)w.plan.NT * w.plan.Qp + 64);
     w.total = a.used();
     return w;
 }
@@ -157,140 +161,215 @@ struct Bf3Scan {
     const unsigned short* plane;
     int64_t N;
     int NT, upc, gpc, nvals;
-    const uint32_t* exclW;      // [NT][Qp]
+    const uint32_t* exclW;      // [Qp][NT]
     float* gmax;                // pass A out
     const float* thr;           // pass B in
     uint32_t* lists;
     int32_t* lcnt;
+    int abl;                    // lab knob (MF_BF3_ABL): 1 = no staging, 2 = no arithmetic -- wrong results, for timing only
 };
 
-template <int D, int ST, bool EXCL>
+template <int D, int ST, int XT, bool EXCL>
 struct Bf3Lds {
     using G = TileGeom<D / 2>;                               // a bf16 row is as long as a fp32 row of half the width
     static constexpr int UNITB = ST * G::TILEB;
-    static constexpr int AUXW = 1024;                        // per wave and unit: ST x 128 B of exclusion words (+ zero fill)
+    static constexpr int AUXW = XT * 256;                    // per wave and unit: one exclusion word per lane and query tile ([xt][tile of the unit][query])
     static constexpr int AUX0 = BF3_NS * UNITB;
     static constexpr int BYTES = AUX0 + (EXCL ? BF3_NS * G::NW * AUXW : 0);
-    static constexpr int SI = ST * G::PPW + (EXCL ? 1 : 0);  // memory instructions per wave and stage
+    static constexpr int SI = ST * G::PPW + (EXCL ? XT : 0); // memory instructions per wave and stage
 };
 
+#ifdef BF3_PROBE
+// tools/lab/bf3_probe.py: cycles of wave 0 of every workgroup, summed: 0 total, 1 prologue, 2 wait + barrier, 3 stage issue,
+// 4 LDS reads + MFMAs, 5 epilogue, 6 tail, 7 workgroups
+static __device__ unsigned long long bf3_dbg[2][8];
+#define BF3_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define BF3_ADD(i, x) dbg[i] += (x)
+#else
+#define BF3_T(v)
+#define BF3_ADD(i, x)
+#endif
+
 // PASS 0: group maxima; PASS 1: candidate lists
-template <int D, int ST, bool EXCL, int PASS>
+template <int D, int ST, int XT, bool EXCL, int PASS>
 __global__ __launch_bounds__(256, 2) void bf3_scan_kernel(Bf3Scan p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using L = Bf3Lds<D, ST, EXCL>;
+    using L = Bf3Lds<D, ST, XT, EXCL>;
     using G = typename L::G;
     constexpr int KS = D / 16;                               // MFMA steps per tile
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int wave = mf_wave_id();
     const int chunk = blockIdx.x;
-    const int64_t x0 = ((int64_t)blockIdx.y * G::NW + wave) * 32;
-    const int64_t x = x0 + c;
+    const int64_t x0 = ((int64_t)blockIdx.y * G::NW + wave) * (32 * XT);     // this wave's XT query tiles
     const int u0 = chunk * p.upc;
     const int units = (p.NT + ST - 1) / ST;
     const int u1 = min(units, u0 + p.upc);
-
-    // the query's bf16 fragments: step s covers k = 16 s + 8 h .. + 7
-    bf16x8 xb[KS];
-    {
-        const bool ok = x < p.Q;
-        const float* xr = p.q + (ok ? x : 0) * D;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-            if (ok) {
-                a = *reinterpret_cast<const f32x4*>(xr + 16 * s + 8 * h);
-                b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 8 * h + 4);
-            }
-            xb[s] = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
-        }
-    }
-    const float thr = (PASS == 1 && x < p.Q) ? p.thr[x] : __builtin_inff();
+#ifdef BF3_PROBE
+    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 1};
+#endif
+    BF3_T(pt0);
 
     TileSrc<D / 2> tsrc;
     mf_tile_src_init<D / 2>(tsrc, reinterpret_cast<const float*>(p.plane), p.N, (int64_t)u0 * ST * 32);
     mf_rsrc_t arsrc;
-    uint32_t aoff = 0u, astep = 0u;
+    uint32_t aoff[XT], astep = 0u;
     if (EXCL) {
-        // exclusion words of a unit: tile j of the unit by lanes 8 j .. 8 j + 7 (128 B = this wave's 32 queries)
-        const int part = lane >> 3, l8 = lane & 7;
-        aoff = part < ST ? (uint32_t)((((int64_t)(u0 * ST + part)) * p.Qp + x0) * 4) + l8 * 16 : MF_SRD_DEAD;
-        astep = part < ST ? (uint32_t)(ST * p.Qp * 4) : 0u;
+        // exclusion words of a unit: lane (c, j) fetches the word of query x0 + 32 xt + c for tile j of the unit (4-byte DMA)
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt)
+            aoff[xt] = h < ST ? (uint32_t)((((int64_t)(x0 + 32 * xt + c)) * p.NT + u0 * ST + h) * 4) : MF_SRD_DEAD;
+        astep = h < ST ? (uint32_t)(ST * 4) : 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint64_t ab = (uint64_t)p.NT * (uint64_t)p.Qp * 4u;
+        const uint64_t ab = ((uint64_t)p.NT * (uint64_t)p.Qp + 64u) * 4u;
         arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.exclW), 0, (int)(ab > MF_SRD_MAX_BYTES ? MF_SRD_MAX_BYTES : ab), 0x00020000);
 #else
         (void)arsrc; (void)aoff;
 #endif
     }
-    auto stage = [&](int u, bool live) {                    // unit u into slot (u - u0) % NS
-        char* slot = smem + ((u - u0) % BF3_NS) * L::UNITB;
-#pragma unroll
-        for (int st = 0; st < ST; ++st)
-#pragma unroll
-            for (int q = 0; q < G::PPW; ++q) mf_stage_tile_piece<D / 2>(slot + st * G::TILEB, (u * ST + st) * 32, q, tsrc, live);
-        if (EXCL) {
+    // memory instruction j (0 .. SI-1) of the staging of unit u into slot (u - u0) % NS
+    auto stage_piece = [&](int u, int j, bool live) {
+        if (j < ST * G::PPW) {
+            char* slot = smem + ((u - u0) % BF3_NS) * L::UNITB;
+            const int st = j / G::PPW, q = j % G::PPW;
+            mf_stage_tile_piece<D / 2>(slot + st * G::TILEB, (u * ST + st) * 32, q, tsrc, live);
+        } else if (EXCL) {
+            const int xt = j - ST * G::PPW;
 #if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (mf_lds_ptr)(smem + L::AUX0 + (((u - u0) % BF3_NS) * G::NW + wave) * L::AUXW), 16,
-                                                     (int)aoff, live ? 0 : (int)MF_SRD_DEAD, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (mf_lds_ptr)(smem + L::AUX0 + (((u - u0) % BF3_NS) * G::NW + wave) * L::AUXW + xt * 256), 4,
+                                                     (int)aoff[xt], live ? 0 : (int)MF_SRD_DEAD, 0, 0);
 #endif
-            aoff += astep;
+            aoff[xt] += astep;
         }
     };
+    auto stage = [&](int u, bool live) {
+#pragma unroll
+        for (int j = 0; j < L::SI; ++j) stage_piece(u, j, live);
+    };
+    // the first units are on their way while the queries are fetched and rounded
+    if (u0 < u1) {
+#pragma unroll
+        for (int j = 0; j < BF3_NS - 1; ++j) stage(u0 + j, u0 + j < u1 && !(p.abl & 1));
+    }
 
-    float gm = -__builtin_inff();                            // running maximum of the current group (this lane's 16 rows per tile)
-    int lc = 0;                                              // PASS 1: entries in this lane's list
-    uint32_t* mylist = PASS == 1 ? p.lists + (((int64_t)chunk * p.Qp + x) * 2 + h) * BF3_LIST : nullptr;
+    // the queries' bf16 fragments: step s covers k = 16 s + 8 h .. + 7
+    bf16x8 xb[XT][KS];
+    float thr[XT];
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) {
+        const int64_t x = x0 + 32 * xt + c;
+        const bool ok = x < p.Q;
+        // (padding lanes read the last query: no branch around the loads, and nothing of theirs is ever stored)
+        const float* xr = p.q + (ok ? x : p.Q - 1) * D;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s + 8 * h);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 8 * h + 4);
+            xb[xt][s] = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+        }
+        thr[xt] = (PASS == 1 && ok) ? p.thr[x] : __builtin_inff();      // (bf3_bound_kernel: already nudged below the bound)
+    }
+
+    float gm[XT];                                            // running maximum of the current group (this lane's 16 rows per tile)
+    int lc[XT];                                              // PASS 1: entries in this lane's lists
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) { gm[xt] = -__builtin_inff(); lc[xt] = 0; }
     const int tail_tile = (p.N & 31) ? p.NT - 1 : -1;        // its rows past N score 0: never a maximum, never a candidate
     const int tail_rows = (int)(p.N & 31);
 
+    BF3_T(pt1);
+    BF3_ADD(1, pt1 - pt0);
     if (u0 < u1) {
-#pragma unroll
-        for (int j = 0; j < BF3_NS - 1; ++j) stage(u0 + j, u0 + j < u1);
         for (int u = u0; u < u1; ++u) {
+            BF3_T(pa);
             // unit u is older than the NS - 2 stages issued after it (every stage issues SI instructions, live or not)
             mf_wait_vmcnt<(BF3_NS - 2) * L::SI>();
             mf_block_barrier();                              // ... for every wave; and unit u - 1's slot is free
-            stage(u + BF3_NS - 1, u + BF3_NS - 1 < u1);
+            BF3_T(pb);
+            const bool live_n = u + BF3_NS - 1 < u1 && !(p.abl & 1);
+            BF3_T(pc);
+            BF3_ADD(2, pb - pa);
+            BF3_ADD(3, pc - pb);
+            if (p.abl & 2) { stage(u + BF3_NS - 1, live_n); continue; }
             const char* slot = smem + ((u - u0) % BF3_NS) * L::UNITB;
+            // every catalog fragment of the unit first (one LDS latency per unit, not per step), then its MFMAs
+            bf16x8 afr[ST][KS];
+            {
+                const char* rowp = slot + c * G::ROWB;
+                const int sw = G::swz(c);
+#pragma unroll
+                for (int st = 0; st < ST; ++st)
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+                        afr[st][s] = *reinterpret_cast<const bf16x8*>(rowp + st * G::TILEB + (((2 * s + h) ^ sw) << 4));
+            }
+            // the staging of unit u + NS - 1 (into the slot unit u - 1 left) goes out one instruction per few MFMAs
+            f32x16 accs[ST][XT];
+            constexpr int NMF = ST * XT * KS, GAP = NMF / L::SI;
+            int issued = 0;
+#pragma unroll
+            for (int st = 0; st < ST; ++st)
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) accs[st][xt][e] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const int i = (st * XT + xt) * KS + s;
+                        if (i % GAP == 0 && i / GAP < L::SI) { stage_piece(u + BF3_NS - 1, i / GAP, live_n); ++issued; }
+                        accs[st][xt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st][s], xb[xt][s], accs[st][xt], 0, 0, 0);
+                    }
+                }
+            static_assert(GAP >= 1, "more staging instructions than MFMAs");
+            (void)issued;
+#ifdef BF3_PROBE
+            asm volatile("s_nop 0" :: "v"(accs[ST - 1][XT - 1][15]));       // (the stamp waits for the last MFMA)
+#endif
+            BF3_T(pd);
+            BF3_ADD(4, pd - pc);
 #pragma unroll
             for (int st = 0; st < ST; ++st) {
                 const int t = u * ST + st;
                 if (t >= p.NT) break;
-                const char* rowp = slot + st * G::TILEB + c * G::ROWB;
-                const int sw = G::swz(c);
-                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const f32x16 (&acc)[XT] = accs[st];
+                const int tl = t - u0 * ST;                  // tile of the chunk
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowp + (((2 * s + h) ^ sw) << 4));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], acc, 0, 0, 0);
-                }
-                uint32_t dead = 0u;                          // rows of this tile that do not count for this lane's query
-                if (EXCL) dead = reinterpret_cast<const uint32_t*>(smem + L::AUX0 + (((u - u0) % BF3_NS) * G::NW + wave) * L::AUXW)[st * 32 + c];
-                if (t == tail_tile) dead |= ~0u << tail_rows;
-                if (PASS == 0) {
-                    if (__any(dead != 0u)) {
+                for (int xt = 0; xt < XT; ++xt) {
+                    const int64_t x = x0 + 32 * xt + c;
+                    uint32_t dead = 0u;                      // rows of this tile that do not count for this lane's query
+                    if (EXCL) dead = reinterpret_cast<const uint32_t*>(smem + L::AUX0 + (((u - u0) % BF3_NS) * G::NW + wave) * L::AUXW + xt * 256)[st * 32 + c];
+                    if (PASS == 0) {
+                        // (v_med3(a, b, +inf) = max(a, b) on finite scores, without the NaN-quieting moves fmaxf asks for)
+                        if (EXCL && __any(dead != 0u)) {
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) gm = fmaxf(gm, ((dead >> mf_acc_row(e, h)) & 1u) ? -__builtin_inff() : acc[e]);
+                            for (int e = 0; e < 16; ++e)
+                                gm[xt] = __builtin_amdgcn_fmed3f(gm[xt], ((dead >> mf_acc_row(e, h)) & 1u) ? -__builtin_inff() : acc[xt][e], __builtin_inff());
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) gm[xt] = __builtin_amdgcn_fmed3f(gm[xt], acc[xt][e], __builtin_inff());
+                        }
+                        if ((tl % BF3_GROUP) == BF3_GROUP - 1 || t == p.NT - 1) {
+                            // the zero rows past N in the last tile are not rows: its group tells the bound nothing
+                            if (x < p.Q) p.gmax[x * p.nvals + ((int64_t)chunk * p.gpc + tl / BF3_GROUP) * 2 + h] = (t == tail_tile) ? -__builtin_inff() : gm[xt];
+                            gm[xt] = -__builtin_inff();
+                        }
                     } else {
+                        // bit (15 - e) of hm: element e is above the bound.  Two instructions per element: the sign of
+                        // thr - score is shifted in (v_alignbit); "score > thr" instead of ">=" is why thr is nudged down below
+                        uint32_t hm = 0u;
 #pragma unroll
-                        for (int e = 0; e < 16; e += 2) gm = fmaxf(gm, fmaxf(acc[e], acc[e + 1]));
-                    }
-                    const int tl = t - u0 * ST;              // tile of the chunk
-                    if ((tl % BF3_GROUP) == BF3_GROUP - 1 || t == p.NT - 1) {
-                        if (x < p.Q) p.gmax[x * p.nvals + ((int64_t)chunk * p.gpc + tl / BF3_GROUP) * 2 + h] = gm;
-                        gm = -__builtin_inff();
-                    }
-                } else {
-                    float best = acc[0];
-#pragma unroll
-                    for (int e = 1; e < 16; ++e) best = fmaxf(best, acc[e]);
-                    if (__any(best >= thr)) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            if (acc[e] >= thr && !((dead >> mf_acc_row(e, h)) & 1u)) {
-                                if (lc < BF3_LIST) mylist[lc] = (uint32_t)t * 32u + (uint32_t)mf_acc_row(e, h);
-                                ++lc;
+                        for (int e = 0; e < 16; ++e)
+                            hm = __builtin_amdgcn_alignbit(hm, __builtin_bit_cast(uint32_t, thr[xt] - acc[xt][e]), 31);
+                        if (__any(hm != 0u)) {
+                            if (t == tail_tile) dead |= ~0u << tail_rows;
+                            uint32_t* mylist = p.lists + (((int64_t)chunk * p.Qp + x) * 2 + h) * BF3_LIST;
+                            while (hm) {
+                                const int e = 15 - __builtin_ctz(hm);
+                                hm &= hm - 1;
+                                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                                if (!((dead >> rr) & 1u)) {
+                                    if (lc[xt] < BF3_LIST) mylist[lc[xt]] = (uint32_t)t * 32u + (uint32_t)rr;
+                                    ++lc[xt];
+                                }
                             }
                         }
                     }
@@ -299,36 +378,57 @@ __global__ __launch_bounds__(256, 2) void bf3_scan_kernel(Bf3Scan p) {
         }
         mf_wait_vmcnt<0>();                                  // nothing of this workgroup may still be on its way into LDS when it ends
     }
-    if (PASS == 0) {
-        // groups this chunk never reached (short last chunk): no rows
-        const int done = u0 < u1 ? (min(u1 * ST, p.NT) - u0 * ST + BF3_GROUP - 1) / BF3_GROUP : 0;
-        if (x < p.Q)
+#ifdef BF3_PROBE
+    {
+        BF3_T(pe);
+        dbg[0] = pe - pt0;
+        dbg[6] = pe - pt1 - dbg[2] - dbg[3] - dbg[4];
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(&bf3_dbg[PASS][i], dbg[i]);
+    }
+#endif
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) {
+        const int64_t x = x0 + 32 * xt + c;
+        if (x >= p.Q) continue;
+        if (PASS == 0) {
+            // groups this chunk never reached (short last chunk): no rows
+            const int done = u0 < u1 ? (min(u1 * ST, p.NT) - u0 * ST + BF3_GROUP - 1) / BF3_GROUP : 0;
             for (int g = done; g < p.gpc; ++g) p.gmax[x * p.nvals + ((int64_t)chunk * p.gpc + g) * 2 + h] = -__builtin_inff();
-    } else if (x < p.Q) {
-        p.lcnt[((int64_t)chunk * p.Qp + x) * 2 + h] = lc;    // > BF3_LIST: overflow
+        } else {
+            p.lcnt[((int64_t)chunk * p.Qp + x) * 2 + h] = lc[xt];      // > BF3_LIST: overflow
+        }
     }
 }
 
 // ------------------------------------------------------------------- bound ----
-// one wave per query: thr = (k-th largest group maximum) - 2 eps
+// one wave per query: thr = (a lower bound of the k-th largest group maximum) - 2 eps.  Every lane reduces its
+// share of the maxima to its two best; the k-th largest of those 128 values (all scores of distinct rows) is at
+// most a few ranks below the exact k-th largest, at a tenth of the cost of searching all of them.
 __global__ __launch_bounds__(64) void bf3_bound_kernel(const float* __restrict__ gmax, int nvals, int k, const float* __restrict__ q,
                                                        int d, const float* __restrict__ ymax2, float* __restrict__ thr) {
     const int64_t r = blockIdx.x;
     const int lane = mf_lane();
-    unsigned v[BF3_MAXV];
-#pragma unroll
-    for (int j = 0; j < BF3_MAXV; ++j) {
-        const int i = lane + 64 * j;
-        // -inf (no row) ranks lowest among what can occur; 0 marks "no value"
-        v[j] = i < nvals ? mf_orderable(gmax[r * nvals + i]) : 0u;
-    }
     const unsigned ninf = mf_orderable(-__builtin_inff());
+    unsigned m1 = 0u, m2 = 0u;                               // 0: "no value" (ranks below -inf)
+    for (int i0 = 0; i0 < nvals; i0 += 64 * 8) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + lane + 64 * j;
+            f[j] = i < nvals ? gmax[r * nvals + i] : -__builtin_inff();
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned v = (i0 + lane + 64 * j) < nvals ? mf_orderable(f[j]) : 0u;
+            m2 = max(m2, min(m1, v));
+            m1 = max(m1, v);
+        }
+    }
     unsigned th = 0u;
     for (int b = 31; b >= 0; --b) {                          // largest th with #{v >= th} >= k
         const unsigned cnd = th | (1u << b);
-        int cge = 0;
-#pragma unroll
-        for (int j = 0; j < BF3_MAXV; ++j) cge += __popcll(__ballot(v[j] >= cnd));
+        const int cge = __popcll(__ballot(m1 >= cnd)) + __popcll(__ballot(m2 >= cnd));
         if (cge >= k) th = cnd;
     }
     float ss = 0.f;
@@ -338,7 +438,9 @@ __global__ __launch_bounds__(64) void bf3_bound_kernel(const float* __restrict__
         const float c = 1.01f * (0x1p-7f + 0x1p-16f + (float)d * 0x1p-22f);
         const float eps = c * sqrtf(ss) * sqrtf(ymax2[0]);
         // fewer than k rows in sight (or a NaN bound): everything is a candidate
+        // the scan tests "score > thr": thr sits strictly below the bound (one part in 2^22, and past zero)
         float t = (th <= ninf) ? -__builtin_inff() : mf_unorderable(th) - 2.f * eps;
+        t = t - fabsf(t) * 0x1p-22f - 1e-37f;
         if (!(t == t)) t = -__builtin_inff();
         thr[r] = t;
     }
@@ -349,7 +451,7 @@ struct Bf3Final {
     const float* q;
     const float* items;
     int64_t N;
-    int d, k, nchunk;
+    int d, k, nchunk, NT;
     int64_t Qp;
     const uint32_t* lists;
     const int32_t* lcnt;
@@ -359,6 +461,28 @@ struct Bf3Final {
     int64_t* out_idx;
 };
 
+// the canonical chain (mf_dot_chain's order) with up to 128 floats of the row in flight at a time
+template <int D>
+__device__ __forceinline__ float bf3_exact_dot(const float* xq, const float* __restrict__ row) {
+    constexpr int B = D < 128 ? D : 128;
+    float acc = 0.f;
+#pragma unroll
+    for (int g0 = 0; g0 < D; g0 += B) {
+        f32x4 y[B / 4];
+#pragma unroll
+        for (int j = 0; j < B / 4; ++j) y[j] = *reinterpret_cast<const f32x4*>(row + g0 + 4 * j);
+#pragma unroll
+        for (int g = 0; g < B; g += 8)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc = __builtin_fmaf(xq[g0 + g + t], y[g / 4][t], acc);
+                acc = __builtin_fmaf(xq[g0 + g + 4 + t], y[g / 4 + 1][t], acc);
+            }
+    }
+    return acc;
+}
+
+template <int D>
 __global__ __launch_bounds__(64) void bf3_final_kernel(Bf3Final p) {
     __shared__ unsigned long long keys[BF3_CAND];
     __shared__ unsigned long long win[64], sorted[64];
@@ -396,11 +520,13 @@ __global__ __launch_bounds__(64) void bf3_final_kernel(Bf3Final p) {
         // exact rescoring: one candidate per lane and round
         for (int i = lane; i < n; i += 64) {
             const unsigned row = (unsigned)keys[i];
-            const float s = mf_dot_chain(xq, p.items + (int64_t)row * p.d, p.d);
+            const float s = bf3_exact_dot<D>(xq, p.items + (int64_t)row * D);
             keys[i] = mf_key_retrieval(s, row);
         }
         __syncthreads();
-        m = mf_row_topk<BF3_CAND / 64>(keys, n, p.k, win, sorted);
+        if (n <= 64) m = mf_row_topk<1>(keys, n, p.k, win, sorted);
+        else if (n <= 256) m = mf_row_topk<4>(keys, n, p.k, win, sorted);
+        else m = mf_row_topk<BF3_CAND / 64>(keys, n, p.k, win, sorted);
     } else {
         // the whole catalog by the exact chain, 64 rows a round; the winners so far ride along in win[]
         const unsigned long long below = (1ull << lane) - 1ull;
@@ -409,8 +535,8 @@ __global__ __launch_bounds__(64) void bf3_final_kernel(Bf3Final p) {
             const int64_t row = base + lane;
             unsigned long long v0 = 0ull;
             if (row < p.N) {
-                const bool ex = p.exclW && ((p.exclW[(row >> 5) * p.Qp + r] >> (row & 31)) & 1u);
-                if (!ex) v0 = mf_key_retrieval(mf_dot_chain(xq, p.items + row * p.d, p.d), (unsigned)row);
+                const bool ex = p.exclW && ((p.exclW[r * p.NT + (row >> 5)] >> (row & 31)) & 1u);
+                if (!ex) v0 = mf_key_retrieval(bf3_exact_dot<D>(xq, p.items + row * D), (unsigned)row);
             }
             const unsigned long long v1 = lane < carry ? win[lane] : 0ull;
             __syncthreads();
@@ -459,19 +585,32 @@ __global__ __launch_bounds__(64) void bf3_final_kernel(Bf3Final p) {
     }
 }
 
-__global__ __launch_bounds__(256) void bf3_excl_scatter_kernel(const int64_t* __restrict__ excl_off, const int64_t* __restrict__ excl_idx,
-                                                               int64_t idx_base, int64_t N, int64_t Qp, uint32_t* __restrict__ exclW) {
+// one workgroup per query: its exclusion list -> its row of bit words, through an LDS window (no memset, no global atomics)
+static constexpr int BF3_EXCL_WIN = 8192;       // words per window (262,144 catalog rows)
+__global__ __launch_bounds__(256) void bf3_excl_rows_kernel(const int64_t* __restrict__ excl_off, const int64_t* __restrict__ excl_idx,
+                                                            int64_t idx_base, int64_t N, int NT, uint32_t* __restrict__ exclW) {
+    __shared__ uint32_t win[BF3_EXCL_WIN];
     const int64_t r = blockIdx.x;
-    for (int64_t e = excl_off[r] + threadIdx.x; e < excl_off[r + 1]; e += 256) {
-        const int64_t y = excl_idx[e] - idx_base;
-        if (y >= 0 && y < N) atomicOr(&exclW[(y >> 5) * Qp + r], 1u << (y & 31));
+    const int64_t e0 = excl_off[r], e1 = excl_off[r + 1];
+    for (int w0 = 0; w0 < NT; w0 += BF3_EXCL_WIN) {
+        const int nw = min(BF3_EXCL_WIN, NT - w0);
+        for (int i = threadIdx.x; i < nw; i += 256) win[i] = 0u;
+        __syncthreads();
+        for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+            const int64_t y = excl_idx[e] - idx_base;
+            const int64_t wd = (y >> 5) - w0;
+            if (y >= 0 && y < N && wd >= 0 && wd < nw) atomicOr(&win[wd], 1u << (y & 31));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nw; i += 256) exclW[r * NT + w0 + i] = win[i];
+        __syncthreads();
     }
 }
 
-template <int D, int ST, bool EXCL, int PASS>
+template <int D, int ST, int XT, bool EXCL, int PASS>
 static void bf3_launch_scan(const Bf3Plan& pl, const Bf3Scan& sp, hipStream_t s) {
-    auto fn = bf3_scan_kernel<D, ST, EXCL, PASS>;
-    const int bytes = Bf3Lds<D, ST, EXCL>::BYTES;
+    auto fn = bf3_scan_kernel<D, ST, XT, EXCL, PASS>;
+    const int bytes = Bf3Lds<D, ST, XT, EXCL>::BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -479,12 +618,31 @@ static void bf3_launch_scan(const Bf3Plan& pl, const Bf3Scan& sp, hipStream_t s)
     }
     fn<<<dim3((unsigned)pl.nchunk, (unsigned)pl.gy), 256, bytes, s>>>(sp);
 }
-template <int D, int ST>
-static void bf3_run(const Bf3Ws& w, Bf3Scan sp, bool excl, int k, const float* q, const float* ymax2, hipStream_t s) {
-    if (excl) bf3_launch_scan<D, ST, true, 0>(w.plan, sp, s); else bf3_launch_scan<D, ST, false, 0>(w.plan, sp, s);
+template <int D, int ST, int XT>
+static void bf3_run_xt(const Bf3Ws& w, const Bf3Scan& sp, bool excl, int k, const float* q, const float* ymax2, hipStream_t s) {
+    if (excl) bf3_launch_scan<D, ST, XT, true, 0>(w.plan, sp, s); else bf3_launch_scan<D, ST, XT, false, 0>(w.plan, sp, s);
     bf3_bound_kernel<<<dim3((unsigned)sp.Q), 64, 0, s>>>(w.gmax, w.plan.nvals, k, q, D, ymax2, w.thr);
-    if (excl) bf3_launch_scan<D, ST, true, 1>(w.plan, sp, s); else bf3_launch_scan<D, ST, false, 1>(w.plan, sp, s);
+    if (excl) bf3_launch_scan<D, ST, XT, true, 1>(w.plan, sp, s); else bf3_launch_scan<D, ST, XT, false, 1>(w.plan, sp, s);
 }
+template <int D, int ST>
+static void bf3_run(const Bf3Ws& w, const Bf3Scan& sp, bool excl, int k, const float* q, const float* ymax2, hipStream_t s) {
+    if (w.plan.XT == 2) {
+        if constexpr (D <= 128) bf3_run_xt<D, ST, 2>(w, sp, excl, k, q, ymax2, s);
+    } else {
+        bf3_run_xt<D, ST, 1>(w, sp, excl, k, q, ymax2, s);
+    }
+}
+
+#ifdef BF3_PROBE
+extern "C" void mf_probe_bf3(unsigned long long* out16, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(bf3_dbg), 16 * 8);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(bf3_dbg), z, 16 * 8);
+    }
+}
+#endif
 
 extern "C" int mf_topk_bf3(const float* q, int64_t Q, const float* items, const void* index, int64_t N, int d, int k,
                            const int64_t* excl_off, const int64_t* excl_idx, int64_t idx_base, void* ws, size_t ws_bytes,
@@ -499,21 +657,20 @@ extern "C" int mf_topk_bf3(const float* q, int64_t Q, const float* items, const 
     if (ws_bytes < mf_topk_bf3_ws_bytes(Q, N, d, k)) return mf_set_error(MF_ENOSPC, "mf_topk_bf3: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Bf3Ws w = bf3_ws(ws, Q, N, d);
-    if (w.plan.nvals > 64 * BF3_MAXV) return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: catalog too long for the bound kernel");
     if ((uint64_t)w.plan.upc * w.plan.ST * 32 * d * 2 > MF_SRD_MAX_BYTES) return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: chunk beyond 4 GiB");
     Bf3Index ix = bf3_index(const_cast<void*>(index), N, d);
     const bool excl = excl_off != nullptr;
-    if (excl) {
-        (void)hipMemsetAsync(w.exclW, 0, (size_t)w.plan.NT * w.plan.Qp * 4, s);
-        bf3_excl_scatter_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.plan.Qp, w.exclW);
-    }
-    Bf3Scan sp{q, Q, w.plan.Qp, ix.plane, N, w.plan.NT, w.plan.upc, w.plan.gpc, w.plan.nvals, w.exclW, w.gmax, w.thr, w.lists, w.lcnt};
+    if (excl) bf3_excl_rows_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.plan.NT, w.exclW);
+    Bf3Scan sp{q, Q, w.plan.Qp, ix.plane, N, w.plan.NT, w.plan.upc, w.plan.gpc, w.plan.nvals, w.exclW, w.gmax, w.thr, w.lists, w.lcnt,
+               getenv("MF_BF3_ABL") ? atoi(getenv("MF_BF3_ABL")) : 0};
     MF_TIMED("topk_bf3", s, {
         if (d == 64) bf3_run<64, 2>(w, sp, excl, k, q, ix.ymax2, s);
         else if (d == 128) bf3_run<128, 2>(w, sp, excl, k, q, ix.ymax2, s);
         else bf3_run<256, 1>(w, sp, excl, k, q, ix.ymax2, s);
-        Bf3Final fp{q, items, N, d, k, w.plan.nchunk, w.plan.Qp, w.lists, w.lcnt, excl ? w.exclW : nullptr, idx_base, out_scores, out_idx};
-        bf3_final_kernel<<<dim3((unsigned)Q), 64, 0, s>>>(fp);
+        Bf3Final fp{q, items, N, d, k, w.plan.nchunk, w.plan.NT, w.plan.Qp, w.lists, w.lcnt, excl ? w.exclW : nullptr, idx_base, out_scores, out_idx};
+        if (d == 64) bf3_final_kernel<64><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
+        else if (d == 128) bf3_final_kernel<128><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
+        else bf3_final_kernel<256><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
     });
     return mf_check_launch("mf_topk_bf3");
 }

@@ -382,7 +382,7 @@ def test_topk_bf16_prefilter_equals_tile_path(mf, case):
     elif case == "few_rows":
         nq, n, k = 70, 45, 20
     elif case == "d64_excl":
-        nq, n, d, k, base = 130, 30000, 64, 64, 11
+        nq, n, d, k, base = 300, 30000, 64, 64, 11
     elif case == "d256":
         nq, n, d, k = 100, 9000, 256, 10
     q, items = _unit(nq, d, g), _unit(n, d, g)
