@@ -127,4 +127,22 @@ __device__ __forceinline__ float mf_group_sum(float x, int width) {  // width: p
     return x;
 }
 
+// A zero fill as a KERNEL (16-byte aligned pointer, bytes a multiple of 4): inside a captured hipGraph a memset node
+// costs ~100 us per replay on this stack, a kernel node its own few microseconds.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void mf_zero_kernel(uint32_t* __restrict__ p, int64_t n4) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, n16 = n4 >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t q = t; q < n16; q += stride) reinterpret_cast<uint4*>(p)[q] = uint4{0u, 0u, 0u, 0u};
+    if (t < (n4 & 3)) p[n16 * 4 + t] = 0u;
+}
+static inline void mf_zero_async(void* p, size_t bytes, hipStream_t s) {
+    const int64_t n4 = (int64_t)(bytes / 4);
+    if (n4 <= 0) return;
+    int64_t blocks = (n4 / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    mf_zero_kernel<0><<<dim3((unsigned)blocks), 256, 0, s>>>(static_cast<uint32_t*>(p), n4);
+}
+
 #endif  // __HIPCC__

@@ -1362,7 +1362,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
     } else if (scores_needed) {
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
         SelectCommon sc{u, B, v, N, 0, (int)((N + 31) / 32), w.plan.tpc, w.Bp, num_negatives, w.plan.xw, w.gtau, w.priv, w.cand, w.cand_cnt, w.plan.rowcap};
-        (void)hipMemsetAsync(w.gtau, 0, (size_t)((char*)(w.cand_cnt + w.Bp) - (char*)w.gtau), s);
+        mf_zero_async(w.gtau, (size_t)((char*)(w.cand_cnt + w.Bp) - (char*)w.gtau), s);
         MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s))); });
         MinedRowParams mr{w.cand, w.cand_cnt, w.plan.rowcap, num_negatives, u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, B, w.Bp, d,
                           sigma, margin, need, w.sel, w.sel_cnt, w.sel_L, w.stats};
@@ -1372,7 +1372,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
             mask_export_mined_kernel<<<dim3((unsigned)((B + 255) / 256)), 256, 0, s>>>(w.sel, w.sel_cnt, B, (int)((N + 31) / 32), out_mask_bits);
         }
     } else {
-        (void)hipMemsetAsync(w.stats, 0, (size_t)NSTAT * w.Bp * 4, s);
+        mf_zero_async(w.stats, (size_t)NSTAT * w.Bp * 4, s);
     }
     finish_kernel<<<dim3((unsigned)((w.Bp + 63) / 64)), 64, 0, s>>>(w.part, merge_splits, B, w.Bp, w.tgt, w.lii, w.dii,
                                                                                        sigma, kind_mask, w.stats, w.rowloss,
@@ -1399,7 +1399,7 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
             diag_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, grad_out, B, N, w.Bp, du, dv);
         });
     } else if (w.mined) {
-        (void)hipMemsetAsync(w.dvfix, 0, (size_t)N * d * 8, s);
+        mf_zero_async(w.dvfix, (size_t)N * d * 8, s);
         MF_DISPATCH_D(d, {
             const int64_t nthreads = B * 32;
             mined_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, w.sel, w.sel_cnt, w.sel_L, grad_out, B,

@@ -205,7 +205,19 @@ class HipOps:
                                           hyper["eps"], hyper["weight_decay"], ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
 
     def topk(self, queries, items, k, exclude_csr, idx_base):
-        return self.mf.retrieval.ItemIndex(items, idx_base=idx_base).search(queries, k, exclude_csr=exclude_csr)
+        # one ItemIndex per shard tensor: its derived copies (bf16 rows, blocked rows) and workspaces are built once.
+        # Like the reference's index (a table written by get_index), it is a SNAPSHOT: drop_indexes() after the rows change.
+        key = (items.data_ptr(), tuple(items.shape), int(idx_base))
+        cache = self.__dict__.setdefault("_indexes", {})
+        index = cache.get(key)
+        if index is None:
+            if len(cache) >= 4:
+                cache.clear()
+            index = cache[key] = self.mf.retrieval.ItemIndex(items, idx_base=idx_base)
+        return index.search(queries, k, exclude_csr=exclude_csr)
+
+    def drop_indexes(self) -> None:
+        self.__dict__.pop("_indexes", None)
 
     def merge(self, part_scores, part_rows, k):
         return self.mf.retrieval.merge_topk(part_scores, part_rows, k)
@@ -440,6 +452,11 @@ class ShardedIndex:
             ops = HipOps(mf if mf is not None else importlib.import_module(__package__))
         self.ops = ops
         self.comm = comm if comm is not None else default_comm(item_shard.device)
+
+    def refresh(self) -> None:
+        """The shard's rows changed (training went on): rebuild the derived search copies at the next search."""
+        if hasattr(self.ops, "drop_indexes"):
+            self.ops.drop_indexes()
 
     def _localise(self, ids: torch.Tensor) -> torch.Tensor:
         """Global item rows -> rows of this shard (-1: not ours, ignored by the scan)."""

@@ -34,7 +34,9 @@ def _csr(exclude: Sequence[Sequence[int]] | None, q: int, device):
 
 
 class ItemIndex:
-    """Item embeddings ``[N, d]`` (row r = global item row ``idx_base + r``) on one GPU."""
+    """Item embeddings ``[N, d]`` (row r = global item row ``idx_base + r``) on one GPU.  A snapshot, like the table the
+    reference's ``get_index`` writes: the derived copies (``blocked()``, ``bf16_index()``) are built on first use from the
+    rows as they are then -- ``refresh()`` after changing the rows in place."""
 
     def __init__(self, embeddings: torch.Tensor, *, idx_base: int = 0) -> None:
         emb = _lib.dev_f32(embeddings.detach(), "embeddings")
@@ -73,6 +75,10 @@ class ItemIndex:
             _lib.check(lib.mf_topk_bf3_build(self.embeddings.data_ptr(), n, d, out.data_ptr(), out.numel(), _lib.stream_ptr()))
             self._bf16 = out
         return self._bf16
+
+    def refresh(self) -> None:
+        """Forget the derived copies: they are rebuilt from the current rows at the next search."""
+        self._blocked = self._bf16 = None
 
     def _workspace(self, key, nbytes: int) -> torch.Tensor:
         ws = self._ws.get(key)
