@@ -2,7 +2,7 @@
 
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY \
               SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d gpurun_out/pmcS -o r -- python3 bench.py --steps 3 --warmup 1
-    python tools/pmc_sq.py gpurun_out/pmcS/r_results.db > profiles/r01_pmc_sq_summary.json
+    python tools/pmc_sq.py gpurun_out/pmcS/r_results.db > profiles/r02_pmc_sq_summary.json
 
 mfma_pipe_busy_frac = MFMA busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs).
 """
@@ -11,7 +11,8 @@ import sqlite3
 import sys
 
 KEEP = ("loss_fwd_dense_kernel", "loss_bwd_dense_kernel", "select_kernel<", "select_seed_kernel<", "gather_rows_kernel",
-        "update_rows_kernel", "mask_sweep_kernel", "rank_count32_kernel", "hits_kernel", "prep_kernel", "finish_kernel")
+        "update_rows_kernel", "update_fused_kernel", "mask_sweep_kernel", "hits_kernel", "prep_kernel", "finish_kernel",
+        "gt_insert_kernel", "sum_parts_kernel", "bf3_scan_kernel", "bf3_bound_kernel", "bf3_final_kernel")
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection "
                   "group by kernel_name, counter_name").fetchall()
