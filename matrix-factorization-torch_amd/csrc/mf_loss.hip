@@ -171,24 +171,33 @@ __device__ __forceinline__ void fill16(uint4* dst, int64_t n16, unsigned pat, in
     for (int64_t q = tid; q < n16; q += nthreads) dst[q] = v;
 }
 
-// 64-thread workgroups: the per-row chains are serial, so the rows are spread over as many CUs as possible
+// 64-thread workgroups: the per-row chains are serial, so the rows are spread over as many CUs as possible.
+// D = 0: no rows (clears only).  The rows come in batches of 32 floats per operand (16 loads in flight per thread).
+template <int D>
 __global__ __launch_bounds__(64) void prep_kernel(PrepParams p) {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (i < p.Np) {
+    if (D > 0 && i < p.Np) {
         const bool hv = i < p.N, hu = i < p.B;                  // B <= N: a user row always has its item row
         float nvv = 0.f, nuu = 0.f, dot = 0.f;
         if (hv) {
-            const f32x4* pv = reinterpret_cast<const f32x4*>(p.v + i * p.d);
-            const f32x4* pu = reinterpret_cast<const f32x4*>(p.u + (hu ? i : 0) * p.d);
-            for (int g = 0; g < p.d / 8; ++g) {                 // k order of mf_dot_chain
-                const f32x4 a = pv[2 * g], b = pv[2 * g + 1];
-                f32x4 ua = {0.f, 0.f, 0.f, 0.f}, ub = ua;
-                if (hu) { ua = pu[2 * g]; ub = pu[2 * g + 1]; }
+            const f32x4* pv = reinterpret_cast<const f32x4*>(p.v + i * D);
+            const f32x4* pu = reinterpret_cast<const f32x4*>(p.u + (hu ? i : 0) * D);     // (no user: row 0 is read and dropped)
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    nvv = __builtin_fmaf(a[t], a[t], nvv);  nvv = __builtin_fmaf(b[t], b[t], nvv);
-                    nuu = __builtin_fmaf(ua[t], ua[t], nuu); nuu = __builtin_fmaf(ub[t], ub[t], nuu);
-                    dot = __builtin_fmaf(ua[t], a[t], dot);  dot = __builtin_fmaf(ub[t], b[t], dot);
+            for (int g0 = 0; g0 < D / 8; g0 += 4) {
+                f32x4 va[8], ua[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { va[j] = pv[2 * g0 + j]; ua[j] = pu[2 * g0 + j]; }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {                   // k order of mf_dot_chain
+                    const f32x4 a = va[2 * g], b = va[2 * g + 1];
+                    const f32x4 xa = hu ? ua[2 * g] : zero4, xb = hu ? ua[2 * g + 1] : zero4;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        nvv = __builtin_fmaf(a[t], a[t], nvv);  nvv = __builtin_fmaf(b[t], b[t], nvv);
+                        nuu = __builtin_fmaf(xa[t], xa[t], nuu); nuu = __builtin_fmaf(xb[t], xb[t], nuu);
+                        dot = __builtin_fmaf(xa[t], a[t], dot);  dot = __builtin_fmaf(xb[t], b[t], dot);
+                    }
                 }
             }
         }
@@ -1295,7 +1304,7 @@ extern "C" int mf_loss_masks(int64_t B, int64_t N, int d, int P, int num_negativ
     pp.ubits = reinterpret_cast<uint4*>(w.ubits); pp.ubits16 = (int64_t)w.NT * w.Bp * 4 / 16;
     pp.ticket = w.ticket;
     const int64_t want = (pp.ubits16 + 64 * 8 - 1) / (64 * 8);
-    prep_kernel<<<dim3((unsigned)(want < 8192 ? (want > 0 ? want : 1) : 8192)), 64, 0, s>>>(pp);   // Np = 0: clears only
+    prep_kernel<0><<<dim3((unsigned)(want < 8192 ? (want > 0 ? want : 1) : 8192)), 64, 0, s>>>(pp);   // clears only
     build_masks(w, item_idx, pos_idx, B, N, P, s);
     return mf_check_launch("mf_loss_masks");
 }
@@ -1333,7 +1342,7 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
             const int64_t want = (pp.ubits16 + 64 * 8 - 1) / (64 * 8);       // ~8 stores per thread
             if (want > nb) nb = (int)(want < 8192 ? want : 8192);
         }
-        prep_kernel<<<dim3((unsigned)nb), 64, 0, s>>>(pp);
+        MF_DISPATCH_D(d, { prep_kernel<D><<<dim3((unsigned)nb), 64, 0, s>>>(pp); });
     }
     if (scores_needed && !masks_ready) build_masks(w, item_idx, pos_idx, B, N, P, s);
     // logq is read by whole float4s up to the padded width: prep_kernel keeps a zero-padded copy in ws
