@@ -381,14 +381,14 @@ def topk_small_leg(mf, lib, index, device, dim: int, rank: int) -> dict:
         off = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).to(device)
         ids = torch.randint(1, index.num_items, (int(lens.sum()),), generator=g).to(device)
         for _ in range(50):
-            index.search(queries, TOP_K, exclude_csr=(off, ids))
+            index.search(queries, TOP_K, exclude_csr=(off, ids), path="scan")
         torch.cuda.synchronize()
         lib.mf_timing_reset()
         lib.mf_timing_enable(1)
         reps = 300
         t0 = time.perf_counter()
         for _ in range(reps):
-            index.search(queries, TOP_K, exclude_csr=(off, ids))
+            index.search(queries, TOP_K, exclude_csr=(off, ids), path="scan")
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / reps
         lib.mf_timing_enable(0)
@@ -397,6 +397,15 @@ def topk_small_leg(mf, lib, index, device, dim: int, rank: int) -> dict:
         out[f"q{q}"] = {"latency_us": round(us, 2), "wall_us_per_call": round(wall * 1e6, 1), "queries_per_s": round(q / wall, 1),
                         "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK_HBM_GBS, 4), "frac_of_6.3TBps_achievable": round(gbs / 6300.0, 4),
                         "kernels": "topk_small_scan_kernel + topk_small_select_kernel", "bound": "hbm"}
+    # the same 8 queries through what "auto" picks from 5 queries on (the bf16 prefilter: four launches)
+    for _ in range(50):
+        index.search(queries, TOP_K, exclude_csr=(off, ids))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        index.search(queries, TOP_K, exclude_csr=(off, ids))
+    torch.cuda.synchronize()
+    out["q8_auto_bf16_prefilter"] = {"wall_us_per_call": round((time.perf_counter() - t0) / 300 * 1e6, 1)}
     return out
 
 

@@ -51,7 +51,9 @@ class ItemIndex:
         self._ws: dict = {}                              # search workspaces, kept between calls
 
     SMALL_Q = 32       # at most this many queries can take the bandwidth-bound matrix-vector path (mf_topk_small)
-    AUTO_SMALL_Q = 16  # "auto" uses it up to here (measured at N = 62,423, d = 128: 17 / 26 / 40 / 107 us at Q = 1 / 4 / 8 / 32)
+    # "auto" (measured at N = 62,423, d = 128, us per call): scan 17 / 26 / 40 / 107 at Q = 1 / 4 / 8 / 32; bf16 prefilter
+    # 31 / 33 / 37 / 51 / 76 at Q = 32 / 64 / 256 / 512 / 1024 (four launches: ~30 us floor); fp32 tiles 95 / 86 / 98 / 133 / 219
+    AUTO_SMALL_Q = 4   # scan up to here, then the bf16 prefilter (d >= 64), else the fp32 tile engine
 
     def blocked(self) -> torch.Tensor:
         """The catalog in the blocked layout of ``mf_topk_small`` (``[64-row block][chunk][row]``), built once."""
@@ -63,8 +65,8 @@ class ItemIndex:
             self._blocked = out
         return self._blocked
 
-    BF16_MIN_Q = 64    # "auto" takes the bf16-prefilter path from here (and d >= 64, N >= BF16_MIN_N)
-    BF16_MIN_N = 8192
+    BF16_MIN_Q = 5     # "auto" takes the bf16-prefilter path from here (and d >= 64, N >= BF16_MIN_N)
+    BF16_MIN_N = 2048
 
     def bf16_index(self) -> torch.Tensor:
         """bf16 rows + the largest row norm, the prefilter index of ``mf_topk_bf3``; built once."""
