@@ -25,7 +25,6 @@
 
 static constexpr int SQ_MAXQ = 32;       // queries per call
 static constexpr int SQ_NW = 4;          // waves per workgroup (each takes one 64-row block per pass)
-static constexpr int SQ_MERGE_WAVES = 16;
 
 // ------------------------------------------------------------- blocked catalog ---
 template <int D>
@@ -223,105 +222,150 @@ __global__ __launch_bounds__(64 * SQ_NW) void topk_small_scan_kernel(SmallParams
     }
 }
 
-// Launch 2, one 1024-thread workgroup per query.  (a) the k best of the block maxima (sixteen waves in parallel, then
-// two merge levels): only those <= k blocks can hold a row of the top k, and the k-th of them is a lower bound of the
-// k-th best key.  (b) their <= 64 k scores are turned back into keys and filtered against that bound.  (c) one wave
-// selects the k best candidates, orders them by rank counting and writes scores / rows.
-template <int KPL>
-__global__ __launch_bounds__(64 * SQ_MERGE_WAVES) void topk_small_select_kernel(const float* __restrict__ scores,
-                                                                               const unsigned long long* __restrict__ wmax,
-                                                                               int64_t nblocks, int k, int64_t idx_base,
-                                                                               float* __restrict__ out_scores,
-                                                                               int64_t* __restrict__ out_idx) {
-    __shared__ unsigned long long win[SQ_MERGE_WAVES][64];
-    __shared__ int win_n[SQ_MERGE_WAVES];
-    __shared__ unsigned long long mid[4][64];
-    __shared__ int mid_n[4];
-    __shared__ unsigned long long top[64];       // the k best block maxima
-    __shared__ unsigned long long cand[64 * 64];
-    __shared__ int cand_n, top_n;
+// Launch 2, one 256-thread workgroup per query.  (a) wave 0 reduces the block maxima to two per lane and takes the k-th
+// largest of those 128 keys as the bound tau: a lower bound of the k-th best key (they are keys of distinct rows), at
+// most a few ranks below the exact k-th largest maximum.  (b) only blocks whose maximum reaches tau can hold a row of
+// the top k: their scores are turned back into keys and filtered against tau, 64 blocks a round.  (c) wave 0 selects
+// the k best candidates (the winners so far riding along between rounds), orders them by rank counting and writes
+// scores / rows.  One search where the first version ran four (three merge levels of exact block selection).
+static constexpr int SQ_SEL_WAVES = 4;
+static constexpr int SQ_ROUND_BLOCKS = 64;      // winning blocks per round: <= 4096 candidates in LDS
+
+__global__ __launch_bounds__(64 * SQ_SEL_WAVES) void topk_small_select_kernel(const float* __restrict__ scores,
+                                                                              const unsigned long long* __restrict__ wmax,
+                                                                              int64_t nblocks, int k, int64_t idx_base,
+                                                                              float* __restrict__ out_scores,
+                                                                              int64_t* __restrict__ out_idx) {
+    __shared__ unsigned long long top[64];       // the winners so far
+    __shared__ unsigned long long two[64];
+    __shared__ unsigned long long cand[SQ_ROUND_BLOCKS * 64];
+    __shared__ int wlist[SQ_ROUND_BLOCKS];
+    __shared__ int cand_n, wl_n, top_m;
     __shared__ unsigned long long tau_s;
     const int lane = mf_lane(), wave = mf_wave_id();
     const int64_t q = blockIdx.x;
     const unsigned long long* src = wmax + q * nblocks;
-    if (threadIdx.x == 0) cand_n = 0;
-    // (a) level 0: every wave reduces its batches of 64 KPL block maxima, winners riding along
-    int carry = 0;
-    for (int64_t base = (int64_t)wave * 64 * KPL; base < nblocks; base += (int64_t)SQ_MERGE_WAVES * 64 * KPL) {
-        unsigned long long v[KPL + 1];
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-            const int64_t idx = base + lane + 64 * j;
-            v[j] = idx < nblocks ? src[idx] : 0ull;
-        }
-        v[KPL] = lane < carry ? win[wave][lane] : 0ull;
-        mf_wave_sync();
-        carry = sq_wave_topk<KPL + 1>(v, k, win[wave]);
-    }
-    if (lane == 0) win_n[wave] = carry;
-    __syncthreads();
-    // level 1: waves 0..3 merge four lists each; level 2: wave 0 merges those four
-    if (wave < 4) {
-        unsigned long long v[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) v[w] = lane < win_n[4 * wave + w] ? win[4 * wave + w][lane] : 0ull;
-        const int m = sq_wave_topk<4>(v, k, mid[wave]);
-        if (lane == 0) mid_n[wave] = m;
-    }
+    if (threadIdx.x == 0) { wl_n = 0; cand_n = 0; top_m = 0; }
     __syncthreads();
     if (wave == 0) {
-        unsigned long long v[4];
+        // (a) two best maxima per lane; the maxima of 1024 blocks (16 per lane) are in flight at once, and stay in
+        // registers for the list of winning blocks when the catalog has no more than that
+        unsigned long long m1 = 0ull, m2 = 0ull;
+        unsigned long long v[16];
+        for (int64_t base = 0; base < nblocks; base += 64 * 16) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v[w] = lane < mid_n[w] ? mid[w][lane] : 0ull;
-        const int m = sq_wave_topk<4>(v, k, top);
+            for (int j = 0; j < 16; ++j) {
+                const int64_t idx = base + lane + 64 * j;
+                v[j] = idx < nblocks ? src[idx] : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const unsigned long long lo = v[j] < m1 ? v[j] : m1;
+                m2 = lo > m2 ? lo : m2;
+                m1 = v[j] > m1 ? v[j] : m1;
+            }
+        }
+        const unsigned long long v2[2] = {m1, m2};
+        const int m = sq_wave_topk<2>(v2, k, two);
         mf_wave_sync();
-        // the bound: the smallest of the k winners when there are k of them, else every key passes
-        unsigned long long mn = lane < m ? top[lane] : ~0ull;
+        unsigned long long mn = lane < m ? two[lane] : ~0ull;
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) {
             const unsigned long long o = mf_shfl_xor_u64(mn, s);
             mn = o < mn ? o : mn;
         }
-        if (lane == 0) { top_n = m; tau_s = m >= k ? mn : 1ull; }
-    }
-    __syncthreads();
-    // (b) the rows of the winning blocks that reach the bound
-    const int m_top = top_n;
-    const unsigned long long tau = tau_s;
-    for (int t = wave; t < m_top; t += SQ_MERGE_WAVES) {
-        const int64_t blk = (int64_t)(mf_key_retrieval_col(top[t]) >> 6);
-        const int64_t row = blk * 64 + lane;
-        const float sc = scores[(size_t)q * nblocks * 64 + row];
-        const unsigned long long key = __builtin_bit_cast(unsigned, sc) == SQ_NOKEY ? 0ull : mf_key_retrieval(sc, (unsigned)row);
-        const bool keep = key != 0ull && key >= tau;
-        const unsigned long long mk = __ballot(keep);
-        int base = 0;
-        if (lane == 0 && mk) base = atomicAdd(&cand_n, __popcll(mk));
-        base = __shfl(base, 0, 64);
-        if (keep) cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = key;
-    }
-    __syncthreads();
-    // (c) final selection by wave 0
-    if (wave != 0) return;
-    const int C = cand_n;
-    int m = 0;
-    if (C <= 64) {
-        const unsigned long long v[1] = {lane < C ? cand[lane] : 0ull};
-        mf_wave_sync();
-        m = sq_wave_topk<1>(v, k, top);
-    } else {
-        int car = 0;
-        for (int base = 0; base < C; base += 64 * 4) {
-            unsigned long long v[5];
+        const unsigned long long tau0 = m >= k ? mn : 1ull;          // fewer than k maxima: every key passes
+        if (lane == 0) tau_s = tau0;
+        // the winning blocks (about k of them), by the same wave: no second trip to memory for a catalog of <= 1024 blocks
+        for (int64_t base = 0; base < nblocks; base += 64 * 16) {
+            if (nblocks > 64 * 16) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = base + lane + 64 * j < C ? cand[base + lane + 64 * j] : 0ull;
-            v[4] = lane < car ? top[lane] : 0ull;
-            mf_wave_sync();
-            car = sq_wave_topk<5>(v, k, top);
+                for (int j = 0; j < 16; ++j) {
+                    const int64_t idx = base + lane + 64 * j;
+                    v[j] = idx < nblocks ? src[idx] : 0ull;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool hit = v[j] != 0ull && v[j] >= tau0;
+                const unsigned long long bal = __ballot(hit);
+                if (bal) {
+                    int at = 0;
+                    if (lane == 0) at = atomicAdd(&wl_n, __popcll(bal));
+                    at = __shfl(at, 0, 64) + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (hit && at < SQ_ROUND_BLOCKS) wlist[at] = (int)(base + lane + 64 * j);
+                }
+            }
         }
-        m = car;
     }
-    mf_wave_sync();
+    __syncthreads();
+    const unsigned long long tau = tau_s;
+    // (b) + (c) for the W blocks in wlist: candidates into LDS, wave 0 merges them into the winners so far
+    auto round = [&](int W) {
+        for (int t = wave; t < W; t += SQ_SEL_WAVES) {
+            const int64_t row = (int64_t)wlist[t] * 64 + lane;
+            const float sc = scores[(size_t)q * nblocks * 64 + row];
+            const unsigned long long key = __builtin_bit_cast(unsigned, sc) == SQ_NOKEY ? 0ull : mf_key_retrieval(sc, (unsigned)row);
+            const bool keep = key != 0ull && key >= tau;
+            const unsigned long long mk = __ballot(keep);
+            int base = 0;
+            if (lane == 0 && mk) base = atomicAdd(&cand_n, __popcll(mk));
+            base = __shfl(base, 0, 64);
+            if (keep) cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = key;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int C = cand_n;
+            int car = top_m;
+            if (C <= 64 && car == 0) {              // the usual case: one key per lane, one search
+                const unsigned long long v1[1] = {lane < C ? cand[lane] : 0ull};
+                mf_wave_sync();
+                car = sq_wave_topk<1>(v1, k, top);
+                mf_wave_sync();
+            } else
+            for (int base = 0; base < C; base += 64 * 4) {
+                unsigned long long v[5];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = base + lane + 64 * j < C ? cand[base + lane + 64 * j] : 0ull;
+                v[4] = lane < car ? top[lane] : 0ull;
+                mf_wave_sync();
+                car = sq_wave_topk<5>(v, k, top);
+                mf_wave_sync();
+            }
+            if (lane == 0) { top_m = car; cand_n = 0; }
+        }
+        __syncthreads();
+    };
+    auto hit_of = [&](int64_t blk) { return blk < nblocks && src[blk] >= tau && src[blk] != 0ull; };
+    const int Wt = wl_n;
+    if (Wt <= SQ_ROUND_BLOCKS) {
+        round(Wt);
+    } else {
+        // (maxima piled up in a few lanes' shares, or thousands of tied rows) SQ_ROUND_BLOCKS blocks a round, in block
+        // order: a block's position among the hits by ballot prefix sums
+        __shared__ int wtot[SQ_SEL_WAVES];
+        for (int lo = 0; lo < Wt; lo += SQ_ROUND_BLOCKS) {
+            int running = 0;
+            for (int64_t base = 0; base < nblocks; base += 64 * SQ_SEL_WAVES) {
+                const int64_t blk = base + threadIdx.x;
+                const bool hit = hit_of(blk);
+                const unsigned long long bal = __ballot(hit);
+                if (lane == 0) wtot[wave] = __popcll(bal);
+                __syncthreads();
+                int off = running + __popcll(bal & ((1ull << lane) - 1ull)), tot = 0;
+                for (int w = 0; w < SQ_SEL_WAVES; ++w) {
+                    if (w < wave) off += wtot[w];
+                    tot += wtot[w];
+                }
+                if (hit && off >= lo && off < lo + SQ_ROUND_BLOCKS) wlist[off - lo] = (int)blk;
+                running += tot;
+                __syncthreads();
+            }
+            round(min(SQ_ROUND_BLOCKS, Wt - lo));
+        }
+    }
+    if (wave != 0) return;
+    const int m = top_m;
     const unsigned long long mine = lane < m ? top[lane] : 0ull;
     int r = 0;
     for (int t = 0; t < m; ++t) r += top[t] > mine ? 1 : 0;
@@ -387,10 +431,7 @@ extern "C" int mf_topk_small(const float* q, int64_t Q, const float* blocked, in
             if (Q == 1) launch_small<D, 1>(sp, grid, s);
             else if (Q <= 4) launch_small<D, 4>(sp, grid, s);
             else launch_small<D, 8>(sp, grid, s);
-            if (nblocks <= 64 * SQ_MERGE_WAVES)
-                topk_small_select_kernel<1><<<dim3((unsigned)Q), 64 * SQ_MERGE_WAVES, 0, s>>>(w.scores, w.wmax, nblocks, k, idx_base, out_scores, out_idx);
-            else
-                topk_small_select_kernel<8><<<dim3((unsigned)Q), 64 * SQ_MERGE_WAVES, 0, s>>>(w.scores, w.wmax, nblocks, k, idx_base, out_scores, out_idx);
+            topk_small_select_kernel<<<dim3((unsigned)Q), 64 * SQ_SEL_WAVES, 0, s>>>(w.scores, w.wmax, nblocks, k, idx_base, out_scores, out_idx);
         });
     });
     return mf_check_launch("mf_topk_small");

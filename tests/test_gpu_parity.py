@@ -366,6 +366,27 @@ def test_topk_bit_exact(mf, cfg):
         assert np.array_equal(s.cpu().numpy().view(np.uint32), ws.view(np.uint32)), path
 
 
+@pytest.mark.parametrize("case", ["zero_query", "maxima_piled_in_one_lane_share", "k64_many_blocks"])
+def test_topk_scan_path_hard_cases(mf, case):
+    """The small-batch selection takes its bound from two block maxima per lane: inputs where that bound is weak (every
+    score equal; the best rows all in blocks 0, 64, 128, ... -- one lane's share -- so that nearly every block passes
+    it and the selection runs in rounds) must still give the tile engine's bits."""
+    g = torch.Generator().manual_seed(3)
+    n, d, k = 62423, 64, 64
+    items = 0.01 * _unit(n, d, g)
+    q = _unit(2, d, g)
+    if case == "zero_query":
+        q[0] = 0.0
+    elif case == "maxima_piled_in_one_lane_share":
+        for b in range(0, 976, 64):
+            items[b * 64: b * 64 + 8] = q[0] * torch.linspace(0.5, 1.0, 8)[:, None] + 0.001 * torch.randn(8, d, generator=g)
+    index = mf.retrieval.ItemIndex(items.to(DEV))
+    st, it = index.search(q.to(DEV), k, path="tiles")
+    ss, is_ = index.search(q.to(DEV), k, path="scan")
+    assert torch.equal(it, is_)
+    assert torch.equal(st.view(torch.int32), ss.view(torch.int32))
+
+
 @pytest.mark.parametrize("case", ["random_1024", "zero_query_and_duplicates", "best_rows_in_one_group", "near_ties", "unnormalised",
                                   "few_rows", "d64_excl", "d256"])
 def test_topk_bf16_prefilter_equals_tile_path(mf, case):
