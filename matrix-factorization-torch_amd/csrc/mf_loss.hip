@@ -736,14 +736,15 @@ __global__ __launch_bounds__(64) void finish_kernel(const float* __restrict__ pa
         for (int w = 32; w > 0; w >>= 1) v += __shfl_xor(v, w, 64);
         if (lane == 0) blockpart[(int64_t)k * gridDim.x + blockIdx.x] = v;
     }
-    __threadfence();
+    // release only (the block sums are in L2 before the ticket moves): a full fence also invalidates the L1, ~1.7 us each;
+    // the last workgroup reads the sums with L1-bypassing loads instead of an acquire fence
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     int last = 0;
     if (lane == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     last = __shfl(last, 0, 64);
     if (last) {
         // the last workgroup adds the block sums of every loss kind: lane-strided partial sums, then a fixed
         // xor tree -- the same order on every run
-        __threadfence();
         float tot[MF_NUM_KINDS];
 #pragma unroll
         for (int k = 0; k < MF_NUM_KINDS; ++k) tot[k] = 0.f;
