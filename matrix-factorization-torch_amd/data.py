@@ -46,7 +46,7 @@ class InteractionBatchType(TypedDict):
 def pad_tensors(batch: Iterable[torch.Tensor], dim: int = -1, *, pad_start: bool = False,
                 pad_value: int = PADDING_IDX) -> torch.Tensor:
     """Stack ragged tensors, padding ``dim`` to the longest (same contract as load.py:38-55,
-    whose 12 shape cases are replayed in tests/test_data.py)."""
+    whose 12 shape cases are replayed in tests/test_host_cpu.py)."""
     tensors = list(batch)
     size = max(t.size(dim) for t in tensors)
     nd = tensors[0].dim()

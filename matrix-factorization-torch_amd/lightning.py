@@ -12,8 +12,10 @@ Differences, all dictated by the north-star: towers are embedding tables indexed
 the optimiser is a sparse row optimiser, retrieval is exact brute force.  The class
 derives from ``lightning.LightningModule`` when Lightning is installed (it is not in the
 build image) and from ``torch.nn.Module`` otherwise, so ``Trainer.fit`` can drive it
-unchanged where Lightning exists.  Metrics, callbacks, loggers, CLI and ``save`` are the
-reference's control plane and stay out of scope.
+unchanged where Lightning exists.  The retrieval metrics (``validation_step`` / ``test_step`` /
+``predict_step``, on the device), ``save`` / ``load`` and the two id-based serving entry points ARE
+implemented; callbacks, loggers and the CLI are the reference's control
+plane and stay out of scope.
 """
 from __future__ import annotations
 

@@ -15,7 +15,13 @@ Pinning status (see DESIGN.md "Oracle"):
     against ``tests/golden/*.npz``, vectors produced in the build container by
     importing the reference's own ``xfmr_rec/losses.py``
     (``tests/golden/make_golden.py``).
-  * embedding tower, SGD / Adam row update, logQ correction, brute-force top-k,
-    sharded merge: the reference has no implementation of these,
-    so these restatements are OUR spec -- **parity unpinned**.
+  * embedding tower, SGD / Adam row update, brute-force top-k, retrieval metrics, the two key
+    orders, the MovieLens split / history logic: the reference has no implementation of these
+    (SURVEY.md 0.3), so they are pinned against THIRD-PARTY definitions instead
+    (``tests/test_oracle_pins.py``, ``tests/test_host_cpu.py``: torch.optim.SGD / AdamW on the
+    touched rows, F.embedding + F.normalize, fp64 matmul + stable sort, hand-worked
+    torchmetrics-formula cases, an independent restatement of the key orders and of the polars
+    expressions).
+  * still OUR spec (**parity unpinned**): the logQ correction, the hash towers' combination
+    rule, the sharded merge, the batch producer's shuffle, ``init_rows``.
 """

@@ -10,7 +10,8 @@
  * xfmr_rec/data/lightning.py:237-259 (cosine score of a unit-norm query against
  * unit-norm item rows == their dot product; exclusion prefilter; top-k desc).
  * The reference's own retrieval is LanceDB ANN (absent here, approximate), so the
- * exact brute-force order below is OUR spec -- "parity unpinned" for top-k.
+ * exact brute-force order below is OUR spec; it is pinned against fp64 matmul + stable
+ * sort and an independent restatement of the key order in tests/test_oracle_pins.py.
  *
  * Built by oracle/Makefile into oracle/_build/liborc.so; only tests/, smoke()
  * and bench.py's cpu_baseline leg may load it.

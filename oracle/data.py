@@ -2,7 +2,9 @@
 ``mf_sample_batch``, csrc/mf_data.hip).  **Parity unpinned**: the reference assembles batches with a
 host datapipe (xfmr_rec/data/lightning.py:311-363) whose shuffle order is torch's; only the batch
 LAYOUT is the reference's (InteractionBatchType, data/lightning.py:72-76; 0-padding of ``pos_idx``,
-data/load.py:38-55).  Exact integer arithmetic in Python ints.
+data/load.py:38-55).  Exact integer arithmetic in Python ints.  ``split_ratings`` / ``rolling_history`` restate the
+polars expressions of data/prepare.py:160-194 / :229-243 on ids only and ARE pinned: tests/test_host_cpu.py checks them
+against a plain-Python restatement of the same expressions (rank("min") semantics, 4-week window).
 """
 from __future__ import annotations
 

@@ -1,9 +1,13 @@
 """CPU restatement of the embedding-table tower and its row updates
-(TEST INFRASTRUCTURE).  **Parity unpinned**: the reference's tower is a BERT text
+(TEST INFRASTRUCTURE).  The reference's tower is a BERT text
 encoder ending in L2-normalisation (xfmr_rec/models.py:42-63) and its optimiser is
 dense ``torch.optim.AdamW`` (xfmr_rec/lightning.py:238-239); embedding tables, SGD
 and row-wise (lazy) Adam are the north-star's replacement and have no reference
-implementation, so this file is our spec in plain torch ops.
+implementation.  Pinned on CPU against third-party definitions
+(tests/test_oracle_pins.py): ``gather`` == F.embedding + F.normalize, ``sgd_update`` /
+``adam_update`` == torch.optim.SGD / AdamW restricted to the touched rows (duplicates summed,
+weight decay, several steps).  **Parity unpinned** for the hash towers' combination rule and
+``init_rows`` (our spec).
 """
 from __future__ import annotations
 

@@ -5,8 +5,9 @@ Follows the *semantics* of ``ItemProcessor.search``
 indexed item (embeddings are unit-norm, so score = dot = 1 - cosine distance),
 prefilter ``NOT IN (exclude)``, best ``top_k`` first.  The reference delegates the
 arithmetic to LanceDB's approximate IVF_HNSW_PQ index (absent here), so the exact
-order -- score descending, item row index ascending -- is OUR spec:
-**parity unpinned**.
+order -- score descending, item row index ascending -- is OUR spec; it is pinned on CPU
+against fp64 ``q @ E.T`` + a stable sort on tie-free data and on constructed ties
+(tests/test_oracle_pins.py).
 """
 from __future__ import annotations
 
@@ -62,7 +63,8 @@ def retrieval_metrics(topk_idx, targets, k: int) -> np.ndarray:
     order among them gives the same @k values once k items were retrieved); relevance = rating,
     binary relevance = rating > 0 except for NDCG.  Formulas: torchmetrics 1.8 functional
     ``retrieval_normalized_dcg / recall / precision / average_precision / hit_rate /
-    reciprocal_rank`` with ``top_k=k`` (torchmetrics is not installed here: **parity unpinned**),
+    reciprocal_rank`` with ``top_k=k`` (torchmetrics is not installed here; pinned by hand-worked cases of those
+    formulas -- fewer than k retrieved, rating-0 targets -- in tests/test_oracle_pins.py),
     empty-target queries score 0 (``empty_target_action="neg"``).
     ``targets``: per query a dict item id -> rating."""
     out = np.zeros((len(targets), 6), dtype=np.float64)
