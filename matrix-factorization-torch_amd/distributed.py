@@ -124,8 +124,44 @@ class RcclComm:
 
 
 def default_comm(device):
-    """RCCL on the compute stream for GPU tensors, torch.distributed otherwise."""
-    return RcclComm(device) if torch.device(device).type == "cuda" else TorchComm()
+    """RCCL on the compute stream for GPU tensors (``RcclComm``), ``torch.distributed`` otherwise.
+
+    The C-side communicator has only ever run on ONE rank where this was built (one GPU per box), so at world > 1 it is
+    checked before it is trusted: every rank exchanges a small all-to-all and an all-gather through it and compares with
+    ``torch.distributed``'s answer; unless ALL ranks agree the job uses ``TorchComm`` -- the same RCCL collectives issued by
+    torch, a few cross-stream joins slower, never a CPU path.  ``MF_COMM=rccl`` / ``torch`` forces one or the other."""
+    import os
+    import warnings
+
+    if torch.device(device).type != "cuda":
+        return TorchComm()
+    mode = os.environ.get("MF_COMM", "auto")
+    if mode == "torch":
+        return TorchComm()
+    if mode == "rccl" or dist.get_world_size() == 1:
+        return RcclComm(device)
+    ok, comm, why = 1, None, ""
+    try:
+        comm = RcclComm(device)
+        w, r = comm.world, comm.rank
+        ref = TorchComm()
+        send = torch.arange(w, dtype=torch.int64, device=device) * 1000 + r
+        counts = [(r + j) % 3 + 1 for j in range(w)]                        # rows this rank sends to rank j
+        recv_counts = [(j + r) % 3 + 1 for j in range(w)]                   # rows rank j sends here
+        rows = torch.arange(sum(counts) * 4, dtype=torch.float32, device=device).reshape(-1, 4) + 100.0 * r
+        same = (torch.equal(comm.counts(send), ref.counts(send)) and torch.equal(comm.gather(send), ref.gather(send))
+                and torch.equal(comm.rows(rows, counts, recv_counts), ref.rows(rows, counts, recv_counts)))
+        if not same:
+            ok, why = 0, "self-test mismatch"
+    except Exception as e:  # noqa: BLE001  (whatever the C side or RCCL raised: fall back together)
+        ok, why = 0, repr(e)
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return comm
+    warnings.warn(f"RcclComm not used ({why or 'another rank failed its self-test'}); falling back to torch.distributed collectives",
+                  stacklevel=2)
+    return TorchComm()
 
 
 # ----------------------------------------------------------------------- local compute ---
