@@ -966,11 +966,11 @@ struct BwdParams {
 template <int D, bool XU>
 struct BwdLds {
     using G = TileGeom<D>;
-    // Two schedules (see the kernel): SPREAD for long tiles (d >= 128) -- 2-slot tile ring, the wave's own
+    // Two schedules (see the kernel): SPREAD for long tiles (d >= 64) -- 2-slot tile ring, the wave's own
     // 4 KiB stash / G' block comes straight into registers (it is wave-private: routing it through LDS
     // only added 16 KiB of DMA writes and 16 KiB of reads per tile to an LDS port that the MFMA operand
     // reads need); otherwise whole stages two tiles ahead, stash blocks behind the tile in each slot.
-    static constexpr bool SPREAD = D >= 128;
+    static constexpr bool SPREAD = D >= 64;
     static constexpr int LT = G::TILEB;                  // (not SPREAD) NW x 4 KiB stash blocks behind the tile
     static constexpr int SLOT = G::TILEB + (SPREAD ? 0 : G::NW * 4096);
     static constexpr int EXTRA = XU ? 0 : G::NW * 32 * 32 * 4;   // dV: per-wave 32 x 32 transpose scratch (XOR-swizzled)
@@ -985,7 +985,7 @@ struct BwdLds {
 // XU = true : lanes hold users, item tiles stream, result d loss / d u   (reads L, writes G' back)
 // XU = false: lanes hold items, user tiles stream, result d loss / d v   (reads G')
 template <int D, bool XU, int GMODE>
-__global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss_bwd_dense_kernel(BwdParams p) {
+__global__ __launch_bounds__(64 * mf_nw(D), (D == 128 || D == 64) ? BWD_MIN_WG : 1) void loss_bwd_dense_kernel(BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using L = BwdLds<D, XU>;
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), D == 128 ? BWD_MIN_WG : 1) void loss
 #pragma unroll
         for (int j = 0; j < L::NDMA; ++j) stage_piece(t, slot_idx, j);
     };
-    // Two schedules.  SPREAD (2-slot ring, d >= 128): the loads of tile ty+1 are issued ONE PER MFMA STEP
+    // Two schedules.  SPREAD (2-slot ring, d >= 64): the loads of tile ty+1 are issued ONE PER MFMA STEP
     // inside the contraction of tile ty, the tile pieces into the slot tile ty-1 left; no second barrier.
     // Otherwise (3 slots, short tiles): whole stages, two tiles ahead.
     if (t0 < t1) stage(t0, 0);
