@@ -14,6 +14,10 @@
 //   F_NOLDS    A fragments read once, reused                   (wrong results: prices the LDS reads)
 //   F_MIDBAR   wait + barrier + DMA issue in the MIDDLE of a tile's MFMAs (correct results)
 //   F_STAMP    s_memtime stamps: wait / barrier / DMA issue / MFMA share of a tile (diagnostic build)
+//   F_BF3      the contraction as THREE v_mfma_f32_32x32x16_bf16 per 16 k (hi.hi + lo.hi + hi.lo of a split-bf16 pair:
+//              24 MFMAs of 32 cycles per tile instead of 64 of 64; same LDS bytes; operand bits are whatever the fp32
+//              data holds -- timing only, no check).  NV / NE then count per bf16 MFMA: 11 / 1 give the forward's
+//              ~260 VALU + 16 exp per tile.  Prices what a split-bf16 training sweep could reach
 // Output per variant: median ms over interleaved rounds, TFLOP/s, fraction of 157.3, the in-kernel clock
 // (s_memtime / s_memrealtime), and for the correct variants a check against a host reference.
 //
@@ -35,7 +39,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
 
 static constexpr int D = 128, ROWB = D * 4, NW = 4;
-enum { F_NODMA = 1, F_NOBAR = 2, F_NOLDS = 4, F_MIDBAR = 8, F_STAMP = 16, F_EPI = 32 };
+enum { F_NODMA = 1, F_NOBAR = 2, F_NOLDS = 4, F_MIDBAR = 8, F_STAMP = 16, F_EPI = 32, F_BF3 = 64 };
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -118,6 +123,42 @@ __device__ __forceinline__ void contract(const char* lds_sub, const XRegs<XT>& x
             }
         mid(g);
     }
+}
+
+template <int XT, int FLAGS, int NV, int NE, class Mid>
+__device__ __forceinline__ void contract_bf3(const char* lds_sub, const XRegs<XT>& x, f32x16 (&acc)[XT], float (&dv)[8], Mid&& mid) {
+    constexpr int KS = D / 16;
+    const int lane = lane_id(), r = lane & 31, h = lane >> 5;
+    const char* rowp = lds_sub + r * ROWB;
+    const int sw = r & 15;
+    bf16x8 ah = *reinterpret_cast<const bf16x8*>(rowp + ((h ^ sw) << 4));
+    bf16x8 al = *reinterpret_cast<const bf16x8*>(rowp + (((16 + h) ^ sw) << 4));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 a_h = ah, a_l = al;
+        if (!(FLAGS & F_NOLDS) && s + 1 < KS) {
+            ah = *reinterpret_cast<const bf16x8*>(rowp + (((2 * (s + 1) + h) ^ sw) << 4));
+            al = *reinterpret_cast<const bf16x8*>(rowp + (((16 + 2 * (s + 1) + h) ^ sw) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < XT; ++j) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, x.v[j][2 * s]), xl = __builtin_bit_cast(bf16x8, x.v[j][2 * s + 1]);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, xh, acc[j], 0, 0, 0);
+            dummy_valu<NV, NE>(dv, 1);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, xh, acc[j], 0, 0, 0);
+            dummy_valu<NV, NE>(dv, 1);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, xl, acc[j], 0, 0, 0);
+            dummy_valu<NV, 0>(dv, 2);
+        }
+        mid(2 * s);
+        mid(2 * s + 1);
+    }
+}
+
+template <int XT, int FLAGS, int NV, int NE, class Mid>
+__device__ __forceinline__ void contract_sel(const char* lds_sub, const XRegs<XT>& x, f32x16 (&acc)[XT], float (&dv)[8], Mid&& mid) {
+    if constexpr ((FLAGS & F_BF3) != 0) contract_bf3<XT, FLAGS, NV, NE>(lds_sub, x, acc, dv, mid);
+    else contract<XT, FLAGS, NV, NE>(lds_sub, x, acc, dv, mid);
 }
 
 struct LabParams {
@@ -217,7 +258,7 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(LabParams p) {
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
             if ((FLAGS & F_MIDBAR) && s == NSUB / 2) {
-                contract<XT, FLAGS, NV, NE>(tile + s * 32 * ROWB, x, acc, dv, [&](int g) {
+                contract_sel<XT, FLAGS, NV, NE>(tile + s * 32 * ROWB, x, acc, dv, [&](int g) {
                     vmem_hook(ty, s, g);
                     if (g == (NSUB == 1 ? 7 : 0)) {
                         // every wave is past the middle of tile ty => all of them finished tile ty-1: its slot is free
@@ -229,7 +270,7 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(LabParams p) {
                     }
                 });
             } else {
-                contract<XT, FLAGS, NV, NE>(tile + s * 32 * ROWB, x, acc, dv, [&](int g) { vmem_hook(ty, s, g); });
+                contract_sel<XT, FLAGS, NV, NE>(tile + s * 32 * ROWB, x, acc, dv, [&](int g) { vmem_hook(ty, s, g); });
             }
         }
         if (FLAGS & F_STAMP) { __builtin_amdgcn_sched_barrier(0); c_mfma += stamp() - m0; __builtin_amdgcn_sched_barrier(0); }
@@ -268,7 +309,7 @@ static void launch_v(const LabParams& p, dim3 grid, int lds, hipStream_t s) {
 }
 #define V(XT, WGPC, YR, FLAGS, NAME) VE(XT, WGPC, YR, FLAGS, 0, 0, 0, 0, NAME)
 #define VE(XT, WGPC, YR, FLAGS, ST, LD, NV, NE, NAME) \
-    Variant { NAME, XT, WGPC, YR, FLAGS, launch_v<XT, WGPC, YR, FLAGS, ST, LD, NV, NE>, ((WGPC) == 1 && 3 * YR * ROWB < 84 * 1024) ? 84 * 1024 : 3 * YR * ROWB, !((FLAGS) & (F_NODMA | F_NOBAR | F_NOLDS)) }
+    Variant { NAME, XT, WGPC, YR, FLAGS, launch_v<XT, WGPC, YR, FLAGS, ST, LD, NV, NE>, ((WGPC) == 1 && 3 * YR * ROWB < 84 * 1024) ? 84 * 1024 : 3 * YR * ROWB, !((FLAGS) & (F_NODMA | F_NOBAR | F_NOLDS | F_BF3)) }
 
 int main(int argc, char** argv) {
     const int64_t nX = 8192, nY = 16384;
@@ -317,6 +358,15 @@ int main(int argc, char** argv) {
         VE(2, 1, 64, F_MIDBAR, 4, 0, 4, 1, "xt2 wg1 yr64 midbar | fwd-like: st4 valu4 exp1"),
         VE(2, 1, 64, F_MIDBAR, 4, 4, 2, 1, "xt2 wg1 yr64 midbar | dU-like: ld4 st4 valu2 exp1"),
         V(1, 2, 32, F_NODMA | F_NOBAR | F_NOLDS, "xt1 wg2 yr32 bare mfma"),
+        VE(1, 2, 32, F_BF3, 0, 0, 0, 0, "bf3 xt1 wg2 yr32 | base"),
+        VE(1, 2, 32, F_BF3, 4, 0, 0, 0, "bf3 xt1 wg2 yr32 | st4"),
+        VE(1, 2, 32, F_BF3, 0, 0, 11, 1, "bf3 xt1 wg2 yr32 | valu264 exp16 per tile"),
+        VE(1, 2, 32, F_BF3, 4, 0, 11, 1, "bf3 xt1 wg2 yr32 | fwd-like: st4 valu264 exp16"),
+        VE(1, 2, 32, F_BF3, 4, 4, 6, 1, "bf3 xt1 wg2 yr32 | dU-like: ld4 st4 valu144 exp16"),
+        VE(2, 2, 32, F_BF3, 0, 0, 0, 0, "bf3 xt2 wg2 yr32 | base"),
+        VE(2, 2, 32, F_BF3, 4, 0, 11, 1, "bf3 xt2 wg2 yr32 | fwd-like: st4 valu264 exp16"),
+        VE(2, 2, 32, F_BF3, 4, 4, 6, 1, "bf3 xt2 wg2 yr32 | dU-like: ld4 st4 valu144 exp16"),
+        V(1, 2, 32, F_BF3 | F_NODMA | F_NOBAR | F_NOLDS, "bf3 xt1 wg2 yr32 bare mfma"),
         V(4, 1, 64, 0, "xt4 wg1 yr64"),
     };
     const char* only = argc > 2 ? argv[2] : nullptr;
