@@ -132,6 +132,7 @@ struct Bf3Ws {
     Bf3Plan plan;
     float* gmax;            // [Qp][nvals]
     float* thr;             // [Qp]
+    bf16x8* xfrag;          // [Qp / 32][d / 16][64]: the queries as pass A rounded them, in MFMA operand order
     uint32_t* lists;        // [nchunk][Qp][2][BF3_LIST] catalog rows
     int32_t* lcnt;          // [nchunk][Qp][2]
     uint32_t* exclW;        // [Qp][NT]: bit r of word t = row 32 t + r is excluded for the query
@@ -143,6 +144,7 @@ static Bf3Ws bf3_ws(void* base, int64_t Q, int64_t N, int d) {
     MfArena a(base);
     w.gmax = a.take<float>((size_t)w.plan.Qp * w.plan.nvals);
     w.thr = a.take<float>((size_t)w.plan.Qp);
+    w.xfrag = a.take<bf16x8>((size_t)w.plan.Qp * d / 8);
     w.lists = a.take<uint32_t>((size_t)w.plan.nchunk * w.plan.Qp * 2 * BF3_LIST);
     w.lcnt = a.take<int32_t>((size_t)w.plan.nchunk * w.plan.Qp * 2);
     w.exclW = a.take<uint32_t>((size_t)w.plan.NT * w.plan.Qp + 64);
@@ -164,6 +166,7 @@ struct Bf3Scan {
     const uint32_t* exclW;      // [Qp][NT]
     float* gmax;                // pass A out
     const float* thr;           // pass B in
+    bf16x8* xfrag;              // pass A out (chunk 0), pass B in
     uint32_t* lists;
     int32_t* lcnt;
     int abl;                    // lab knob (MF_BF3_ABL): 1 = no staging, 2 = no arithmetic -- wrong results, for timing only
@@ -251,20 +254,38 @@ __global__ __launch_bounds__(256, 2) void bf3_scan_kernel(Bf3Scan p) {
         for (int j = 0; j < BF3_NS - 1; ++j) stage(u0 + j, u0 + j < u1 && !(p.abl & 1));
     }
 
-    // the queries' bf16 fragments: step s covers k = 16 s + 8 h .. + 7
+    // the queries' bf16 fragments: step s covers k = 16 s + 8 h .. + 7.  Reading the fp32 rows here (one row per lane:
+    // every load instruction touches 64 cache lines) costs ~6 us of address processing per workgroup, so it happens at
+    // most once: pass A does it when nothing else ran before (no exclusion lists) and, in chunk 0, leaves the rounded
+    // fragments in operand order; with exclusion lists bf3_excl_rows_kernel has written them already.  Everything else
+    // reads the fragments back with coalesced 1 KiB loads
     bf16x8 xb[XT][KS];
     float thr[XT];
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt) {
         const int64_t x = x0 + 32 * xt + c;
         const bool ok = x < p.Q;
-        // (padding lanes read the last query: no branch around the loads, and nothing of theirs is ever stored)
-        const float* xr = p.q + (ok ? x : p.Q - 1) * D;
+        bf16x8* xf = p.xfrag + ((x0 / 32 + xt) * KS) * 64 + lane;
+        if (PASS == 0 && !EXCL) {
+            // (padding lanes read the last query: no branch around the loads, and nothing of theirs is ever stored)
+            const float* xr = p.q + (ok ? x : p.Q - 1) * D;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s + 8 * h);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 8 * h + 4);
-            xb[xt][s] = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+            for (int s = 0; s < KS; ++s) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s + 8 * h);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 8 * h + 4);
+                xb[xt][s] = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+            }
+            if (chunk == 0) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) xf[s * 64] = xb[xt][s];
+            }
+        } else {
+            const bf16x8 zero8 = {};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 f = xf[s * 64];
+                xb[xt][s] = ok ? f : zero8;         // (the fragments of padding queries were never written)
+            }
         }
         thr[xt] = (PASS == 1 && ok) ? p.thr[x] : __builtin_inff();      // (bf3_bound_kernel: already nudged below the bound)
     }
@@ -588,9 +609,18 @@ __global__ __launch_bounds__(64) void bf3_final_kernel(Bf3Final p) {
 // one workgroup per query: its exclusion list -> its row of bit words, through an LDS window (no memset, no global atomics)
 static constexpr int BF3_EXCL_WIN = 8192;       // words per window (262,144 catalog rows)
 __global__ __launch_bounds__(256) void bf3_excl_rows_kernel(const int64_t* __restrict__ excl_off, const int64_t* __restrict__ excl_idx,
-                                                            int64_t idx_base, int64_t N, int NT, uint32_t* __restrict__ exclW) {
+                                                            int64_t idx_base, int64_t N, int NT, uint32_t* __restrict__ exclW,
+                                                            const float* __restrict__ q, int d, bf16x8* __restrict__ xfrag) {
     __shared__ uint32_t win[BF3_EXCL_WIN];
     const int64_t r = blockIdx.x;
+    // this query's bf16 fragments in MFMA operand order (lane (c, h) of tile r / 32, step s: k = 16 s + 8 h .. + 7)
+    if ((int)threadIdx.x < d / 8) {
+        const int s = threadIdx.x >> 1, h = threadIdx.x & 1;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(q + r * d + 16 * s + 8 * h);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(q + r * d + 16 * s + 8 * h + 4);
+        xfrag[((r >> 5) * (d / 16) + s) * 64 + h * 32 + (r & 31)] =
+            bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+    }
     const int64_t e0 = excl_off[r], e1 = excl_off[r + 1];
     for (int w0 = 0; w0 < NT; w0 += BF3_EXCL_WIN) {
         const int nw = min(BF3_EXCL_WIN, NT - w0);
@@ -660,8 +690,8 @@ extern "C" int mf_topk_bf3(const float* q, int64_t Q, const float* items, const 
     if ((uint64_t)w.plan.upc * w.plan.ST * 32 * d * 2 > MF_SRD_MAX_BYTES) return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: chunk beyond 4 GiB");
     Bf3Index ix = bf3_index(const_cast<void*>(index), N, d);
     const bool excl = excl_off != nullptr;
-    if (excl) bf3_excl_rows_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.plan.NT, w.exclW);
-    Bf3Scan sp{q, Q, w.plan.Qp, ix.plane, N, w.plan.NT, w.plan.upc, w.plan.gpc, w.plan.nvals, w.exclW, w.gmax, w.thr, w.lists, w.lcnt,
+    if (excl) bf3_excl_rows_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.plan.NT, w.exclW, q, d, w.xfrag);
+    Bf3Scan sp{q, Q, w.plan.Qp, ix.plane, N, w.plan.NT, w.plan.upc, w.plan.gpc, w.plan.nvals, w.exclW, w.gmax, w.thr, w.xfrag, w.lists, w.lcnt,
                getenv("MF_BF3_ABL") ? atoi(getenv("MF_BF3_ABL")) : 0};
     MF_TIMED("topk_bf3", s, {
         if (d == 64) bf3_run<64, 2>(w, sp, excl, k, q, ix.ymax2, s);
