@@ -20,7 +20,7 @@
 // and the chain's) each stay within d 2^-24 sum |terms| (1 + O(d 2^-24)) of the real sum.  With 1 % slack for the
 // fp32 evaluation of the norms:  eps_q = 1.01 (2^-7 + 2^-16 + d 2^-22) |x_q|_2 ymax.
 //
-// A query whose candidates do not fit (more than BF3_LIST rows above thr in one lane's share of a chunk, or more
+// A query whose candidates do not fit (more than BF3_LCAP rows above thr in one lane's share of a chunk, or more
 // than BF3_CAND in all: a zero query, thousands of duplicate rows, a catalog whose best rows all sit in one group)
 // is answered by the same wave scanning the whole catalog with the exact chain: slow, but exact.
 // Two scans of a catalog HALF the size of the fp32 one, 1/16 of the matrix time each: DMA-bound, not MFMA-bound.
@@ -33,7 +33,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 static constexpr int BF3_NS = 4;            // ring slots (units of ST tiles); NS - 1 units in flight
 static constexpr int BF3_GROUP = 4;         // tiles per maxima group (128 rows)
-static constexpr int BF3_LIST = 16;         // rows per lane-private list (per chunk, query, lane half)
+static constexpr int BF3_LIST = 16;         // words per lane-private list (per chunk, query, lane half): the count, then <= 15 rows
+static constexpr int BF3_LCAP = BF3_LIST - 1;
 static constexpr int BF3_CAND = 1024;       // candidates rescored per query
 
 __device__ __forceinline__ unsigned short bf3_round(float x) {
@@ -115,7 +116,7 @@ static Bf3Plan bf3_plan(int64_t Q, int64_t N, int d) {
     p.gy = (int)(p.Qp / (128 * p.XT));
     const int units = (p.NT + p.ST - 1) / p.ST;
     int want = (512 + p.gy - 1) / p.gy;                        // two workgroups per CU
-    if (want > 128) want = 128;
+    if (want > 128) want = 128;                                // (bf3_final_kernel: at most 256 lists per query)
     if (want > units) want = units;
     if (want < 1) want = 1;
     p.upc = (units + want - 1) / want;
@@ -133,8 +134,7 @@ struct Bf3Ws {
     float* gmax;            // [Qp][nvals]
     float* thr;             // [Qp]
     bf16x8* xfrag;          // [Qp / 32][d / 16][64]: the queries as pass A rounded them, in MFMA operand order
-    uint32_t* lists;        // [nchunk][Qp][2][BF3_LIST] catalog rows
-    int32_t* lcnt;          // [nchunk][Qp][2]
+    uint32_t* lists;        // [nchunk][Qp][2][BF3_LIST]: word 0 the number of rows found (> BF3_LCAP: overflow), then the rows
     uint32_t* exclW;        // [Qp][NT]: bit r of word t = row 32 t + r is excluded for the query
     size_t total;
 };
@@ -146,7 +146,6 @@ static Bf3Ws bf3_ws(void* base, int64_t Q, int64_t N, int d) {
     w.thr = a.take<float>((size_t)w.plan.Qp);
     w.xfrag = a.take<bf16x8>((size_t)w.plan.Qp * d / 8);
     w.lists = a.take<uint32_t>((size_t)w.plan.nchunk * w.plan.Qp * 2 * BF3_LIST);
-    w.lcnt = a.take<int32_t>((size_t)w.plan.nchunk * w.plan.Qp * 2);
     w.exclW = a.take<uint32_t>((size_t)w.plan.NT * w.plan.Qp + 64);
     w.total = a.used();
     return w;
@@ -168,7 +167,6 @@ struct Bf3Scan {
     const float* thr;           // pass B in
     bf16x8* xfrag;              // pass A out (chunk 0), pass B in
     uint32_t* lists;
-    int32_t* lcnt;
     int abl;                    // lab knob (MF_BF3_ABL): 1 = no staging, 2 = no arithmetic -- wrong results, for timing only
 };
 
@@ -388,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void bf3_scan_kernel(Bf3Scan p) {
                                 hm &= hm - 1;
                                 const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
                                 if (!((dead >> rr) & 1u)) {
-                                    if (lc[xt] < BF3_LIST) mylist[lc[xt]] = (uint32_t)t * 32u + (uint32_t)rr;
+                                    if (lc[xt] < BF3_LCAP) mylist[1 + lc[xt]] = (uint32_t)t * 32u + (uint32_t)rr;
                                     ++lc[xt];
                                 }
                             }
@@ -417,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void bf3_scan_kernel(Bf3Scan p) {
             const int done = u0 < u1 ? (min(u1 * ST, p.NT) - u0 * ST + BF3_GROUP - 1) / BF3_GROUP : 0;
             for (int g = done; g < p.gpc; ++g) p.gmax[x * p.nvals + ((int64_t)chunk * p.gpc + g) * 2 + h] = -__builtin_inff();
         } else {
-            p.lcnt[((int64_t)chunk * p.Qp + x) * 2 + h] = lc[xt];      // > BF3_LIST: overflow
+            p.lists[(((int64_t)chunk * p.Qp + x) * 2 + h) * BF3_LIST] = (uint32_t)lc[xt];      // > BF3_LCAP: overflow
         }
     }
 }
@@ -475,7 +473,6 @@ struct Bf3Final {
     int d, k, nchunk, NT;
     int64_t Qp;
     const uint32_t* lists;
-    const int32_t* lcnt;
     const uint32_t* exclW;      // NULL: nothing excluded
     int64_t idx_base;
     float* out_scores;
@@ -517,21 +514,27 @@ __global__ __launch_bounds__(64) void bf3_final_kernel(Bf3Final p) {
     // gather the lane-private lists of every chunk: list j = (chunk, half)
     bool overflow = false;
     const int nl = p.nchunk * 2;
-    for (int j0 = 0; j0 < nl; j0 += 64) {
-        const int j = j0 + lane;
-        int cnt = 0;
-        const uint32_t* src = nullptr;
-        if (j < nl) {
-            const int64_t li = ((int64_t)(j >> 1) * p.Qp + r) * 2 + (j & 1);
-            cnt = p.lcnt[li];
-            src = p.lists + li * BF3_LIST;
-        }
-        if (cnt > BF3_LIST) overflow = true;
-        const int take = min(cnt, BF3_LIST);
+    // (nchunk <= 128: at most four lists per lane; their heads -- the count and the first three rows -- in one trip)
+    uint4 head[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = jj * 64 + lane;
+        head[jj] = uint4{0u, 0u, 0u, 0u};
+        if (j < nl) head[jj] = *reinterpret_cast<const uint4*>(p.lists + (((int64_t)(j >> 1) * p.Qp + r) * 2 + (j & 1)) * BF3_LIST);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = jj * 64 + lane;
+        const int cnt = (int)head[jj].x;
+        if (cnt > BF3_LCAP) overflow = true;
+        const int take = min(cnt, BF3_LCAP);
         int at = 0;
         if (take > 0) at = atomicAdd(&s_n, take);
-        for (int e = 0; e < take; ++e)
-            if (at + e < BF3_CAND) keys[at + e] = (unsigned long long)src[e];     // (row ids for now)
+        const uint32_t* src = p.lists + (((int64_t)(j >> 1) * p.Qp + r) * 2 + (j & 1)) * BF3_LIST;
+        for (int e = 0; e < take; ++e) {
+            const uint32_t row = e == 0 ? head[jj].y : e == 1 ? head[jj].z : e == 2 ? head[jj].w : src[1 + e];
+            if (at + e < BF3_CAND) keys[at + e] = (unsigned long long)row;     // (row ids for now)
+        }
     }
     __syncthreads();
     int n = s_n;
@@ -691,13 +694,13 @@ extern "C" int mf_topk_bf3(const float* q, int64_t Q, const float* items, const 
     Bf3Index ix = bf3_index(const_cast<void*>(index), N, d);
     const bool excl = excl_off != nullptr;
     if (excl) bf3_excl_rows_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.plan.NT, w.exclW, q, d, w.xfrag);
-    Bf3Scan sp{q, Q, w.plan.Qp, ix.plane, N, w.plan.NT, w.plan.upc, w.plan.gpc, w.plan.nvals, w.exclW, w.gmax, w.thr, w.xfrag, w.lists, w.lcnt,
+    Bf3Scan sp{q, Q, w.plan.Qp, ix.plane, N, w.plan.NT, w.plan.upc, w.plan.gpc, w.plan.nvals, w.exclW, w.gmax, w.thr, w.xfrag, w.lists,
                getenv("MF_BF3_ABL") ? atoi(getenv("MF_BF3_ABL")) : 0};
     MF_TIMED("topk_bf3", s, {
         if (d == 64) bf3_run<64, 2>(w, sp, excl, k, q, ix.ymax2, s);
         else if (d == 128) bf3_run<128, 2>(w, sp, excl, k, q, ix.ymax2, s);
         else bf3_run<256, 1>(w, sp, excl, k, q, ix.ymax2, s);
-        Bf3Final fp{q, items, N, d, k, w.plan.nchunk, w.plan.NT, w.plan.Qp, w.lists, w.lcnt, excl ? w.exclW : nullptr, idx_base, out_scores, out_idx};
+        Bf3Final fp{q, items, N, d, k, w.plan.nchunk, w.plan.NT, w.plan.Qp, w.lists, excl ? w.exclW : nullptr, idx_base, out_scores, out_idx};
         if (d == 64) bf3_final_kernel<64><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
         else if (d == 128) bf3_final_kernel<128><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
         else bf3_final_kernel<256><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
