@@ -310,9 +310,7 @@ __global__ __launch_bounds__(256, 2) void bf3_scan_kernel(Bf3Scan p) {
             BF3_ADD(3, pc - pb);
             if (p.abl & 2) { stage(u + BF3_NS - 1, live_n); continue; }
             const char* slot = smem + ((u - u0) % BF3_NS) * L::UNITB;
-            // every catalog fragment of the unit first (one LDS latency per unit, not per step), then its MFMAs.
-            // (Reading the NEXT unit's fragments before this unit's epilogue -- wait, barrier and LDS latency behind the
-            // epilogue's VALU work -- was measured: 69.7 -> 74.6 us per call; 25..45 more live registers, no gain.)
+            // every catalog fragment of the unit first (one LDS latency per unit, not per step), then its MFMAs
             bf16x8 afr[ST][KS];
             {
                 const char* rowp = slot + c * G::ROWB;
