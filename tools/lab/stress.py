@@ -1,0 +1,118 @@
+"""Randomised cross-checks of the round-2 kernels (not part of the test suite: minutes of GPU time).
+  * top-k: the three retrieval paths (fp32 tiles, few-query scan, bf16 prefilter) must return the same bits on random
+    shapes -- Q, N (incl. N % 32 != 0 and tiny N), d, k, exclusion lists, idx_base, duplicate rows, scaled norms;
+  * sparse update: the one-launch path against the oracle's coalesced row-Adam on random id multisets (Zipf, uniform,
+    one dominant id, out-of-range ids), and bit-reproducibility of a repeated call.
+    python tools/lab/stress.py [seconds]"""
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import embed as oembed  # noqa: E402
+
+mf = importlib.import_module("matrix-factorization-torch_amd")
+lib = mf._lib.lib()
+dev = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+g = torch.Generator().manual_seed(int(os.environ.get("STRESS_SEED", "1")))
+
+
+def ri(lo, hi):
+    return int(torch.randint(lo, hi + 1, (1,), generator=g))
+
+
+def topk_case():
+    d = [32, 64, 128, 256][ri(0, 3)]
+    n = [ri(1, 40), ri(41, 3000), ri(3000, 70000), ri(8192, 200000)][ri(0, 3)]
+    q = [ri(1, 4), ri(5, 40), ri(41, 300), ri(300, 1500)][ri(0, 3)]
+    k = [1, ri(2, 20), 20, 64][ri(0, 3)]
+    base = [0, ri(1, 1000)][ri(0, 1)]
+    items = torch.randn(n, d, generator=g)
+    qs = torch.randn(q, d, generator=g)
+    if ri(0, 1):
+        items = torch.nn.functional.normalize(items, dim=-1)
+        qs = torch.nn.functional.normalize(qs, dim=-1)
+    else:
+        items = items * torch.exp(torch.randn(n, 1, generator=g))
+    if n > 10 and ri(0, 1):
+        items[ri(0, n - 1)] = items[ri(0, n - 1)]
+    if ri(0, 3) == 0:
+        qs[ri(0, q - 1)] = 0.0
+    if n > 300 and ri(0, 2) == 0:
+        lo = ri(0, n - 200)
+        items[lo: lo + 150] = qs[0] + 0.01 * torch.randn(150, d, generator=g)
+    excl = None
+    if ri(0, 1):
+        excl = [sorted(set((torch.randint(0, n, (ri(0, min(300, n)),), generator=g) + base).tolist())) for _ in range(q)]
+    index = mf.retrieval.ItemIndex(items.to(dev), idx_base=base)
+    ref = index.search(qs.to(dev), k, exclude=excl, path="tiles")
+    paths = []
+    if q <= index.SMALL_Q:
+        paths.append("scan")
+    if d >= 64:
+        paths.append("bf16")
+    for path in paths:
+        got = index.search(qs.to(dev), k, exclude=excl, path=path)
+        if not (torch.equal(got[1], ref[1]) and torch.equal(got[0].view(torch.int32), ref[0].view(torch.int32))):
+            print(f"TOPK MISMATCH path={path} q={q} n={n} d={d} k={k} base={base} excl={excl is not None}", flush=True)
+            return False
+    return True
+
+
+def update_case():
+    d = [32, 64, 128, 256][ri(0, 3)]
+    rows = [ri(1, 50), ri(51, 5000), ri(5000, 200000)][ri(0, 2)]
+    n = [ri(1, 40), ri(41, 5000), ri(5000, 65536), ri(65537, 90000)][ri(0, 3)]
+    kind = ri(0, 3)
+    if kind == 0:
+        idx = torch.randint(0, rows, (n,), generator=g)
+    elif kind == 1:
+        w = 1.0 / torch.arange(1, rows + 1, dtype=torch.float64)
+        idx = torch.multinomial(w, n, replacement=True, generator=g)
+    elif kind == 2:
+        idx = torch.randint(0, rows, (n,), generator=g)
+        idx[torch.rand(n, generator=g) < 0.7] = ri(0, rows - 1)
+    else:
+        idx = torch.randint(-3, rows + 3, (n,), generator=g)
+    grad = torch.randn(n, d, generator=g)
+    valid = (idx >= 0) & (idx < rows)
+    table0 = torch.randn(rows, d, generator=g)
+    table = table0.to(dev)
+    em, ev = torch.zeros_like(table), torch.zeros_like(table)
+    ws = mf._lib.workspace(lib.mf_update_ws_bytes(n, d), dev)
+    gi, gg = idx.to(dev), grad.to(dev)
+    ref, rm, rv = table0.clone(), torch.zeros_like(table0), torch.zeros_like(table0)
+    for step in (1, 2):
+        mf._lib.check(lib.mf_update_adam(table.data_ptr(), em.data_ptr(), ev.data_ptr(), rows, d, gi.data_ptr(), n, gg.data_ptr(), 0,
+                                         step, None, 0.05, 0.9, 0.999, 1e-8, 0.01, ws.data_ptr(), ws.numel(), None))
+        if valid.any():
+            oembed.adam_update(ref, rm, rv, idx[valid], grad[valid], step=step, lr=0.05, weight_decay=0.01)
+    # sums of many gradient rows in a different order than index_add; near-zero sums make Adam's sign-like first steps differ by lr
+    diff = (table.cpu() - ref).abs()
+    bad = diff > (2e-4 * ref.abs() + 2e-5)
+    if bad.float().mean() > 1e-4:
+        print(f"UPDATE MISMATCH rows={rows} n={n} d={d} kind={kind} frac_bad={bad.float().mean():.2e} max={diff.max():.3e}", flush=True)
+        return False
+    t2 = table0.to(dev)
+    m2, v2 = torch.zeros_like(t2), torch.zeros_like(t2)
+    for step in (1, 2):
+        mf._lib.check(lib.mf_update_adam(t2.data_ptr(), m2.data_ptr(), v2.data_ptr(), rows, d, gi.data_ptr(), n, gg.data_ptr(), 0,
+                                         step, None, 0.05, 0.9, 0.999, 1e-8, 0.01, ws.data_ptr(), ws.numel(), None))
+    if not torch.equal(t2, table):
+        print(f"UPDATE NOT REPRODUCIBLE rows={rows} n={n} d={d} kind={kind}", flush=True)
+        return False
+    return True
+
+
+t0, n_ok, n_bad = time.time(), 0, 0
+while time.time() - t0 < budget:
+    for fn in (topk_case, update_case):
+        ok = fn()
+        n_ok += ok
+        n_bad += not ok
+print(f"stress: {n_ok} cases ok, {n_bad} failed in {time.time() - t0:.0f} s", flush=True)
+sys.exit(1 if n_bad else 0)
