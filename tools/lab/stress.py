@@ -108,11 +108,59 @@ def update_case():
     return True
 
 
+def loss_case():
+    """random tile-ragged shapes through every loss class, dense and mined, against the oracle (the forward's loop is
+    unrolled by two tiles: odd / even tile counts, every split length)"""
+    import numpy as np
+
+    from oracle import chain, losses as ol
+    from tests import test_gpu_parity as tp
+
+    d = [32, 64, 128, 256][ri(0, 3)]
+    b = [ri(1, 40), ri(41, 300), ri(300, 700)][ri(0, 2)]
+    n = b + [0, ri(1, 64), ri(64, 900)][ri(0, 2)]
+    p = ri(1, 40)
+    k = [0, 0, ri(1, 8), ri(9, 64), n + 5][ri(0, 4)]
+    if 0 < k < n and k > 64:
+        k = 64
+    sigma, margin = [(1.0, 1.0), (3.0, 0.25), (0.5, 0.0)][ri(0, 2)]
+    t = tp._random_case(b, n, d, p, seed=ri(0, 10**6))
+    logq = None if ri(0, 1) else torch.log(torch.rand(n, generator=g) * 0.9 + 0.05)
+    lg = chain.logits(t["u"].numpy(), t["v"].numpy(), t["target"].numpy(), sigma, None if logq is None else logq.numpy())
+    for kind in ol.KINDS:
+        u = t["u"].clone().requires_grad_()
+        v = t["v"].clone().requires_grad_()
+        want = ol.loss(kind, u, v, t["target"], item_idx=t["item_idx"], pos_idx=t["pos_idx"], num_negatives=k, sigma=sigma,
+                       margin=margin, logq=logq, mining_logits=lg)
+        want.backward()
+        got, du, dv = tp._run_gpu(mf, kind, t, k, sigma, margin, logq)
+        w = float(want.detach())
+        if not np.isfinite(w):
+            ok = got == w or (np.isnan(got) and np.isnan(w))
+        else:
+            bu = ~np.isclose(du, u.grad.numpy(), rtol=2e-4, atol=2e-5 * sigma)
+            bv = ~np.isclose(dv, v.grad.numpy(), rtol=2e-4, atol=2e-5 * sigma)
+            rows_off = int(bu.any(axis=1).sum() + bv.any(axis=1).sum())
+            # the hinge-type losses have step-function gradients: an element whose argument is within rounding of the kink
+            # (the oracle's logits are torch's, ours the fmaf chain's: 1e-7 apart) flips one (user, item) contribution --
+            # one row of du and one of dv.  Counted, not failed, when the loss agrees and at most 4 such pairs exist.
+            kink = kind in ("ContrastiveLoss", "AlignmentContrastiveLoss", "PairwiseHingeLoss") and 0 < rows_off <= 8
+            if kink:
+                global n_kink
+                n_kink += 1
+            ok = abs(got - w) <= 1e-4 * sigma * max(1.0, abs(w)) and (rows_off == 0 or kink)
+        if not ok:
+            print(f"LOSS MISMATCH kind={kind} b={b} n={n} d={d} p={p} k={k} sigma={sigma} logq={logq is not None} got={got} want={w}", flush=True)
+            return False
+    return True
+
+
+n_kink = 0
 t0, n_ok, n_bad = time.time(), 0, 0
 while time.time() - t0 < budget:
-    for fn in (topk_case, update_case):
+    for fn in ((loss_case,) if os.environ.get("STRESS_ONLY") == "loss" else (topk_case, update_case, loss_case)):
         ok = fn()
         n_ok += ok
         n_bad += not ok
-print(f"stress: {n_ok} cases ok, {n_bad} failed in {time.time() - t0:.0f} s", flush=True)
+print(f"stress: {n_ok} cases ok, {n_bad} failed in {time.time() - t0:.0f} s ({n_kink} hinge-kink flips tolerated)", flush=True)
 sys.exit(1 if n_bad else 0)
