@@ -204,6 +204,15 @@ int mf_topk(const float* q, int64_t Q, const float* items, int64_t N, int d, int
 int mf_topk_merge(const float* part_scores, const int64_t* part_idx, int G, int64_t Q, int k,
                   float* out_scores, int64_t* out_idx, mf_stream_t stream);
 
+/* Sharded retrieval in ONE exchange: mf_topk_pack turns a rank's partial result (n = Q * k scores and LOCAL rows of its
+ * shard; -1 = none) into one int64 per entry -- score bits << 32 | global row (local * stride + offset, < 2^32), -1 for
+ * none -- and mf_topk_merge_packed merges G such blocks [G][Q][k] (as they arrive from one all-to-all) into the global
+ * top-k, exactly like mf_topk_merge on (scores, global rows). */
+int mf_topk_pack(const float* scores, const int64_t* rows, int64_t n, int64_t stride, int64_t offset, int64_t* out_packed,
+                 mf_stream_t stream);
+int mf_topk_merge_packed(const int64_t* packed, int G, int64_t Q, int k, float* out_scores, int64_t* out_idx,
+                         mf_stream_t stream);
+
 /* Small-batch form of mf_topk: Q <= 32 queries (the reference's search takes ONE query per call,
  * xfmr_rec/data/lightning.py:237-259; recommend, xfmr_rec/lightning.py:76-95).  A matrix-vector scan is
  * bandwidth-bound, so this path streams a BLOCKED copy of the catalog -- [block of 64 rows][16-byte chunk][row],

@@ -62,6 +62,8 @@ SIGNATURES = {
     "mf_topk_blocked_build": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "mf_topk_small_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int]),
     "mf_topk_small": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "mf_topk_pack": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    "mf_topk_merge_packed": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
     "mf_topk_bf3_index_bytes": (c_sz, [c_i64, c_int]),
     "mf_topk_bf3_build": (c_int, [c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
     "mf_topk_bf3_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int]),

@@ -139,6 +139,56 @@ __global__ __launch_bounds__(64) void topk_merge_parts_kernel(const float* __res
     });
 }
 
+// Sharded retrieval, one exchange instead of two: a rank's partial result (scores, LOCAL rows) becomes one int64 per entry
+// -- score bits << 32 | global row (local * stride + offset; < 2^32), all ones for "none" -- in a single launch (the row
+// mapping alone took four elementwise launches), travels as ONE all-to-all, and is merged straight from that form.
+__global__ __launch_bounds__(256) void topk_pack_kernel(const float* __restrict__ s, const int64_t* __restrict__ rows, int64_t n,
+                                                        int64_t stride, int64_t offset, int64_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int64_t r = rows[t];
+    out[t] = r >= 0 ? (int64_t)(((unsigned long long)__builtin_bit_cast(unsigned, s[t]) << 32) | (unsigned long long)(unsigned)(r * stride + offset))
+                    : -1ll;
+}
+
+__global__ __launch_bounds__(64) void topk_merge_packed_kernel(const int64_t* __restrict__ packed, int G, int64_t Q, int k,
+                                                               float* __restrict__ out_scores, int64_t* __restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+    const int64_t r = blockIdx.x;
+    const int lane = mf_lane();
+    const int total = G * k;
+    for (int t = lane; t < total; t += 64) {
+        const int g = t / k, e = t % k;
+        const int64_t v = packed[((int64_t)g * Q + r) * k + e];
+        s_keys[t] = v != -1ll ? mf_key_retrieval(__builtin_bit_cast(float, (unsigned)((unsigned long long)v >> 32)), (unsigned)v) : 0ull;
+    }
+    __syncthreads();
+    mf_wave_select(s_keys, total, k, [&](int t, unsigned long long key) {
+        if (key != 0ull) {
+            out_scores[r * k + t] = mf_key_retrieval_score(key);
+            out_idx[r * k + t] = (int64_t)mf_key_retrieval_col(key);
+        } else {
+            out_scores[r * k + t] = -INFINITY;
+            out_idx[r * k + t] = -1;
+        }
+    });
+}
+
+extern "C" int mf_topk_pack(const float* scores, const int64_t* rows, int64_t n, int64_t stride, int64_t offset, int64_t* out_packed,
+                            mf_stream_t stream) {
+    if (!scores || !rows || !out_packed || n < 0 || stride <= 0 || offset < 0) return mf_set_error(MF_EINVAL, "mf_topk_pack: bad argument");
+    if (n == 0) return MF_OK;
+    topk_pack_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, static_cast<hipStream_t>(stream)>>>(scores, rows, n, stride, offset, out_packed);
+    return mf_check_launch("mf_topk_pack");
+}
+
+extern "C" int mf_topk_merge_packed(const int64_t* packed, int G, int64_t Q, int k, float* out_scores, int64_t* out_idx, mf_stream_t stream) {
+    if (!packed || !out_scores || !out_idx || G <= 0 || Q <= 0 || k <= 0) return mf_set_error(MF_EINVAL, "mf_topk_merge_packed: bad argument");
+    if ((size_t)G * k * 8 > 64 * 1024) return mf_set_error(MF_ENOTSUP, "mf_topk_merge_packed: G * k too large");
+    topk_merge_packed_kernel<<<dim3((unsigned)Q), 64, (size_t)G * k * 8, static_cast<hipStream_t>(stream)>>>(packed, G, Q, k, out_scores, out_idx);
+    return mf_check_launch("mf_topk_merge_packed");
+}
+
 #ifdef MF_PROBE
 static TopkWs g_probe_ws;
 extern "C" long long mf_probe_topk_cand() {       // tools/topk_probe.py: candidate keys kept by the last mf_topk

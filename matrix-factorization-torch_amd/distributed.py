@@ -258,6 +258,19 @@ class HipOps:
     def merge(self, part_scores, part_rows, k):
         return self.mf.retrieval.merge_topk(part_scores, part_rows, k)
 
+    def pack(self, scores, rows, stride, offset):
+        """(scores, LOCAL rows) -> one int64 per entry with the GLOBAL row (``mf_topk_pack``): one exchange, not two."""
+        out = torch.empty(rows.shape, dtype=torch.int64, device=rows.device)
+        _lib.check(_lib.lib().mf_topk_pack(scores.data_ptr(), rows.data_ptr(), rows.numel(), int(stride), int(offset), out.data_ptr(),
+                                           _lib.stream_ptr()))
+        return out
+
+    def merge_packed(self, packed, world, q, k):
+        scores = torch.empty(q, k, dtype=torch.float32, device=packed.device)
+        rows = torch.empty(q, k, dtype=torch.int64, device=packed.device)
+        _lib.check(_lib.lib().mf_topk_merge_packed(packed.data_ptr(), world, q, k, scores.data_ptr(), rows.data_ptr(), _lib.stream_ptr()))
+        return scores, rows
+
 
 def optimizer_hyper(optimizer: str, lr: float | None = None, **over) -> dict:
     """The hyper-parameters of ``optim.SparseSGD`` / ``optim.RowAdam`` (their constructor defaults), in one place."""
@@ -527,6 +540,10 @@ class ShardedIndex:
             csr = (torch.cat(offs), self._localise(ids_all) if base else ids_all - 1)
             self._csr_key, self._csr_all, self._csr_src = key, csr, exclude_csr   # (keeps the source tensors alive)
         ps, pi = self.ops.topk(all_q, self.items, top_k, csr, 0)                 # [world * q, k], local rows
+        if hasattr(self.ops, "pack"):
+            # scores and global rows as ONE int64 per entry: one launch for the row mapping, one exchange, merged as they are
+            packed = comm.equal(self.ops.pack(ps, pi, self.stride, self.offset))
+            return self.ops.merge_packed(packed, world, q, top_k)
         pi = torch.where(pi >= 0, pi * self.stride + self.offset, pi)            # -> global rows, before the merge
         rs = comm.equal(ps)                                                      # block g -> rank g
         ri = comm.equal(pi)
