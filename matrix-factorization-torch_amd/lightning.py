@@ -41,6 +41,7 @@ except ImportError:  # noqa: SIM105
 
 
 class MatrixFactorizationLitConfig(models.ModelConfig):
+    hidden_size: int = 32          # xfmr_rec/lightning.py:33
     train_loss: str = "PairwiseHingeLoss"
     num_negatives: int = 4
     sigma: float = 1.0

@@ -32,6 +32,55 @@ KINDS = (
 MAX_MINED_NEGATIVES = 64
 
 
+class _SquaredDistance(torch.autograd.Function):
+    """``D[i, j] = 0.5 * max(|q_i|^2 + |c_j|^2 - 2 q_i . c_j, 0)`` with the dot products from the fp32 MFMA tile engine
+    (``mf_scores``: the canonical chain of include/mf_numerics.h) and chain-ordered norms (``mf_row_sqnorm``)."""
+
+    @staticmethod
+    def forward(ctx, query_embed, candidate_embed):
+        q = _lib.dev_f32(query_embed, "query_embed")
+        c = _lib.dev_f32(candidate_embed, "candidate_embed")
+        if q.dim() != 2 or c.dim() != 2 or q.shape[1] != c.shape[1]:  # noqa: PLR2004
+            msg = f"expected (Q, d) and (N, d): {tuple(q.shape) = }, {tuple(c.shape) = }"
+            raise ValueError(msg)
+        d = q.shape[1]
+        dp = _lib.padded_width(d)
+        qp, cp = (q, c) if dp == d else (torch.nn.functional.pad(q, (0, dp - d)), torch.nn.functional.pad(c, (0, dp - d)))
+        lib = _lib.lib()
+        dot = torch.empty(q.shape[0], c.shape[0], dtype=torch.float32, device=q.device)
+        nq = torch.empty(q.shape[0], dtype=torch.float32, device=q.device)
+        nc = torch.empty(c.shape[0], dtype=torch.float32, device=q.device)
+        st = _lib.stream_ptr()
+        _lib.check(lib.mf_scores(qp.data_ptr(), qp.shape[0], cp.data_ptr(), cp.shape[0], dp, dot.data_ptr(), st))
+        _lib.check(lib.mf_row_sqnorm(qp.data_ptr(), qp.shape[0], dp, nq.data_ptr(), st))
+        _lib.check(lib.mf_row_sqnorm(cp.data_ptr(), cp.shape[0], dp, nc.data_ptr(), st))
+        sq = torch.addcmul(nq[:, None] + nc[None, :], dot, dot.new_tensor(-2.0))      # mf_half_sqdist, elementwise
+        ctx.save_for_backward(q, c, sq)
+        ctx.dtypes = (query_embed.dtype, candidate_embed.dtype)
+        return sq.clamp_min(0.0) * 0.5
+
+    @staticmethod
+    def backward(ctx, grad):
+        q, c, sq = ctx.saved_tensors
+        g = torch.where(sq > 0, grad.to(torch.float32), torch.zeros((), device=grad.device))   # the clamp's subgradient
+        dq = g.sum(dim=1, keepdim=True) * q - g @ c              # d D_ij / d q_i = q_i - c_j
+        dc = g.sum(dim=0)[:, None] * c - g.t() @ q
+        return dq.to(ctx.dtypes[0]), dc.to(ctx.dtypes[1])
+
+
+def squared_distance(query_embed: torch.Tensor, candidate_embed: torch.Tensor) -> torch.Tensor:
+    """``cdist(q, c) ** 2 / 2`` (losses.py:9-12) as a ``[Q, N]`` matrix -- the public helper; the losses themselves
+    never materialise it.  Differentiable (the backward is plain torch on the GPU: not the hot path)."""
+    return _SquaredDistance.apply(query_embed, candidate_embed)
+
+
+def weighted_mean(values: torch.Tensor, sample_weights: torch.Tensor, *, dim: int | None = None,
+                  keepdim: bool = False) -> torch.Tensor:
+    """losses.py:15-23: ``sum(values * w / (sum(w) + 1e-10))`` along ``dim``."""
+    denominator = sample_weights.sum(dim=dim, keepdim=True) + 1e-10
+    return (values * sample_weights / denominator).sum(dim=dim, keepdim=keepdim)
+
+
 def _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq, logq_table=None):
     u = _lib.dev_f32(user_embed, "user_embed")
     v = _lib.dev_f32(item_embed, "item_embed")
@@ -277,13 +326,40 @@ class EmbeddingLoss(torch.nn.Module, abc.ABC):
         """losses.py:134-162 on a materialised logits matrix (the losses themselves mine on the fly)."""
         return self._mine(logits, negative_masks, semi_hard=True)
 
+    def _loss_of_kind(self, kind: int, user_embed, item_embed, target, *, item_idx, pos_idx, logq=None, prepared=None,
+                      logq_table=None) -> torch.Tensor:
+        k = int(self.num_negatives)
+        if kind != 0:
+            _check_num_negatives(k, item_embed.size(0))
+        return _LossFunction.apply(user_embed, item_embed, target, item_idx, pos_idx, logq, 1 << kind, kind,
+                                   k, float(self.sigma), float(self.margin), prepared, logq_table)
+
     def loss(self, user_embed, item_embed, target, *, item_idx, pos_idx, logq=None, prepared=None,
              logq_table=None) -> torch.Tensor:
-        k = int(self.num_negatives)
-        if self.kind != 0:
-            _check_num_negatives(k, item_embed.size(0))
-        return _LossFunction.apply(user_embed, item_embed, target, item_idx, pos_idx, logq, 1 << self.kind, self.kind,
-                                   k, float(self.sigma), float(self.margin), prepared, logq_table)
+        return self._loss_of_kind(self.kind, user_embed, item_embed, target, item_idx=item_idx, pos_idx=pos_idx, logq=logq,
+                                  prepared=prepared, logq_table=logq_table)
+
+    # ---- the reference's per-loss methods (losses.py:164-246): any instance can evaluate any of them, with ITS
+    # num_negatives / sigma / margin, exactly like upstream where the subclasses only pick one
+    def alignment_loss(self, user_embed: torch.Tensor, item_embed: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """losses.py:164-170 (positives only; no ids needed)."""
+        ids = torch.zeros(item_embed.size(0), dtype=torch.int64, device=item_embed.device)
+        return self._loss_of_kind(KINDS.index("AlignmentLoss"), user_embed, item_embed, target, item_idx=ids, pos_idx=None)
+
+    def contrastive_loss(self, user_embed, item_embed, target, *, item_idx, pos_idx, **kw) -> torch.Tensor:
+        """losses.py:172-193."""
+        return self._loss_of_kind(KINDS.index("ContrastiveLoss"), user_embed, item_embed, target, item_idx=item_idx,
+                                  pos_idx=pos_idx, **kw)
+
+    def infonce_loss(self, user_embed, item_embed, target, *, item_idx, pos_idx, **kw) -> torch.Tensor:
+        """losses.py:195-223."""
+        return self._loss_of_kind(KINDS.index("InfomationNoiseContrastiveEstimationLoss"), user_embed, item_embed, target,
+                                  item_idx=item_idx, pos_idx=pos_idx, **kw)
+
+    def mine_loss(self, user_embed, item_embed, target, *, item_idx, pos_idx, **kw) -> torch.Tensor:
+        """losses.py:225-246."""
+        return self._loss_of_kind(KINDS.index("MutualInformationNeuralEstimationLoss"), user_embed, item_embed, target,
+                                  item_idx=item_idx, pos_idx=pos_idx, **kw)
 
 
 class AlignmentLoss(EmbeddingLoss):  # losses.py:249-259
@@ -307,15 +383,19 @@ class MutualInformationNeuralEstimationLoss(EmbeddingLoss):  # losses.py:309-321
 
 
 class PairwiseEmbeddingLoss(EmbeddingLoss, abc.ABC):  # losses.py:324-349
-    pass
+    @abc.abstractmethod
+    def score_loss_fn(self, score: torch.Tensor) -> torch.Tensor:
+        """phi of losses.py:348-349 on a caller's tensor (API parity; the kernels apply it per tile element)."""
 
 
 class PairwiseLogisticLoss(PairwiseEmbeddingLoss):  # losses.py:352-354 (BPR when margin = 0)
-    pass
+    def score_loss_fn(self, score: torch.Tensor) -> torch.Tensor:
+        return -torch.nn.functional.logsigmoid(-score)
 
 
 class PairwiseHingeLoss(PairwiseEmbeddingLoss):  # losses.py:357-359 (default train_loss)
-    pass
+    def score_loss_fn(self, score: torch.Tensor) -> torch.Tensor:
+        return score.relu()
 
 
 @torch.no_grad()

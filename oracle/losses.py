@@ -82,6 +82,20 @@ def semi_hard_mining(lg: torch.Tensor, neg: torch.Tensor, k: int) -> torch.Tenso
     return neg & sel
 
 
+@torch.no_grad()
+def hard_mining(lg: torch.Tensor, neg: torch.Tensor, k: int) -> torch.Tensor:
+    """losses.py:112-132 (defined upstream, never called): keeps, per row, the min(k, #valid) valid negatives with
+    the highest logits, lowest column on exact ties (torch.topk leaves ties unspecified)."""
+    n = lg.shape[1]
+    if k <= 0 or k >= n:
+        return neg
+    key = torch.where(neg, lg, torch.full_like(lg, float("-inf")))
+    top = torch.argsort(key, dim=1, descending=True, stable=True)[:, :k]
+    sel = torch.zeros_like(neg)
+    sel.scatter_(1, top, True)
+    return neg & sel
+
+
 def _wmean(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """losses.py:15-23."""
     wf = w.to(x.dtype)

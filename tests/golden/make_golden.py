@@ -11,7 +11,8 @@ The outputs -- inputs and the reference's outputs, i.e. data -- are committed as
 For every shape x the 7 loss classes x num_negatives in {0, 4, N} x
 (sigma, margin) in {(1,1), (2,0.5), (1,0)} it stores the scalar loss, the
 post-mining boolean mask (packed bits) and d loss/d user_embed, d loss/d item_embed
-(every ``gstride``-th row for the two larger shapes, to keep the fixtures small).
+(every ``gstride``-th row for the larger shapes, to keep the fixtures small), and -- per (sigma, margin) -- the
+mask ``hard_mining`` (losses.py:112-132, k = 4) leaves of the same negative mask.
 """
 from __future__ import annotations
 
@@ -38,6 +39,7 @@ SHAPES = (
     (32, 64, 32, 16, 2, False),
     (48, 96, 64, 33, 6, False),
     (64, 128, 128, 64, 16, False),
+    (256, 512, 64, 24, 32, False),     # 2 x 4 sweep tiles of 128 x 128: the multi-block paths against the reference itself
 )
 
 
@@ -107,6 +109,10 @@ def main() -> None:
                     if ki == 1:  # the mask does not depend on the loss class
                         out[f"mask_{k}_{smi}"] = np.packbits(mask.numpy())
                         out[f"logits_{smi}"] = lg.numpy()
+                        if k == 4:   # hard_mining is defined upstream but never called: pinned through its own output
+                            with torch.no_grad():
+                                hard = fn.hard_mining(lg, fn.negative_masks(lg, item_idx=item_idx, pos_idx=pos_idx))
+                            out[f"hard_{k}_{smi}"] = np.packbits(hard.numpy())
         name = f"losses_B{B}_N{N}_d{d}_P{P}.npz"
         np.savez_compressed(HERE / name, **out)
         print(name, (HERE / name).stat().st_size // 1024, "KiB")

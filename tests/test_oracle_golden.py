@@ -20,7 +20,7 @@ def _load(path):
 
 
 def test_golden_present():
-    assert len(FILES) == 5
+    assert len(FILES) == 6
 
 
 @pytest.mark.parametrize("path", FILES, ids=lambda p: p.stem)
@@ -42,6 +42,21 @@ def test_masks_match_reference(path):
                 assert got[i].sum() == want[i].sum()
                 assert np.array_equal(np.sort(ref_key[i][got[i]]), np.sort(ref_key[i][want[i]])), (
                     path.stem, smi, k, i)
+
+
+@pytest.mark.parametrize("path", FILES, ids=lambda p: p.stem)
+def test_hard_mining_matches_reference(path):
+    """hard_mining (losses.py:112-132) on the reference's own logits and masks: identical sets, or differing only
+    among equal logits at the cut (torch.topk leaves ties unspecified)."""
+    z, t = _load(path)
+    B, N = t["u"].shape[0], t["v"].shape[0]
+    for smi in range(len(SIGMA_MARGIN)):
+        lg = torch.from_numpy(z[f"logits_{smi}"])
+        want = np.unpackbits(z[f"hard_4_{smi}"])[: B * N].reshape(B, N).astype(bool)
+        got = ol.hard_mining(lg, ol.negative_masks(t["item_idx"], t["pos_idx"], B), 4).numpy()
+        for i in np.nonzero((got != want).any(1))[0]:
+            assert got[i].sum() == want[i].sum()
+            assert np.array_equal(np.sort(lg[i].numpy()[got[i]]), np.sort(lg[i].numpy()[want[i]])), (path.stem, smi, i)
 
 
 @pytest.mark.parametrize("path", FILES, ids=lambda p: p.stem)
