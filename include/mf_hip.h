@@ -195,6 +195,10 @@ int mf_update_adam(float* table, float* exp_avg, float* exp_avg_sq, int64_t n_ro
  * out_scores[Q,k] fp32, out_idx[Q,k] int64 global indices (-1 / -inf padding when
  * fewer than k candidates).  k <= 64. */
 size_t mf_topk_ws_bytes(int64_t Q, int64_t N, int d, int k);
+/* Host-only geometry query: the number of catalog chunks (one workgroup column each) mf_topk would use for this shape, and
+ * the rows per chunk -- a chunk is staged through one 32-bit buffer descriptor, so rows_per_chunk * d * 4 <= ~4 GiB always
+ * holds.  0 = unsupported shape. */
+int mf_topk_chunks(int64_t Q, int64_t N, int d, int k, int64_t* rows_per_chunk);
 int mf_topk(const float* q, int64_t Q, const float* items, int64_t N, int d, int k,
             const int64_t* excl_off, const int64_t* excl_idx, int64_t idx_base, void* ws,
             size_t ws_bytes, float* out_scores, int64_t* out_idx, mf_stream_t stream);
@@ -280,6 +284,9 @@ int mf_comm_unique_id(void* out128);
 int mf_comm_create(int world, int rank, const void* id128, void** out_comm);
 int mf_comm_destroy(void* comm);
 int mf_comm_world(void* comm);
+/* where the RCCL entry points came from: "shared: ..." (the librccl torch had already mapped: RTLD_NOLOAD),
+ * "own: dlopen" (a process without one), "not loaded" */
+const char* mf_comm_source(void);
 int mf_comm_all_to_all_rows(void* comm, const void* send, const int64_t* send_rows_host, void* recv,
                             const int64_t* recv_rows_host, int64_t row_bytes, mf_stream_t stream);
 int mf_comm_all_gather(void* comm, const void* send, void* recv, int64_t bytes, mf_stream_t stream);

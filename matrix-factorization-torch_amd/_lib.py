@@ -56,6 +56,8 @@ SIGNATURES = {
     "mf_comm_create": (c_int, [c_int, c_int, c_vp, ctypes.POINTER(c_vp)]),
     "mf_comm_destroy": (c_int, [c_vp]),
     "mf_comm_world": (c_int, [c_vp]),
+    "mf_comm_source": (ctypes.c_char_p, []),
+    "mf_topk_chunks": (c_int, [c_i64, c_i64, c_int, c_int, ctypes.POINTER(c_i64)]),
     "mf_comm_all_to_all_rows": (c_int, [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64), c_i64, c_vp]),
     "mf_comm_all_gather": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mf_topk_blocked_bytes": (c_sz, [c_i64, c_int]),
@@ -70,6 +72,7 @@ SIGNATURES = {
     "mf_topk_bf3": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_vp]),
 }
 
+MF_OK, MF_EINVAL, MF_ENOSPC, MF_ELAUNCH, MF_ENOTSUP = 0, -1, -2, -3, -4       # return codes (include/mf_hip.h)
 LOSS_TARGET_I64, LOSS_ROWC, LOSS_MASKS_READY = 1, 2, 4     # flags of mf_loss_fwd / mf_loss_bwd (include/mf_hip.h)
 
 _lib: ctypes.CDLL | None = None

@@ -30,6 +30,7 @@ struct RcclApi {
     int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t);
     int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t);
     const char* (*GetErrorString)(int);
+    const char* source = "not loaded";
     bool ok = false;
 };
 
@@ -37,8 +38,24 @@ RcclApi& api() {
     static RcclApi a;
     static std::once_flag once;
     std::call_once(once, [] {
-        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        // torch has usually mapped ITS librccl already (the bootstrap process group): take that very copy -- two RCCL
+        // runtimes in one process would each own a set of proxy threads and IPC handles.  First by soname without
+        // loading (RTLD_NOLOAD), then whatever image already exports the symbols (torch may link RCCL into another of
+        // its libraries), and only in a process that has no RCCL at all a fresh dlopen.
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            if (h) { a.source = "shared: already mapped"; break; }
+        }
+        if (!h && dlsym(RTLD_DEFAULT, "ncclCommInitRank") && dlsym(RTLD_DEFAULT, "ncclSend")) {
+            h = RTLD_DEFAULT;
+            a.source = "shared: process symbols";
+        }
+        if (!h) {
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) a.source = "own: dlopen";
+        }
         if (!h) return;
         bool all = true;
         auto sym = [&](const char* n) { void* p = dlsym(h, n); all = all && p; return p; };
@@ -98,6 +115,9 @@ extern "C" int mf_comm_destroy(void* comm) {
 }
 
 extern "C" int mf_comm_world(void* comm) { return comm ? static_cast<MfComm*>(comm)->world : 0; }
+
+// where the RCCL entry points came from ("shared: ..." = the copy torch had already mapped; "own: dlopen"; "not loaded")
+extern "C" const char* mf_comm_source(void) { return api().ok ? api().source : "not loaded"; }
 
 // Direct all-to-all of row blocks: rank r receives recv_rows_host[p] rows of row_bytes bytes from every peer p (laid out in
 // peer order in `recv`) and sends send_rows_host[p] rows to it (peer order in `send`).  The counts live on the HOST (RCCL

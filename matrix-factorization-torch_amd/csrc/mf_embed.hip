@@ -470,6 +470,9 @@ static constexpr int FUSED_RANK_MAX = 512;      // all-pairs rank sort up to her
 static constexpr int FUSED_THREADS = 1024;
 static constexpr int FUSED_MAX_BITS = 9;
 static constexpr int FUSED_SCAN_UNROLL = 8;
+#ifndef FUSED_NF_ADAM
+#define FUSED_NF_ADAM 12
+#endif
 static constexpr unsigned long long FUSED_PAD = ~0ull;
 static constexpr unsigned FUSED_POS_MASK = 0xFFFFFFu;
 
@@ -509,6 +512,9 @@ __device__ __forceinline__ void fused_append(bool mine, unsigned long long key, 
 template <int D, bool ADAM, class Keys>
 __device__ __forceinline__ void fused_runs(Keys K, int m, const FusedUpdateParams& p, float bc1, float bc2) {
     constexpr int LPR = D / 4, GPW = 64 / LPR, NWAVE = FUSED_THREADS / 64;
+    // gradient rows in flight per lane group.  1024 threads leave 128 registers per lane; with Adam the row and its two
+    // moments are in flight beside the gradients (12 registers): sixteen rows spilled 20 registers, twelve fit
+    constexpr int NF = ADAM ? FUSED_NF_ADAM : 16;
     const int lane = mf_lane(), wave = threadIdx.x >> 6;
     const int grp = lane / LPR, c = lane % LPR;
     for (int pass = 0; pass < 2; ++pass) {
@@ -558,13 +564,13 @@ __device__ __forceinline__ void fused_runs(Keys K, int m, const FusedUpdateParam
                     int e = kk + 1;
                     while (e < chunk_end && (K[e] >> 24) == row) ++e;
                     int q = kk;
-                    for (; q + 16 <= e; q += 16) {                      // sixteen rows in flight, added in order
-                        f32x4 g16[16];
+                    for (; q + NF <= e; q += NF) {                      // NF rows in flight, added in order
+                        f32x4 g16[NF];
 #pragma unroll
-                        for (int j = 0; j < 16; ++j)
+                        for (int j = 0; j < NF; ++j)
                             g16[j] = reinterpret_cast<const f32x4*>(p.grad + (int64_t)((unsigned)K[q + j] & FUSED_POS_MASK) * D)[c];
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) acc += g16[j];
+                        for (int j = 0; j < NF; ++j) acc += g16[j];
                     }
                     for (; q + 4 <= e; q += 4) {
                         f32x4 g4[4];
@@ -580,21 +586,21 @@ __device__ __forceinline__ void fused_runs(Keys K, int m, const FusedUpdateParam
                 } else {
                     acc = reinterpret_cast<const f32x4*>(park)[c];
                     int q = chunk_end;
-                    while (q < m && (K[q] >> 24) == row) {              // the run's further chunks: sixteen parked sums in flight
-                        f32x4 g16[16];
+                    while (q < m && (K[q] >> 24) == row) {              // the run's further chunks: NF parked sums in flight
+                        f32x4 g16[NF];
                         int cnt = 0;
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) {
+                        for (int j = 0; j < NF; ++j) {
                             const int qq = q + j * RUN_CHUNK;
                             const bool in_run = qq < m && (K[qq < m ? qq : q] >> 24) == row;
                             g16[j] = reinterpret_cast<const f32x4*>(p.partial + (int64_t)((unsigned)K[in_run ? qq : q] & FUSED_POS_MASK) * D)[c];
                             cnt += in_run ? 1 : 0;      // (a run is contiguous: the chunks in it are the first cnt)
                         }
 #pragma unroll
-                        for (int j = 0; j < 16; ++j)
+                        for (int j = 0; j < NF; ++j)
                             if (j < cnt) acc += g16[j];
-                        q += 16 * RUN_CHUNK;
-                        if (cnt < 16) break;
+                        q += NF * RUN_CHUNK;
+                        if (cnt < NF) break;
                     }
                     apply = true;
                 }

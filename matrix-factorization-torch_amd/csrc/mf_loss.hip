@@ -183,7 +183,10 @@ __global__ __launch_bounds__(64) void prep_kernel(PrepParams p) {
             const f32x4* pv = reinterpret_cast<const f32x4*>(p.v + i * D);
             const f32x4* pu = reinterpret_cast<const f32x4*>(p.u + (hu ? i : 0) * D);     // (no user: row 0 is read and dropped)
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+            // batches of 16 loads; at most 4 batches (64 registers x 4) are in flight at once: fully unrolled, d = 256
+            // asked for 8 batches' worth of registers and spilled 396 of them
+            constexpr int PREP_UNROLL = D / 32 <= 4 ? (D / 32 > 0 ? D / 32 : 1) : 2;
+#pragma unroll PREP_UNROLL
             for (int g0 = 0; g0 < D / 8; g0 += 4) {
                 f32x4 va[8], ua[8];
 #pragma unroll
@@ -1417,6 +1420,8 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
         });
         dv_fix_to_f32_kernel<<<dim3((unsigned)((N * d + 255) / 256)), 256, 0, s>>>(w.dvfix, N * d, dv);
     } else {
+        if ((size_t)w.tps_u * 32 * d * 4 > MF_SRD_MAX_BYTES || (size_t)w.tps_v * 32 * d * 4 > MF_SRD_MAX_BYTES)
+            return mf_set_error(MF_ENOTSUP, "mf_loss_bwd: a sweep's share of the batch exceeds 4 GiB (buffer descriptor)");
         BwdParams bp{u, v, w.rowc, grad_out, w.stash, w.gstash, w.dpart, w.rpart, B, N, w.Bp, w.Np, w.NT, 0, 0};
         MF_DISPATCH_D(d, {
             bp.YT = w.NT; bp.tps = w.tps_u;

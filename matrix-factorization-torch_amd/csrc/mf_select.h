@@ -620,6 +620,14 @@ static inline SelectPlan mf_select_plan(int64_t nX, int64_t nY, int d, int k) {
     }
     if (want > s.YT) want = s.YT;
     if (want < 1) want = 1;
+    // a chunk is staged through ONE 32-bit buffer descriptor based at its first row (mf_stream.h): its tiles must fit
+    // MF_SRD_MAX_BYTES, or rows past that would arrive as zeros -- unmasked, since they are below nY
+    {
+        const int64_t tile_bytes = 32ll * d * 4, max_tpc = (int64_t)0xFFF00000ll / tile_bytes;
+        const int64_t min_chunks = (s.YT + max_tpc - 1) / max_tpc;
+        if (min_chunks > want) want = (int)(min_chunks < s.YT ? min_chunks : s.YT);
+        if (min_chunks > 128) s.ok = false;          // (a catalog beyond 512 GiB: sharded long before)
+    }
     s.tpc = (s.YT + want - 1) / want;
     s.nchunk = (s.YT + s.tpc - 1) / s.tpc;
     s.nsets = s.nchunk * s.nsub;

@@ -68,7 +68,9 @@ __device__ __forceinline__ int mf_wave_id() { return __builtin_amdgcn_readfirstl
 // the compiler otherwise emits costs ~25 VALU instructions per piece, 3 % of the matrix pipe's time) and no
 // ragged-tile branch: the hardware range check covers voffset + soffset at dword granularity (measured:
 // tools/lab/srd_bounds.hip), so rows past nY arrive as ZEROS (the kernels mask them anyway).  The descriptor
-// starts at the workgroup's first row, so offsets stay below 4 GiB for any catalog.
+// starts at the workgroup's first row and covers at most MF_SRD_MAX_BYTES: every HOST plan must keep a workgroup's
+// share of Y (tiles per chunk x 32 x row bytes) within that -- mf_select_plan, bf3_plan's check and the loss sweeps'
+// checks do; a row beyond it would arrive as zeros while still counting as a real row.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t mf_rsrc_t;
 #else

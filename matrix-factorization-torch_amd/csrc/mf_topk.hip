@@ -94,6 +94,15 @@ extern "C" size_t mf_topk_ws_bytes(int64_t Q, int64_t N, int d, int k) {
     return topk_ws(nullptr, Q, N, d, k).total;
 }
 
+// host-only geometry query (tests, sizing): how mf_topk would cut a catalog for Q queries
+extern "C" int mf_topk_chunks(int64_t Q, int64_t N, int d, int k, int64_t* rows_per_chunk) {
+    if (Q <= 0 || N <= 0 || k <= 0 || !mf_width_ok(d)) return 0;
+    const SelectPlan pl = mf_select_plan(Q, N, d, k);
+    if (!pl.ok) return 0;
+    if (rows_per_chunk) *rows_per_chunk = (int64_t)pl.tpc * 32;
+    return pl.nchunk;
+}
+
 // one wave per query: the row's candidate list -> ordered top-k
 __global__ __launch_bounds__(64) void topk_merge_cand_kernel(const unsigned long long* __restrict__ cand,
                                                              const int32_t* __restrict__ cand_cnt, int rowcap, int k,

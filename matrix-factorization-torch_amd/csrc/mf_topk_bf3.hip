@@ -216,13 +216,17 @@ __global__ __launch_bounds__(256, 2) void bf3_scan_kernel(Bf3Scan p) {
     uint32_t aoff[XT], astep = 0u;
     if (EXCL) {
         // exclusion words of a unit: lane (c, j) fetches the word of query x0 + 32 xt + c for tile j of the unit (4-byte DMA)
+        // the descriptor starts at the first query of this WORKGROUP (blockIdx only: provably uniform), so a lane's offset
+        // stays below 128 XT queries x NT words whatever Q is (the host refuses catalogs beyond that: bf3_excl_fits)
+        const int64_t xb0 = (int64_t)blockIdx.y * G::NW * (32 * XT);
 #pragma unroll
         for (int xt = 0; xt < XT; ++xt)
-            aoff[xt] = h < ST ? (uint32_t)((((int64_t)(x0 + 32 * xt + c)) * p.NT + u0 * ST + h) * 4) : MF_SRD_DEAD;
+            aoff[xt] = h < ST ? (uint32_t)((((int64_t)(x0 - xb0 + 32 * xt + c)) * p.NT + u0 * ST + h) * 4) : MF_SRD_DEAD;
         astep = h < ST ? (uint32_t)(ST * 4) : 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint64_t ab = ((uint64_t)p.NT * (uint64_t)p.Qp + 64u) * 4u;
-        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.exclW), 0, (int)(ab > MF_SRD_MAX_BYTES ? MF_SRD_MAX_BYTES : ab), 0x00020000);
+        const uint64_t ab = ((uint64_t)p.NT * (uint64_t)(p.Qp - xb0) + 64u) * 4u;
+        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.exclW + xb0 * p.NT), 0,
+                                                  (int)(ab > MF_SRD_MAX_BYTES ? MF_SRD_MAX_BYTES : ab), 0x00020000);
 #else
         (void)arsrc; (void)aoff;
 #endif
@@ -687,10 +691,16 @@ extern "C" int mf_topk_bf3(const float* q, int64_t Q, const float* items, const 
     if (N >= (1ll << 31) || idx_base < 0 || idx_base + N > (1ll << 32))
         return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: item indices must fit 32 bits");
     if ((excl_off == nullptr) != (excl_idx == nullptr)) return mf_set_error(MF_EINVAL, "mf_topk_bf3: excl_off/excl_idx mismatch");
+    // geometry limits first (host arithmetic only: nothing below this point may run for an unsupported shape)
+    const Bf3Plan plan = bf3_plan(Q, N, d);
+    if ((uint64_t)plan.upc * plan.ST * 32 * d * 2 > MF_SRD_MAX_BYTES) return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: chunk beyond 4 GiB");
+    // exclusion words are staged through a 32-bit buffer descriptor based at a workgroup's first query: its 128 XT query
+    // rows of NT words must fit (NT < ~4 M tiles: 134 M catalog rows per shard)
+    if (excl_off && ((uint64_t)plan.NT * (uint64_t)(128 * plan.XT) + 64u) * 4u > MF_SRD_MAX_BYTES)
+        return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: exclusion words of one query block beyond 4 GiB (use mf_topk)");
     if (ws_bytes < mf_topk_bf3_ws_bytes(Q, N, d, k)) return mf_set_error(MF_ENOSPC, "mf_topk_bf3: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Bf3Ws w = bf3_ws(ws, Q, N, d);
-    if ((uint64_t)w.plan.upc * w.plan.ST * 32 * d * 2 > MF_SRD_MAX_BYTES) return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: chunk beyond 4 GiB");
     Bf3Index ix = bf3_index(const_cast<void*>(index), N, d);
     const bool excl = excl_off != nullptr;
     if (excl) bf3_excl_rows_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.plan.NT, w.exclW, q, d, w.xfrag);

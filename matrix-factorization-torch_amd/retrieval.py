@@ -129,10 +129,14 @@ class ItemIndex:
             return scores, rows
         if path == "bf16" or (path == "auto" and nq >= self.BF16_MIN_Q and n >= self.BF16_MIN_N and d >= 64):
             ws = self._workspace(("bf16", nq, top_k), lib.mf_topk_bf3_ws_bytes(nq, n, d, top_k))
-            _lib.check(lib.mf_topk_bf3(q.data_ptr(), nq, self.embeddings.data_ptr(), self.bf16_index().data_ptr(), n, d, top_k,
-                                       _lib.ptr(off), _lib.ptr(ids), self.idx_base, ws.data_ptr(), ws.numel(), scores.data_ptr(),
-                                       rows.data_ptr(), _lib.stream_ptr()))
-            return scores, rows
+            rc = lib.mf_topk_bf3(q.data_ptr(), nq, self.embeddings.data_ptr(), self.bf16_index().data_ptr(), n, d, top_k,
+                                 _lib.ptr(off), _lib.ptr(ids), self.idx_base, ws.data_ptr(), ws.numel(), scores.data_ptr(),
+                                 rows.data_ptr(), _lib.stream_ptr())
+            # a shape outside the prefilter's descriptor limits (MF_ENOTSUP, decided on the host before any launch) goes
+            # to the fp32 tile engine when the caller left the choice to us; an explicit path="bf16" raises
+            if not (rc == _lib.MF_ENOTSUP and path == "auto"):
+                _lib.check(rc)
+                return scores, rows
         ws = self._workspace(("tile", nq, top_k), lib.mf_topk_ws_bytes(nq, n, d, top_k))
         _lib.check(lib.mf_topk(q.data_ptr(), nq, self.embeddings.data_ptr(), n, d, top_k, _lib.ptr(off), _lib.ptr(ids),
                                self.idx_base, ws.data_ptr(), ws.numel(), scores.data_ptr(), rows.data_ptr(),

@@ -33,6 +33,54 @@ def test_workspace_queries_need_no_gpu(mf):
     assert lib.mf_update_ws_bytes(16384, 128) >= 16384 * 128 * 4
 
 
+def test_descriptor_limits_are_enforced_on_the_host(mf):
+    """Tiles are staged through 32-bit buffer descriptors (csrc/mf_stream.h): a workgroup's share of a catalog, and the
+    exclusion words of a query block, must stay below ~4 GiB or rows would silently arrive as zeros.  Both
+    limits are decided by host arithmetic before any launch, so they are testable without a GPU."""
+    import ctypes
+
+    lib = mf._lib.lib()
+    rows = ctypes.c_int64()
+    # fp32 tile engine: every chunk of every plan fits one descriptor, also when few chunks would do for occupancy
+    for q, n, d in ((1024, 62_423, 128), (65_536, 8_400_000, 256), (8_192, 100_000_000, 128), (1, 2_000_000_000, 32)):
+        chunks = lib.mf_topk_chunks(q, n, d, 20, ctypes.byref(rows))
+        assert chunks >= 1 and rows.value * chunks >= n
+        assert rows.value * d * 4 <= 0xFFF00000, (q, n, d, chunks, rows.value)
+    assert lib.mf_topk_chunks(65_536, 8_400_000, 256, 20, ctypes.byref(rows)) >= 3       # one chunk would be 8 GiB
+    # bf16 prefilter with exclusion lists: a query block's words beyond 4 GiB are refused (MF_ENOTSUP), nothing is launched
+    fake = ctypes.c_void_p(0x1000)           # never dereferenced: the geometry check comes first
+    n_big = 150_000_000                      # 4.7 M tiles x 256 queries x 4 bytes > 4 GiB
+    rc = lib.mf_topk_bf3(fake, 8192, fake, fake, n_big, 64, 20, fake, fake, 0, fake, ctypes.c_size_t(2**62), fake, fake, None)
+    assert rc == mf._lib.MF_ENOTSUP and b"exclusion words" in lib.mf_last_error()
+
+
+def test_no_product_kernel_spills():
+    """vgpr_spill_count == 0 and no scratch for every kernel of the training step, its set-up and the retrieval paths
+    (read from the code objects' notes: tools/kernel_resources.py).  Spills in update_fused_kernel<*, Adam> and
+    prep_kernel<256> went unnoticed for a round."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("kernel_resources", ROOT / "tools" / "kernel_resources.py")
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    res = kr.kernel_resources()
+    assert len(res) > 100
+    watched = ("loss_fwd_dense_kernel", "loss_bwd_dense_kernel", "select_kernel", "select_seed_kernel", "gather_rows_kernel",
+               "gather_hashed_kernel", "update_fused_kernel", "update_rows_kernel", "prep_kernel", "finish_kernel", "sum_parts_kernel",
+               "hits_kernel", "gt_insert_kernel", "mask_sweep_kernel", "mined_rows_kernel", "mined_bwd_kernel", "topk_small_scan_kernel",
+               "topk_small_select_kernel", "bf3_scan_kernel", "bf3_bound_kernel", "step_small_kernel")
+    seen = set()
+    for name, r in res.items():
+        hit = [w for w in watched if w in name]
+        if not hit:
+            continue
+        seen.update(hit)
+        # (SGPR "spills" go to VGPR lanes -- v_writelane / v_readlane, no memory: the one-query scan keeps a whole query
+        # in scalar registers on purpose -- so the bar is: no VGPR spill and not a byte of scratch)
+        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
+    assert {"loss_fwd_dense_kernel", "loss_bwd_dense_kernel", "update_fused_kernel", "prep_kernel", "bf3_scan_kernel"} <= seen
+
+
 def test_no_cpu_fallback(mf):
     """The product path raises on CPU tensors instead of computing somewhere else."""
     fn = mf.losses.InfomationNoiseContrastiveEstimationLoss()
