@@ -15,6 +15,14 @@ timed region starts.
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment: this process starts the N ranks itself, as FRESH child
+processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), before it has made any GPU call, waits for them
+and exits with their worst code.  Under ``torch.distributed.run`` the ranks exist already; a WORLD_SIZE that differs from
+``--gpus`` is an error (exit 2), never a silently smaller job.  The line reports ``n_gpus``, ``rccl_ranks`` (the size of the
+C-side RCCL communicator, ``mf_comm_world``) and ``transport`` ("mf_comm": RCCL called from libmf_hip.so on the compute
+stream; "torch": torch.distributed's collectives).  ``MF_BENCH_DRY_RUN=1`` rehearses the launch / barrier / max-over-ranks /
+JSON plumbing on CPU (gloo, a stub step, no kernels): tests/test_host_cpu.py.
+
 Whenever this part has idled for a few milliseconds the three sweeps run 13 % slower and recover over ~25 launches
 (constant sclk / mclk; tools/ramp_probe.py, ramp_probe2.py, clock_probe.py).  `spin_up` therefore queues ~60 ms of
 the leg's dominant kernels on scratch data right in front of the W warm-up steps (no benchmark state is touched),
@@ -409,11 +417,81 @@ def topk_small_leg(mf, lib, index, device, dim: int, rank: int) -> dict:
     return out
 
 
+def spawn_ranks(args) -> int:
+    """``--gpus N`` without a launcher: start the N ranks as fresh children of this (GPU-untouched) process."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    dry = os.environ.get("MF_BENCH_DRY_RUN") == "1"
+    if not dry and torch.cuda.device_count() < n:          # (counting devices does not initialise the GPU)
+        print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MF_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, str(pathlib.Path(__file__).resolve()), *sys.argv[1:]], env=env))
+    worst, left = 0, list(procs)
+    while left:
+        for pr in list(left):
+            try:
+                rc = pr.wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            left.remove(pr)
+            if rc != 0:
+                worst = worst or rc
+                for other in left:                         # the others would wait in a collective for ever
+                    other.terminate()
+    return worst
+
+
+def dry_run(args, world: int, rank: int) -> None:
+    """The launch contract on CPU (no GPU, no kernels): gloo group, W stub warm-up steps, K stub steps between barriers,
+    max over ranks, one JSON line from rank 0 with the fields the driver and the tests read."""
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if dist.get_world_size() != args.gpus:
+        raise SystemExit(2)
+    step = lambda i: time.sleep(0.001)          # noqa: E731
+    for i in range(args.warmup):
+        step(i)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ranks = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(ranks)
+    if rank == 0:
+        print(json.dumps({"metric": "train pairs/sec + full-catalog top-k queries/sec, ML-25M d=128", "value": 0.0, "unit": "pairs/s",
+                          "n_gpus": int(ranks), "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t) / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
+                          "config": {"workload": "dry run: launch / barrier / reduction plumbing only", "parallelism": f"dp{world}"},
+                          "rccl_ranks": None, "transport": "dry-run (gloo, no kernels)"}), flush=True)
+    dist.destroy_process_group()
+
+
 def main() -> None:
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))             # nothing above has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("MF_BENCH_DRY_RUN") == "1":
+        dry_run(args, world, rank)
+        return
     dist_on = world > 1 or os.environ.get("MF_BENCH_FORCE_DIST") == "1"   # the override rehearses the sharded path on one GPU
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -423,6 +501,9 @@ def main() -> None:
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.distributed.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
+        if torch.distributed.get_world_size() != args.gpus:
+            print(f"bench.py: process group of {torch.distributed.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
     mf = importlib.import_module("matrix-factorization-torch_amd")
     lib = mf._lib.lib()
     B, Q, K, W = args.batch, args.queries, args.steps, args.warmup
@@ -433,11 +514,16 @@ def main() -> None:
     if dist_on:
         n_batches = min(K + W, 8)
         batches, _ = make_batches(n_batches, B, seed=1000 + rank, device=device)
-        trainer = mf.distributed.ShardedTrainer(mf, device, args.optimizer, args.num_negatives,
-                                                num_users=NUM_USERS, num_items=NUM_ITEMS, dim=DIM, logq=logq_table(device))
-        span_u = trainer.user_hi - trainer.user_lo          # pairs are partitioned by user shard
-        for b in batches:
-            b["user"] = trainer.user_lo + b["user"] % span_u
+        # default: example-sharded batches (any user on any rank, as the reference's loader deals examples,
+        # xfmr_rec/data/lightning.py:109) through the fused user + item exchange; MF_BENCH_USER_MODE=partitioned times the
+        # user-partitioned stream instead (user rows never travel)
+        user_mode = os.environ.get("MF_BENCH_USER_MODE", "routed")
+        trainer = mf.distributed.ShardedTrainer(mf, device, args.optimizer, args.num_negatives, num_users=NUM_USERS,
+                                                num_items=NUM_ITEMS, dim=DIM, logq=logq_table(device), user_mode=user_mode)
+        if user_mode == "partitioned":
+            span_u = trainer.user_hi - trainer.user_lo
+            for b in batches:
+                b["user"] = trainer.user_lo + b["user"] % span_u
         # the sharded step prefetches the exchange plan of the batch after it (ids are known ahead)
         run_step = lambda j: trainer.step(batches[j % n_batches], next_b=batches[(j + 1) % n_batches])  # noqa: E731
         # everything that would stall the first sharded step happens before the spin-up: RCCL's lazy
@@ -453,6 +539,7 @@ def main() -> None:
         lib.mf_timing_enable(TIME_EVERY)
         dt_train = timed(lambda i: run_step(W + i), K, dist_on)
         lib.mf_timing_enable(0)
+        trainer.finish()                        # deferred error flags (id range / exchange capacity) of the timed steps
         spans = {n: kernel_span(lib, n)[0] for n in TRAIN_KERNELS}
         spans = {k: v for k, v in spans.items() if v}
     else:
@@ -575,7 +662,9 @@ def main() -> None:
             "config": {"workload": "C3: MovieLens-25M shape (162,541 users x 62,423 items), d=128, InfoNCE + logQ, "
                                    f"num_negatives={args.num_negatives}, row-{args.optimizer} update",
                        "batch_per_gpu": B, "items_per_step": N, "pos_pad": POS_PAD,
-                       "parallelism": f"dp{world}" + (" + item rows sharded" if dist_on else "")},
+                       "parallelism": f"dp{world}" + (f" + both tables row-sharded, {trainer.user_mode} users" if dist_on else "")},
+            "rccl_ranks": trainer.comm.rccl_ranks if dist_on else None,
+            "transport": trainer.comm.transport if dist_on else "none (one process, one GPU)",
             "cold_ms_per_step": None if cold_ms is None else round(cold_ms, 4),
             "roofline": train_roof,
             "topk": {"value": round(qps, 1), "unit": "queries/s", "ms_per_step": round(dt_topk / K * 1e3, 4),

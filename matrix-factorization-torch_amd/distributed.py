@@ -1,28 +1,34 @@
 """Multi-GPU hot path: one process per GPU; exchanges by RCCL over xGMI on the compute stream (``RcclComm``,
 ``mf_comm_*``), or by ``torch.distributed`` (``TorchComm``: ``gloo`` in the CPU tests).
 
-The reference has no explicit collective anywhere (implicit DDP of a
-dense BERT); the sharding below is the north-star's and our design:
+The reference has no explicit collective anywhere (implicit DDP of a dense BERT, examples dealt to the
+ranks by ``sharding_filter``, xfmr_rec/data/lightning.py:109; one worker by default, xfmr_rec/ray.py:40); the sharding
+below is the north-star's and our design:
 
-* **item table row-sharded, rows dealt round-robin** (rank r owns rows ``r, r + G, r + 2G, ...``):
-  item popularity is heavy-tailed and id order often follows it, so contiguous blocks would send most
-  of every batch to one owner (its gather, sort and update then set the step time of the whole job);
-  **user table sharded in contiguous blocks** and the training pairs partitioned by user shard, so
-  user rows never travel;
+* **both tables row-sharded, rows dealt round-robin** (rank r owns rows ``r, r + G, r + 2G, ...``): item popularity is
+  heavy-tailed and id order often follows it, so contiguous blocks would send most of every batch to one owner (its
+  gather, sort and update then set the step time of the whole job).  A rank's batch may hold ARBITRARY users and items
+  (example-sharded data, like the reference's loader): every id is routed to its owner and back (``RowExchange``).
+  ``user_mode="partitioned"`` keeps the round-2 fast path -- the user table in contiguous blocks and the training pairs
+  partitioned by user shard, so user rows never travel -- and a batch that breaks that promise RAISES (it used to gather
+  a silent zero row);
 * **hash / bloom towers** (BASELINE config 5: 10 M users x 100 M items do not get a row each): both
   BUCKET tables are dealt round-robin and every id's ``num_hashes`` bucket rows go through the same
-  exchange as item rows (an id's buckets live on arbitrary ranks, users included);
+  exchange (an id's buckets live on arbitrary ranks);
 * every shard is **initialised on its own device** from a counter-based generator (``mf_init_rows``: a
   pure function of (seed, global row, column)) -- no rank ever holds a whole table (102 GB for
   100 M x 256) and the values do not depend on the number of ranks;
-* **training step**: each rank needs the item rows of its own batch (B positives + B
-  sampled negatives).  Rows are fetched from their owners with one all-to-all of ids
-  and one all-to-all of rows (8 MB per rank at B = 8192, d = 128 -- latency-bound on
-  xGMI, so direct all-to-all, never a ring all-reduce of a dense table), the score /
-  loss kernels run on the local B x 2B block (in-batch negatives stay local, exactly
-  like the reference, which has no cross-rank gather), item-row gradients go back to
-  their owners with one more all-to-all and each owner applies ONE sparse update per
+* **training step**: each rank needs the rows of its own batch (B users, B positives + B sampled negatives).  Rows are
+  fetched from their owners with one all-to-all of ids and one all-to-all of rows per table (8 MB per rank at B = 8192,
+  d = 128 -- latency-bound on xGMI, so direct all-to-all, never a ring all-reduce of a dense table: the north-star's
+  "all-reduce of user gradients" would move the whole 83 MB user table every step), the score / loss kernels run on the
+  local B x 2B block (in-batch negatives stay local, exactly like the reference, which has no cross-rank gather),
+  row gradients go back to their owners with one more all-to-all and each owner applies ONE sparse update per table and
   step (duplicates summed in (rank, batch) order: deterministic);
+* **exchange plans**: RCCL wants the per-peer row counts on the host.  A plan built AHEAD (``prefetch``: the ids of the
+  next batch are known, the host read happens beside the current step's sweeps) uses exact counts; a step whose plan
+  was not prefetched uses **capacity-padded** exchanges -- equal splits of ``capacity`` rows per peer, padding ids -1,
+  which the gather answers with zeros and the update skips -- and never reads anything back (no host sync);
 * **retrieval**: queries are all-gathered, every rank scans ITS shard for all queries
   (``mf_topk`` on local rows, mapped to global rows before they leave), the partial top-k travel back to the query's rank by
   all-to-all and are merged exactly (``mf_topk_merge``): bit-identical to the
@@ -30,7 +36,7 @@ dense BERT); the sharding below is the north-star's and our design:
 
 Local compute goes through an ``ops`` object (default :class:`HipOps`) and the exchanges through a ``comm``
 object, so that the routing logic can be exercised on CPU with ``gloo`` by injecting the oracle.
-No scaling curve has been measured: only one-GPU boxes were available.
+No scaling curve has been measured by the builder: only one-GPU boxes were available.
 """
 from __future__ import annotations
 
@@ -47,6 +53,9 @@ from . import _lib
 class TorchComm:
     """Exchanges through ``torch.distributed`` (the CPU tests' ``gloo``; also works with ``nccl``, at two
     cross-stream joins per collective)."""
+
+    transport = "torch"
+    rccl_ranks = None
 
     def __init__(self) -> None:
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
@@ -75,20 +84,32 @@ class TorchComm:
 class RcclComm:
     """Exchanges by RCCL called from ``libmf_hip.so`` on the CURRENT stream (``mf_comm_*``): no second stream, no
     event joins.  The communicator is bootstrapped through the already initialised ``torch.distributed`` group
-    (rank 0's 128-byte id is broadcast as a Python object)."""
+    (rank 0's 128-byte id is broadcast as a Python object, together with rank 0's verdict on getting it: a rank
+    that cannot create the id must not leave the others waiting in another collective)."""
+
+    transport = "mf_comm"
 
     def __init__(self, device) -> None:
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         lib = _lib.lib()
         buf = ctypes.create_string_buffer(128)
+        err = ""
         if self.rank == 0:
-            _lib.check(lib.mf_comm_unique_id(buf))
-        box = [bytes(buf.raw)]
+            rc = lib.mf_comm_unique_id(buf)
+            if rc != 0:
+                err = lib.mf_last_error().decode()
+        box = [bytes(buf.raw), err]
         dist.broadcast_object_list(box, src=0, device=torch.device(device))
+        if box[1]:
+            raise _lib.MfHipError(f"rank 0 could not create an RCCL id: {box[1]}")
         handle = ctypes.c_void_p()
         with torch.cuda.device(device):
             _lib.check(lib.mf_comm_create(self.world, self.rank, ctypes.create_string_buffer(box[0], 128), ctypes.byref(handle)))
         self.handle = handle
+
+    @property
+    def rccl_ranks(self) -> int:
+        return int(_lib.lib().mf_comm_world(self.handle))
 
     def __del__(self) -> None:
         try:
@@ -123,13 +144,28 @@ class RcclComm:
         return self.rows(x, [per] * self.world, [per] * self.world)
 
 
+def _all_agree(ok: bool, device) -> bool:
+    """True iff ``ok`` on EVERY rank (one tiny all-reduce through torch.distributed: every rank must call it at the same point)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item()) == 1
+
+
 def default_comm(device):
     """RCCL on the compute stream for GPU tensors (``RcclComm``), ``torch.distributed`` otherwise.
 
     The C-side communicator has only ever run on ONE rank where this was built (one GPU per box), so at world > 1 it is
-    checked before it is trusted: every rank exchanges a small all-to-all and an all-gather through it and compares with
-    ``torch.distributed``'s answer; unless ALL ranks agree the job uses ``TorchComm`` -- the same RCCL collectives issued by
-    torch, a few cross-stream joins slower, never a CPU path.  ``MF_COMM=rccl`` / ``torch`` forces one or the other."""
+    checked before it is trusted, and every stage is AGREED on by all ranks before the next collective is entered (a rank
+    that raised while the others sat in a different collective would hang the job -- ADVICE r2):
+
+    1. every rank reports whether ``libmf_hip.so`` found RCCL at all (``mf_comm_source``); unless all did, the whole job
+       uses ``TorchComm`` -- the same RCCL collectives issued by torch, a few cross-stream joins slower, never a CPU path;
+    2. rank 0's id travels together with rank 0's verdict on creating it; all ranks agree on the outcome of
+       ``ncclCommInitRank``;
+    3. a small all-to-all of counts, an all-gather and a ragged all-to-all of rows are each compared with
+       ``torch.distributed``'s answer and agreed on one by one.
+    A failure in 2 or 3 leaves RCCL in an unknown state: it is raised on EVERY rank (the launcher sees a non-zero exit)
+    instead of being papered over.  ``MF_COMM=rccl`` / ``torch`` forces one or the other without the checks."""
     import os
     import warnings
 
@@ -140,28 +176,39 @@ def default_comm(device):
         return TorchComm()
     if mode == "rccl" or dist.get_world_size() == 1:
         return RcclComm(device)
-    ok, comm, why = 1, None, ""
+    source = _lib.lib().mf_comm_source().decode()
+    if not _all_agree(source != "not loaded", device):
+        warnings.warn(f"RcclComm not used (librccl not loadable from libmf_hip.so on some rank; here: {source}); "
+                      "using torch.distributed collectives on every rank", stacklevel=2)
+        return TorchComm()
+    comm, why = None, ""
     try:
-        comm = RcclComm(device)
-        w, r = comm.world, comm.rank
-        ref = TorchComm()
-        send = torch.arange(w, dtype=torch.int64, device=device) * 1000 + r
-        counts = [(r + j) % 3 + 1 for j in range(w)]                        # rows this rank sends to rank j
-        recv_counts = [(j + r) % 3 + 1 for j in range(w)]                   # rows rank j sends here
-        rows = torch.arange(sum(counts) * 4, dtype=torch.float32, device=device).reshape(-1, 4) + 100.0 * r
-        same = (torch.equal(comm.counts(send), ref.counts(send)) and torch.equal(comm.gather(send), ref.gather(send))
-                and torch.equal(comm.rows(rows, counts, recv_counts), ref.rows(rows, counts, recv_counts)))
-        if not same:
-            ok, why = 0, "self-test mismatch"
-    except Exception as e:  # noqa: BLE001  (whatever the C side or RCCL raised: fall back together)
-        ok, why = 0, repr(e)
-    flag = torch.tensor([ok], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 1:
-        return comm
-    warnings.warn(f"RcclComm not used ({why or 'another rank failed its self-test'}); falling back to torch.distributed collectives",
-                  stacklevel=2)
-    return TorchComm()
+        comm = RcclComm(device)                 # (its broadcast carries rank 0's verdict: all ranks raise, or none)
+    except Exception as e:  # noqa: BLE001
+        why = f"communicator: {e!r}"
+    if not _all_agree(comm is not None, device):
+        raise _lib.MfHipError(f"RCCL communicator could not be created on every rank ({why or 'another rank failed'})")
+    w, r = comm.world, comm.rank
+    ref = TorchComm()
+    send = torch.arange(w, dtype=torch.int64, device=device) * 1000 + r
+    counts = [(r + j) % 3 + 1 for j in range(w)]                        # rows this rank sends to rank j
+    recv_counts = [(j + r) % 3 + 1 for j in range(w)]                   # rows rank j sends here
+    rows = torch.arange(sum(counts) * 4, dtype=torch.float32, device=device).reshape(-1, 4) + 100.0 * r
+    for name, mine, theirs in (("counts", lambda: comm.counts(send), lambda: ref.counts(send)),
+                               ("gather", lambda: comm.gather(send), lambda: ref.gather(send)),
+                               ("rows", lambda: comm.rows(rows, counts, recv_counts), lambda: ref.rows(rows, counts, recv_counts))):
+        ok, why = True, ""
+        try:
+            got = mine()
+        except Exception as e:  # noqa: BLE001
+            ok, why, got = False, repr(e), None
+        want = theirs()                          # every rank enters torch's collective, whatever happened above
+        if ok and not torch.equal(got, want):
+            ok, why = False, "mismatch against torch.distributed"
+        if not _all_agree(ok, device):
+            raise _lib.MfHipError(f"RcclComm self-test '{name}' failed ({why or 'on another rank'}); set MF_COMM=torch to run "
+                                  "on torch.distributed's collectives")
+    return comm
 
 
 # ----------------------------------------------------------------------- local compute ---
@@ -241,19 +288,17 @@ class HipOps:
                                           hyper["eps"], hyper["weight_decay"], ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
 
     def topk(self, queries, items, k, exclude_csr, idx_base):
-        # one ItemIndex per shard tensor: its derived copies (bf16 rows, blocked rows) and workspaces are built once.
-        # Like the reference's index (a table written by get_index), it is a SNAPSHOT: drop_indexes() after the rows change.
-        key = (items.data_ptr(), tuple(items.shape), int(idx_base))
-        cache = self.__dict__.setdefault("_indexes", {})
-        index = cache.get(key)
-        if index is None:
-            if len(cache) >= 4:
-                cache.clear()
-            index = cache[key] = self.mf.retrieval.ItemIndex(items, idx_base=idx_base)
-        return index.search(queries, k, exclude_csr=exclude_csr)
+        # ONE ItemIndex for the shard tensor last searched: its derived copies (bf16 rows, blocked rows) and workspaces are
+        # built once.  The entry holds the source tensor itself (so its address cannot be handed to another tensor while
+        # the entry lives) and its version counter: an in-place change of the rows rebuilds the index.  Like the
+        # reference's index (a table written by get_index) it is a SNAPSHOT of the rows at build time.
+        hit = self.__dict__.get("_index")
+        if hit is None or hit[0] is not items or hit[1] != items._version or hit[2] != int(idx_base):
+            hit = self._index = (items, items._version, int(idx_base), self.mf.retrieval.ItemIndex(items, idx_base=idx_base))
+        return hit[3].search(queries, k, exclude_csr=exclude_csr)
 
     def drop_indexes(self) -> None:
-        self.__dict__.pop("_indexes", None)
+        self.__dict__.pop("_index", None)
 
     def merge(self, part_scores, part_rows, k):
         return self.mf.retrieval.merge_topk(part_scores, part_rows, k)
@@ -295,54 +340,130 @@ def cyclic_rows(n_rows: int, world: int, rank: int) -> int:
 
 
 class RowExchange:
-    """Routes a list of global row ids to their owning ranks and back (rows dealt round-robin:
-    owner = id mod world, local row = id div world)."""
+    """Routes a list of row requests to their owning ranks and back (rows dealt round-robin: owner = id mod world,
+    local row = id div world).  ``ids`` are the global rows; ``payload`` (default: the ids) is what travels to the owner
+    -- e.g. ``id << 1 | table`` when one exchange serves two tables.
 
-    def __init__(self, ids: torch.Tensor, comm, ops=None) -> None:
+    ``capacity=None``: exact per-peer counts (RCCL needs them on the HOST: one host sync, which ``ShardedTrainer.prefetch``
+    moves off the critical path).  ``capacity=C``: every peer gets a fixed block of C slots (padding payload -1), so
+    nothing is read back; ``overflow`` is a device flag that is set when some peer's share did not fit (never for
+    C >= len(ids)) -- the exchange is then incomplete and the caller must treat the step as invalid."""
+
+    def __init__(self, ids: torch.Tensor, comm, ops=None, capacity: int | None = None, payload: torch.Tensor | None = None) -> None:
         self.comm, world = comm, comm.world
         self.ids = ids                                               # keeps the routed ids (and their storage) alive
+        n = ids.numel()
+        payload = ids if payload is None else payload
         owner = torch.remainder(ids, world)
         # batch position of every sent slot: a stable sort by owner (on the GPU the library's rank sort -- three small
         # launches -- instead of torch's radix sort + bincount: ~250 us of kernels on the plan stream at n = 16,384)
         if ops is not None and hasattr(ops, "stable_argsort") and ids.is_cuda:
             self.order, sorted_owner = ops.stable_argsort(owner)
             bounds = torch.searchsorted(sorted_owner, torch.arange(world + 1, device=ids.device, dtype=sorted_owner.dtype))
-            send = bounds[1:] - bounds[:-1]
         else:
             self.order = torch.argsort(owner, stable=True)
-            send = torch.bincount(owner, minlength=world)
-        recv = comm.counts(send)
-        # RCCL needs the split sizes on the host: the one host sync of the step
-        self.send_counts, self.recv_counts = send.tolist(), recv.tolist()
-        # rows of MY shard that the others (and I) asked for, grouped by requesting rank
-        self.local_ids = torch.div(comm.rows(ids[self.order], self.send_counts, self.recv_counts), world, rounding_mode="floor")
+            sorted_owner = owner[self.order]
+            bounds = torch.cat([torch.zeros(1, dtype=torch.int64, device=ids.device), torch.cumsum(torch.bincount(owner, minlength=world), 0)])
+        send = bounds[1:] - bounds[:-1]
+        self.capacity = None if capacity is None else int(capacity)
+        if self.capacity is None:
+            recv = comm.counts(send)
+            # RCCL needs the split sizes on the host: the one host sync of an exact plan
+            self.send_counts, self.recv_counts = send.tolist(), recv.tolist()
+            # requests for rows of MY shard, grouped by requesting rank
+            self.requests = comm.rows(payload[self.order], self.send_counts, self.recv_counts)
+            self.overflow = None
+        else:
+            cap = self.capacity
+            pos = torch.arange(n, device=ids.device) - bounds[:-1][sorted_owner]          # position inside the owner's block
+            last = world * cap                                                            # one spare slot swallows what does not fit
+            self.slot = torch.where(pos < cap, sorted_owner * cap + pos, torch.full_like(pos, last))
+            self.overflow = (send > cap).any()
+            buf = torch.full((last + 1,), -1, dtype=payload.dtype, device=ids.device)
+            buf[self.slot] = payload[self.order]
+            self.requests = comm.equal(buf[:last])                                        # [world * cap], -1 = padding
+        self.local_ids = torch.where(self.requests >= 0, torch.div(self.requests, world, rounding_mode="floor"),
+                                     torch.full_like(self.requests, -1))
 
     def fetch(self, rows_for_requests: torch.Tensor) -> torch.Tensor:
-        """owner -> requester: rows gathered for ``local_ids`` come back in batch order."""
-        got = self.comm.rows(rows_for_requests, self.recv_counts, self.send_counts)
-        out = torch.empty_like(got)
-        out[self.order] = got
+        """owner -> requester: rows gathered for ``requests`` come back in batch order."""
+        out = torch.empty((self.ids.numel(),) + tuple(rows_for_requests.shape[1:]), dtype=rows_for_requests.dtype,
+                          device=rows_for_requests.device)
+        if self.capacity is None:
+            out[self.order] = self.comm.rows(rows_for_requests, self.recv_counts, self.send_counts)
+        else:
+            got = self.comm.equal(rows_for_requests)
+            out[self.order] = got[self.slot.clamp_max(got.shape[0] - 1)]                  # (overflowed slots: flagged, garbage)
         return out
 
     def push(self, per_batch_rows: torch.Tensor) -> torch.Tensor:
-        """requester -> owner: one row per batch slot, delivered aligned with ``local_ids``."""
-        return self.comm.rows(per_batch_rows[self.order], self.send_counts, self.recv_counts)
+        """requester -> owner: one row per batch slot, delivered aligned with ``requests`` (padding slots carry
+        unspecified values: their request is -1 and every consumer skips them)."""
+        if self.capacity is None:
+            return self.comm.rows(per_batch_rows[self.order], self.send_counts, self.recv_counts)
+        last = self.comm.world * self.capacity
+        buf = torch.zeros((last + 1,) + tuple(per_batch_rows.shape[1:]), dtype=per_batch_rows.dtype, device=per_batch_rows.device)
+        buf[self.slot] = per_batch_rows[self.order]
+        return self.comm.equal(buf[:last])
 
 
 class _Plan:
     """The exchange plans of one batch (+ the event that orders a side-stream build before its use)."""
 
-    def __init__(self, key, item: RowExchange, user: RowExchange | None, ready, built_at: int, buckets) -> None:
+    def __init__(self, key, item: RowExchange, user: RowExchange | None, ready, built_at: int, buckets, bad_users=None) -> None:
         self.key, self.item, self.user, self.ready, self.built_at, self.buckets = key, item, user, ready, built_at, buckets
+        self.bad_users = bad_users          # device flag: ids outside this rank's user shard (partitioned mode)
+
+
+class _LazyCheck:
+    """A device-side error flag that is read WITHOUT stalling the step that produced it: its value is copied to pinned
+    host memory behind the work that computes it, and looked at once that copy has completed (a later step, or
+    ``ShardedTrainer.finish``)."""
+
+    def __init__(self, step: int, message: str, flag: torch.Tensor) -> None:
+        self.step, self.message = step, message
+        if flag.is_cuda:
+            self.host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            self.host.copy_(flag.reshape(1).to(torch.int32), non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.host, self.event = flag.reshape(1).to(torch.int32), None
+
+    def done(self) -> bool:
+        return self.event is None or self.event.query()
+
+    def wait(self) -> None:
+        if self.event is not None:
+            self.event.synchronize()
+
+    def failed(self) -> bool:
+        return bool(int(self.host[0]))
+
+
+USER_MODES = ("routed", "partitioned")
 
 
 class ShardedTrainer:
     """Row-sharded tables + the training step described in the module docstring.  ``num_hashes > 0``: hash / bloom
-    towers -- ``num_users`` / ``num_items`` are then BUCKET counts and ids may be arbitrary int64."""
+    towers -- ``num_users`` / ``num_items`` are then BUCKET counts and ids may be arbitrary int64.
+
+    ``user_mode``: "routed" (default) -- the user table is dealt round-robin like the item table and a rank's batch may
+    hold any users (example-sharded data, as the reference's loader deals it, xfmr_rec/data/lightning.py:109): user and
+    item rows travel in ONE fused exchange each way.  "partitioned" -- contiguous user blocks, every rank's batch holds
+    only users of its own block (``data.DeviceInteractionSampler(user_range=...)``), user rows never travel; a user id
+    outside the block raises (at the plan's host read when the plan is exact, one or two steps later otherwise).
+    ``capacity_factor``: per-peer slots of an un-prefetched (capacity-padded) exchange as a multiple of the even share
+    ``len(ids) / world``; ``None`` = ``len(ids)`` slots per peer, which can never overflow.  An overflow raises (late, like
+    the id check) and leaves the step's updates incomplete -- prefetch plans, or keep ``None``."""
 
     def __init__(self, mf, device, optimizer: str, num_negatives: int, *, num_users: int, num_items: int, dim: int,
                  logq: torch.Tensor | None = None, kind: str = "InfomationNoiseContrastiveEstimationLoss",
-                 lr: float | None = None, ops=None, comm=None, seed: int = 0, num_hashes: int = 0, hash_seed: int = 0) -> None:
+                 lr: float | None = None, ops=None, comm=None, seed: int = 0, num_hashes: int = 0, hash_seed: int = 0,
+                 user_mode: str = "routed", capacity_factor: float | None = None) -> None:
+        if user_mode not in USER_MODES:
+            msg = f"user_mode must be one of {USER_MODES}: {user_mode = }"
+            raise ValueError(msg)
         self.ops = ops if ops is not None else HipOps(mf)
         self.comm = comm if comm is not None else default_comm(device)
         self.rank, self.world = self.comm.rank, self.comm.world
@@ -350,9 +471,11 @@ class ShardedTrainer:
         self.hyper = optimizer_hyper(optimizer, lr)
         self.num_users, self.num_items, self.dim = num_users, num_items, dim
         self.num_hashes, self.hash_seed = int(num_hashes), int(hash_seed)
+        self.user_mode = "routed" if self.num_hashes else user_mode
+        self.capacity_factor = capacity_factor
         std = 1.0 / (dim * max(self.num_hashes, 1)) ** 0.5
         # every shard is generated in place (seed + 1: the item table's stream)
-        if self.num_hashes:                                       # both bucket tables dealt round-robin
+        if self.user_mode == "routed":                            # dealt round-robin (bucket tables of hashed towers too)
             self.user_lo, self.user_hi = 0, num_users
             self.user_table = self.ops.init_rows(cyclic_rows(num_users, self.world, self.rank), dim, self.rank, self.world, seed,
                                                  std, device)
@@ -367,6 +490,8 @@ class ShardedTrainer:
         self.steps = 0
         self._plans: dict = {}
         self._plan_stream = None
+        self._checks: list[_LazyCheck] = []
+        self.padded_steps = 0           # steps that ran on capacity-padded exchanges (no prefetched plan)
 
     # -- bench helpers ------------------------------------------------------------------------
     def item_shard(self) -> torch.Tensor:
@@ -384,40 +509,88 @@ class ShardedTrainer:
         return self.item_shard()
 
     def user_vectors(self, rows: torch.Tensor) -> torch.Tensor:
-        """Unit-norm vectors of global user rows that this rank owns (others wrap into its shard)."""
-        local = (rows - self.user_lo) % max(self.user_table.shape[0], 1)
+        """Unit-norm vectors of this rank's OWN user rows picked by ``rows`` (any int64: wrapped into the shard) -- query
+        vectors for the retrieval leg of the benchmark."""
+        local = torch.remainder(rows, max(self.user_table.shape[0], 1))
         return self.ops.gather(self.user_table, local, True)
+
+    # -- deferred error flags -------------------------------------------------------------------
+    def _raise_failed(self, block: bool) -> None:
+        keep = []
+        for chk in self._checks:
+            if block:
+                chk.wait()
+            if not chk.done():
+                keep.append(chk)
+            elif chk.failed():
+                self._checks = []
+                raise _lib.MfHipError(f"step {chk.step}: {chk.message}")
+        self._checks = keep
+
+    def finish(self) -> None:
+        """Wait for the error flags of the steps issued so far (id range, exchange capacity) and raise if one is set."""
+        self._raise_failed(block=True)
 
     # -- exchange plans ------------------------------------------------------------------------
     @staticmethod
     def _key(b) -> tuple:
         return (b["item"].data_ptr(), b["item"]._version, b["item"].numel(), b["user"].data_ptr(), b["user"]._version)
 
-    def _build(self, b) -> tuple:
+    def _capacity(self, n: int) -> int:
+        if self.capacity_factor is None:
+            return n
+        return min(n, -(-int(math.ceil(self.capacity_factor * n / self.world)) // 8) * 8)       # (whole 64-byte id lines)
+
+    def _build(self, b, padded: bool) -> tuple:
+        """(item exchange, user exchange or None, bucket rows or None, out-of-shard flag or None)"""
+        cap = (lambda n: self._capacity(n)) if padded else (lambda n: None)   # noqa: E731
         if self.num_hashes:
             ib = self.ops.hash_buckets(b["item"], self.num_hashes, self.hash_seed + 1, self.num_items)
             ub = self.ops.hash_buckets(b["user"], self.num_hashes, self.hash_seed, self.num_users)
-            return RowExchange(ib, self.comm, self.ops), RowExchange(ub, self.comm, self.ops), (ub, ib)
-        return RowExchange(b["item"], self.comm, self.ops), None, None
+            return (RowExchange(ib, self.comm, self.ops, cap(ib.numel())), RowExchange(ub, self.comm, self.ops, cap(ub.numel())),
+                    (ub, ib), None)
+        if self.user_mode == "routed":
+            # ONE exchange for both tables: the users' ids then the items', the table in the payload's lowest bit
+            ids = torch.cat([b["user"], b["item"]])
+            tag = torch.zeros_like(ids)
+            tag[b["user"].numel():] = 1
+            return RowExchange(ids, self.comm, self.ops, cap(ids.numel()), payload=ids * 2 + tag), None, None, None
+        user = b["user"]
+        bad = ((user < self.user_lo) | (user >= self.user_hi)).any()
+        return RowExchange(b["item"], self.comm, self.ops, cap(b["item"].numel())), None, None, bad
+
+    def _new_plan(self, key, b, padded: bool, ready=None) -> _Plan:
+        item, user, buckets, bad = self._build(b, padded)
+        if bad is not None and not padded:
+            # an exact plan has just read its split sizes on the host: one more flag, on the same (plan) stream, costs
+            # nothing -- and the error surfaces before the step that would have gathered zero rows
+            if bool(bad):
+                msg = (f"user ids outside this rank's shard [{self.user_lo}, {self.user_hi}) in a user-partitioned batch "
+                       "(user_mode='partitioned' needs per-rank batches of its own users; use user_mode='routed' for "
+                       "example-sharded data)")
+                raise _lib.MfHipError(msg)
+            bad = None
+        return _Plan(key, item, user, ready, self.steps, buckets, bad)
 
     def _plan(self, b) -> _Plan:
-        """The routing plan of a batch.  Building one costs a host sync (the split sizes); ``prefetch`` moves that sync
+        """The routing plan of a batch.  An exact plan costs a host sync (the split sizes); ``prefetch`` moves that sync
         off the critical path.  A prefetched plan is only used for the very tensors it was built from (same storage, same
-        version: the plan holds a reference, so the allocator cannot hand that address to another batch meanwhile)."""
+        version: the plan holds a reference, so the allocator cannot hand that address to another batch meanwhile).
+        Without one the step runs on capacity-padded exchanges: no host sync at all."""
         key = self._key(b)
         hit = self._plans.pop(key, None)
         # whatever else was prefetched and not consumed by now (epoch end, skipped batch) is stale: drop it
         for k in [k for k, p in self._plans.items() if p.built_at < self.steps - 1]:
             del self._plans[k]
         if hit is None:
-            item, user, buckets = self._build(b)
-            return _Plan(key, item, user, None, self.steps, buckets)
+            self.padded_steps += 1
+            return self._new_plan(key, b, padded=True)
         if hit.ready is not None:                  # built on the side stream: order it before our use
             cur = torch.cuda.current_stream()
             cur.wait_event(hit.ready)
             for ex in (hit.item, hit.user):
                 if ex is not None:
-                    for t in (ex.order, ex.local_ids):
+                    for t in (ex.order, ex.local_ids, ex.requests):
                         t.record_stream(cur)
         return hit
 
@@ -434,8 +607,7 @@ class ShardedTrainer:
             return
         ids = next_b["item"]
         if not ids.is_cuda:
-            item, user, buckets = self._build(next_b)
-            self._plans[key] = _Plan(key, item, user, None, self.steps, buckets)
+            self._plans[key] = self._new_plan(key, next_b, padded=False)
             return
         cur = torch.cuda.current_stream()
         if self._plan_stream is None:
@@ -446,28 +618,49 @@ class ShardedTrainer:
         else:
             self._plan_stream.wait_stream(cur)      # conservative: everything queued so far
         with torch.cuda.stream(self._plan_stream):
-            item, user, buckets = self._build(next_b)
-            ready = torch.cuda.Event()
-            ready.record(self._plan_stream)
+            plan = self._new_plan(key, next_b, padded=False)
+            plan.ready = torch.cuda.Event()
+            plan.ready.record(self._plan_stream)
         for t in (next_b["item"], next_b["user"]):
             t.record_stream(self._plan_stream)
-        self._plans[key] = _Plan(key, item, user, ready, self.steps, buckets)
+        self._plans[key] = plan
 
     # -- one step -----------------------------------------------------------------------------
     def step(self, b, next_b=None) -> torch.Tensor:
-        """``b``: ``user`` (global rows inside this rank's user shard; any ids with hashed towers), ``item`` (2B
-        global rows: positives then negatives), ``target``, ``pos``.  ``next_b``: the batch after it, if known
-        (its exchange plan is then prefetched behind this step's compute)."""
+        """``b``: ``user`` (global user rows -- any, or this rank's block in "partitioned" mode; any ids with hashed
+        towers), ``item`` (2B global rows: positives then negatives), ``target``, ``pos``.  ``next_b``: the batch
+        after it, if known (its exchange plan is then prefetched behind this step's compute)."""
         self.steps += 1
+        self._raise_failed(block=False)           # flags of earlier steps whose host copies have landed by now
         entry = None
         if next_b is not None and b["item"].is_cuda:
             entry = torch.cuda.Event()
             entry.record()                        # next_b's ids are queued by now; this step's sweeps are not
         plan = self._plan(b)
         ops, H = self.ops, self.num_hashes
+        for ex in (plan.item, plan.user):
+            if ex is not None and ex.overflow is not None and self.capacity_factor is not None:
+                self._checks.append(_LazyCheck(self.steps, f"exchange capacity exceeded (capacity_factor = {self.capacity_factor}); "
+                                               "this step's updates are incomplete", ex.overflow))
+        if plan.bad_users is not None:            # (padded plan: nothing is read back now; an exact plan checked at build time)
+            self._checks.append(_LazyCheck(self.steps, f"user ids outside this rank's shard [{self.user_lo}, {self.user_hi}) in a "
+                                           "user-partitioned batch (use user_mode='routed' for example-sharded data); the rows "
+                                           "were gathered as zeros and not updated", plan.bad_users))
+        nb = b["user"].numel()
         if H:
             v, v_inv = ops.bloom_forward(plan.item.fetch(ops.gather(self.item_table, plan.item.local_ids, False)), H)
             u, u_inv = ops.bloom_forward(plan.user.fetch(ops.gather(self.user_table, plan.user.local_ids, False)), H)
+        elif self.user_mode == "routed":
+            # requests carry the table in bit 0: rows of the other table are asked for as -1 (a zero row), so the two
+            # gathers add up to the mixed block exactly
+            req = plan.item.requests
+            none = torch.full_like(req, -1)
+            is_user = (req >= 0) & (torch.remainder(req, 2) == 0)
+            is_item = (req >= 0) & (torch.remainder(req, 2) == 1)
+            lid = torch.div(torch.div(req, 2, rounding_mode="floor"), self.world, rounding_mode="floor")
+            uid, iid = torch.where(is_user, lid, none), torch.where(is_item, lid, none)
+            rows = plan.item.fetch(ops.gather(self.user_table, uid, True) + ops.gather(self.item_table, iid, True))
+            u, v = rows[:nb], rows[nb:]
         else:
             user_local = b["user"] - self.user_lo
             v = plan.item.fetch(ops.gather(self.item_table, plan.item.local_ids, True))
@@ -480,6 +673,10 @@ class ShardedTrainer:
             du_owned = plan.user.push(ops.bloom_backward(u, u_inv, du, H))
             ops.update(self.optimizer, self.item_table, self.state["item"], plan.item.local_ids, dv_owned, False, self.steps, self.hyper)
             ops.update(self.optimizer, self.user_table, self.state["user"], plan.user.local_ids, du_owned, False, self.steps, self.hyper)
+        elif self.user_mode == "routed":
+            owned = plan.item.push(torch.cat([du, dv]))
+            ops.update(self.optimizer, self.item_table, self.state["item"], iid, owned, True, self.steps, self.hyper)
+            ops.update(self.optimizer, self.user_table, self.state["user"], uid, owned, True, self.steps, self.hyper)
         else:
             dv_owned = plan.item.push(dv)
             ops.update(self.optimizer, self.item_table, self.state["item"], plan.item.local_ids, dv_owned, True, self.steps, self.hyper)

@@ -22,7 +22,9 @@ class OracleOps:
         return oembed.init_rows(n_local, d, row_start, row_stride, seed, std)
 
     def gather(self, table, ids, normalize, want_inv=False):
-        rows = table[ids]
+        # ids outside the table (the -1 of a padded or other-table request) give a zero row, like mf_gather_rows
+        ok = (ids >= 0) & (ids < table.shape[0])
+        rows = table[torch.where(ok, ids, torch.zeros_like(ids))] * ok[:, None].to(table.dtype)
         if not normalize:
             return (rows, torch.ones(ids.numel())) if want_inv else rows
         inv = 1.0 / rows.norm(dim=-1).clamp_min(1e-12)
@@ -50,6 +52,8 @@ class OracleOps:
         return loss.detach(), u.grad, v.grad
 
     def update(self, optimizer, table, state, ids, grad, normalized, step, hyper):
+        keep = (ids >= 0) & (ids < table.shape[0])          # out-of-range ids are skipped, like mf_update_*
+        ids, grad = ids[keep], grad[keep]
         if ids.numel() == 0:
             return
         g = oembed.normalize_backward(table[ids], grad) if normalized else grad
@@ -99,44 +103,74 @@ def _run(fn: str, tmp_path, world: int = 2) -> None:
 N_USERS, N_ITEMS, DIM, B, P, K = 64, 101, 32, 16, 4, 7
 
 
-def _batch(rank: int, world: int, mfd):
-    g = torch.Generator().manual_seed(100 + rank)
-    lo, hi = mfd.shard_bounds(N_USERS, world, rank)
+def _batch(rank: int, world: int, mfd, mode: str = "routed", salt: int = 0):
+    """"routed": example-sharded, as the reference's loader deals examples (data/lightning.py:109) -- any user on any rank,
+    the same user on several ranks; "partitioned": every rank draws from its own user block."""
+    g = torch.Generator().manual_seed(100 + rank + 1000 * salt)
+    lo, hi = mfd.shard_bounds(N_USERS, world, rank) if mode == "partitioned" else (0, N_USERS)
     item = torch.randint(0, N_ITEMS, (2 * B,), generator=g)
     item[:4] = 3                                       # duplicates, all owned by one rank
     pos = torch.randint(0, N_ITEMS, (B, P), generator=g)
     pos[:, 0] = item[:B]
-    return {"user": torch.randint(lo, hi, (B,), generator=g), "item": item,
-            "target": torch.randint(1, 6, (B,), generator=g), "pos": pos}
+    user = torch.randint(lo, hi, (B,), generator=g)
+    if mode == "routed":
+        user[:3] = 5                                   # one user three times here -- and on every other rank too
+    return {"user": user, "item": item, "target": torch.randint(1, 6, (B,), generator=g), "pos": pos}
 
 
-def _train_case(rank: int, world: int, out_dir: str) -> None:
+def _save(tr, loss, out_dir, tag, rank):
+    torch.save({"user": tr.user_table, "item": tr.item_table, "loss": loss}, f"{out_dir}/{tag}_{rank}.pt")
+
+
+def _train_case(rank: int, world: int, out_dir: str, mode: str = "routed") -> None:
     mf = importlib.import_module("matrix-factorization-torch_amd")
     mfd = mf.distributed
     for opt in ("sgd", "adam"):
-        tr = mfd.ShardedTrainer(mf, "cpu", opt, 0, num_users=N_USERS, num_items=N_ITEMS, dim=DIM, ops=OracleOps(), lr=0.05,
-                                kind="PairwiseLogisticLoss")
+        def trainer(**kw):
+            return mfd.ShardedTrainer(mf, "cpu", opt, 0, num_users=N_USERS, num_items=N_ITEMS, dim=DIM, ops=OracleOps(), lr=0.05,
+                                      kind="PairwiseLogisticLoss", user_mode=mode, **kw)
+
+        tr = trainer()
         assert isinstance(tr.comm, mfd.TorchComm)
-        b = _batch(rank, world, mfd)
-        tr.prefetch(b)                                   # the plan built ahead of time is the one the step uses
-        assert tr._key(b) in tr._plans
+        b = _batch(rank, world, mfd, mode)
+        tr.prefetch(b)                                   # the plan built ahead of time (exact counts) is the one the step uses
+        assert tr._key(b) in tr._plans and tr._plans[tr._key(b)].item.capacity is None
         # a plan is bound to the very tensors it was built from: a batch that merely looks alike gets its own
         other = {k: v.clone() for k, v in b.items()}
         assert tr._key(other) not in tr._plans
         loss = tr.step(b, next_b=b)
-        assert list(tr._plans) == [tr._key(b)]           # consumed, and the next one prefetched
-        torch.save({"user": tr.user_table, "item": tr.item_table, "loss": loss}, f"{out_dir}/{opt}_{rank}.pt")
+        assert list(tr._plans) == [tr._key(b)] and tr.padded_steps == 0    # consumed, and the next one prefetched
+        _save(tr, loss, out_dir, f"{opt}_exact", rank)
         # a prefetched plan that is never consumed (skipped batch, epoch end) is dropped, not matched to a later batch
         tr.prefetch(other)
-        for _ in range(3):
-            tr.step(_batch(rank, world, mfd))
-        assert tr._key(other) not in tr._plans
+        for j in range(3):
+            tr.step(_batch(rank, world, mfd, mode, salt=j + 1))
+        assert tr._key(other) not in tr._plans and tr.padded_steps == 3
+        tr.finish()
+        # the same first step WITHOUT a prefetched plan: capacity-padded exchanges (no host read), same result
+        tr2 = trainer()
+        loss2 = tr2.step(b)
+        assert tr2.padded_steps == 1
+        tr2.finish()
+        _save(tr2, loss2, out_dir, f"{opt}_padded", rank)
+        # ... and with a capacity that holds (2 x the even share, rounded up to 64 slots)
+        tr3 = trainer(capacity_factor=2.0)
+        loss3 = tr3.step(b)
+        tr3.finish()
+        _save(tr3, loss3, out_dir, f"{opt}_cap2", rank)
 
 
-def _check_train(tmp_path, world: int) -> None:
+def _train_case_partitioned(rank: int, world: int, out_dir: str) -> None:
+    _train_case(rank, world, out_dir, mode="partitioned")
+
+
+def _check_train(tmp_path, world: int, mode: str = "routed", tags=("exact", "padded", "cap2"), batch_fn=None, rtol=1e-5, atol=1e-6) -> None:
+    """The shards of every rank, put back together, against ONE process applying every rank's gradients (computed from the
+    same pre-step tables) in a single sparse update per table."""
     mf = importlib.import_module("matrix-factorization-torch_amd")
     mfd = mf.distributed
     std = 1.0 / DIM**0.5
+    batch_fn = batch_fn or (lambda r: _batch(r, world, mfd, mode))
     for opt in ("sgd", "adam"):
         ut = oembed.init_rows(N_USERS, DIM, 0, 1, 0, std)          # the virtual tables every shard was cut from
         it = oembed.init_rows(N_ITEMS, DIM, 0, 1, 1, std)
@@ -145,7 +179,7 @@ def _check_train(tmp_path, world: int) -> None:
         hyper = mfd.optimizer_hyper(opt, 0.05)
         u_ids, u_g, i_ids, i_g, losses = [], [], [], [], []
         for r in range(world):
-            b = _batch(r, world, mfd)
+            b = batch_fn(r)
             loss, du, dv = ops.loss_and_grads("PairwiseLogisticLoss", oembed.gather(ut0, b["user"], True),
                                               oembed.gather(it0, b["item"], True), b["target"], b["item"], b["pos"], None,
                                               0, 1.0, 1.0)
@@ -154,19 +188,27 @@ def _check_train(tmp_path, world: int) -> None:
         ops.update(opt, ut, st, torch.cat(u_ids), torch.cat(u_g), True, 1, hyper)
         st = {"m": torch.zeros_like(it), "v": torch.zeros_like(it)}
         ops.update(opt, it, st, torch.cat(i_ids), torch.cat(i_g), True, 1, hyper)
-        got = [torch.load(f"{tmp_path}/{opt}_{r}.pt") for r in range(world)]
-        torch.testing.assert_close(torch.cat([x["user"] for x in got]), ut, rtol=1e-5, atol=1e-6)
-        items = torch.empty_like(it)
-        for r in range(world):
-            items[r::world] = got[r]["item"]              # item rows are dealt round-robin
-        torch.testing.assert_close(items, it, rtol=1e-5, atol=1e-6)
-        for r in range(world):
-            torch.testing.assert_close(got[r]["loss"], losses[r])
+        for tag in tags:
+            got = [torch.load(f"{tmp_path}/{opt}_{tag}_{r}.pt") for r in range(world)]
+            if mode == "partitioned":                         # contiguous user blocks
+                users = torch.cat([x["user"] for x in got])
+            else:                                             # user rows dealt round-robin, like the items
+                users = torch.empty_like(ut)
+                for r in range(world):
+                    users[r::world] = got[r]["user"]
+            torch.testing.assert_close(users, ut, rtol=rtol, atol=atol)
+            items = torch.empty_like(it)
+            for r in range(world):
+                items[r::world] = got[r]["item"]              # item rows are dealt round-robin
+            torch.testing.assert_close(items, it, rtol=rtol, atol=atol)
+            for r in range(world):
+                torch.testing.assert_close(got[r]["loss"], losses[r], rtol=max(rtol, 1.3e-6), atol=max(atol, 1e-5))
 
 
 def test_sharded_training_step_matches_single_process(tmp_path):
-    """After one step the concatenated shards equal one process applying every rank's gradients
-    (computed from the same pre-step tables) in a single sparse update per table."""
+    """EXAMPLE-sharded batches (any user on any rank, as the reference's loader deals them): after one step the shards equal
+    one process applying every rank's gradients in a single sparse update per table -- through a prefetched exact plan,
+    through capacity-padded exchanges (no host sync) and through a tighter capacity."""
     _run("_train_case", tmp_path)
     _check_train(tmp_path, 2)
 
@@ -174,6 +216,44 @@ def test_sharded_training_step_matches_single_process(tmp_path):
 def test_sharded_training_step_world_4(tmp_path):
     _run("_train_case", tmp_path, world=4)
     _check_train(tmp_path, 4)
+
+
+def test_sharded_training_step_user_partitioned(tmp_path):
+    """The fast path of a user-partitioned stream: user rows never travel."""
+    _run("_train_case_partitioned", tmp_path)
+    _check_train(tmp_path, 2, mode="partitioned")
+
+
+def _guard_case(rank: int, world: int, out_dir: str) -> None:
+    """Errors instead of silent zero rows / silently dropped rows."""
+    mf = importlib.import_module("matrix-factorization-torch_amd")
+    mfd = mf.distributed
+    kw = dict(num_users=N_USERS, num_items=N_ITEMS, dim=DIM, ops=OracleOps(), lr=0.05, kind="PairwiseLogisticLoss")
+    # user-partitioned trainer fed an example-sharded batch: raises when the exact plan is built ...
+    tr = mfd.ShardedTrainer(mf, "cpu", "sgd", 0, user_mode="partitioned", **kw)
+    b = _batch(rank, world, mfd, "routed")
+    b["user"][0] = (tr.user_hi + 1) % N_USERS if world > 1 else b["user"][0]       # certainly another rank's row
+    with pytest.raises(mf.MfHipError, match="outside this rank's shard"):
+        tr.prefetch(b)
+    # (every rank raised at the same point: the collectives stay aligned) ... and after a padded step, at finish()
+    tr = mfd.ShardedTrainer(mf, "cpu", "sgd", 0, user_mode="partitioned", **kw)
+    tr.step(b)
+    with pytest.raises(mf.MfHipError, match="outside this rank's shard"):
+        tr.finish()
+    # a capacity too small for a batch whose items all live on one owner
+    tr = mfd.ShardedTrainer(mf, "cpu", "sgd", 0, capacity_factor=0.5, **kw)
+    b = _batch(rank, world, mfd, "routed")
+    b["item"][:] = 3
+    b["user"][:] = 3
+    tr.step(b)
+    with pytest.raises(mf.MfHipError, match="capacity exceeded"):
+        tr.finish()
+    with pytest.raises(ValueError, match="user_mode"):
+        mfd.ShardedTrainer(mf, "cpu", "sgd", 0, user_mode="replicated", **kw)
+
+
+def test_sharded_trainer_raises_instead_of_zero_rows(tmp_path):
+    _run("_guard_case", tmp_path)
 
 
 # hash / bloom towers (BASELINE config 5 shape: ids far beyond the table height, d = 256 there; 2 hashes)
@@ -196,6 +276,7 @@ def _hashed_case(rank: int, world: int, out_dir: str) -> None:
                                        num_hashes=HH, hash_seed=3)
     b = _hashed_batch(rank)
     loss = tr.step(b, next_b=b)
+    tr.finish()
     torch.save({"user": tr.user_table, "item": tr.item_table, "loss": loss}, f"{out_dir}/hashed_{rank}.pt")
 
 

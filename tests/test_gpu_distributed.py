@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from oracle import chain, embed as oembed
+from oracle import chain
 from tests import test_distributed_cpu as tdc
 
 pytestmark = pytest.mark.gpu
@@ -43,13 +43,18 @@ def _gpu_train_case(rank: int, world: int, out_dir: str) -> None:
     mf = importlib.import_module("matrix-factorization-torch_amd")
     mfd = mf.distributed
     for opt in ("sgd", "adam"):
-        tr = mfd.ShardedTrainer(mf, DEV, opt, 0, num_users=tdc.N_USERS, num_items=tdc.N_ITEMS, dim=tdc.DIM, lr=0.05,
-                                kind="PairwiseLogisticLoss", comm=_relay_comm(mfd))
-        assert isinstance(tr.ops, mfd.HipOps)
-        b = {k: v.to(DEV) for k, v in tdc._batch(rank, world, mfd).items()}
-        loss = tr.step(b, next_b=b)
-        torch.cuda.synchronize()
-        torch.save({"user": tr.user_table.cpu(), "item": tr.item_table.cpu(), "loss": loss.cpu()}, f"{out_dir}/{opt}_{rank}.pt")
+        for tag in ("exact", "padded"):
+            tr = mfd.ShardedTrainer(mf, DEV, opt, 0, num_users=tdc.N_USERS, num_items=tdc.N_ITEMS, dim=tdc.DIM, lr=0.05,
+                                    kind="PairwiseLogisticLoss", comm=_relay_comm(mfd))        # user_mode "routed": any user anywhere
+            assert isinstance(tr.ops, mfd.HipOps)
+            b = {k: v.to(DEV) for k, v in tdc._batch(rank, world, mfd).items()}
+            if tag == "exact":
+                tr.prefetch(b)                       # exact counts (host read on the plan stream); else capacity-padded
+            loss = tr.step(b, next_b=b)
+            assert tr.padded_steps == (0 if tag == "exact" else 1)
+            tr.finish()
+            torch.cuda.synchronize()
+            torch.save({"user": tr.user_table.cpu(), "item": tr.item_table.cpu(), "loss": loss.cpu()}, f"{out_dir}/{opt}_{tag}_{rank}.pt")
 
 
 def _gpu_topk_case(rank: int, world: int, out_dir: str) -> None:
@@ -83,39 +88,14 @@ def _run(fn: str, tmp_path, world: int = 2) -> None:
 
 
 def test_sharded_step_world_2_with_hip_kernels(tmp_path):
-    """Two ranks sharing one card: after one step the concatenated shards equal ONE process (the oracle) applying both
-    ranks' gradients in a single sparse update per table -- device-side shard initialisation, HIP gathers / loss /
-    one-launch updates, duplicates across ranks."""
+    """Two ranks sharing one card, EXAMPLE-sharded batches (any user on any rank): after one step the shards equal ONE
+    process (the oracle) applying both ranks' gradients in a single sparse update per table -- device-side shard
+    initialisation, the fused user + item exchange (exact and capacity-padded), HIP gathers (-1 requests: zero rows) /
+    loss / one-launch updates (-1 ids skipped), duplicates across ranks.
+    (The device's log / cos differ from libm's in the last bits of the initial rows: 1e-6; Adam's first step is
+    lr * sign-like: a sign flip of a ~0 gradient component would show as 2 lr, none occurs at this seed.)"""
     _run("_gpu_train_case", tmp_path)
-    mf = importlib.import_module("matrix-factorization-torch_amd")
-    mfd = mf.distributed
-    world, std = 2, 1.0 / tdc.DIM**0.5
-    ops = tdc.OracleOps()
-    for opt in ("sgd", "adam"):
-        ut = oembed.init_rows(tdc.N_USERS, tdc.DIM, 0, 1, 0, std)
-        it = oembed.init_rows(tdc.N_ITEMS, tdc.DIM, 0, 1, 1, std)
-        ut0, it0 = ut.clone(), it.clone()
-        hyper = mfd.optimizer_hyper(opt, 0.05)
-        u_ids, u_g, i_ids, i_g, losses = [], [], [], [], []
-        for r in range(world):
-            b = tdc._batch(r, world, mfd)
-            loss, du, dv = ops.loss_and_grads("PairwiseLogisticLoss", oembed.gather(ut0, b["user"], True),
-                                              oembed.gather(it0, b["item"], True), b["target"], b["item"], b["pos"], None, 0, 1.0, 1.0)
-            u_ids.append(b["user"]); u_g.append(du); i_ids.append(b["item"]); i_g.append(dv); losses.append(loss)
-        st = {"m": torch.zeros_like(ut), "v": torch.zeros_like(ut)}
-        ops.update(opt, ut, st, torch.cat(u_ids), torch.cat(u_g), True, 1, hyper)
-        st = {"m": torch.zeros_like(it), "v": torch.zeros_like(it)}
-        ops.update(opt, it, st, torch.cat(i_ids), torch.cat(i_g), True, 1, hyper)
-        got = [torch.load(f"{tmp_path}/{opt}_{r}.pt") for r in range(world)]
-        # (the device's log / cos differ from libm's in the last bits of the initial rows: 1e-6; Adam's first step is
-        # lr * sign-like: a sign flip of a ~0 gradient component would show as 2 lr, none occurs at this seed)
-        torch.testing.assert_close(torch.cat([x["user"] for x in got]), ut, rtol=1e-4, atol=2e-5)
-        items = torch.empty_like(it)
-        for r in range(world):
-            items[r::world] = got[r]["item"]
-        torch.testing.assert_close(items, it, rtol=1e-4, atol=2e-5)
-        for r in range(world):
-            torch.testing.assert_close(got[r]["loss"], losses[r], rtol=1e-4, atol=1e-5)
+    tdc._check_train(tmp_path, 2, tags=("exact", "padded"), rtol=1e-4, atol=2e-5)
 
 
 def test_sharded_topk_world_2_with_hip_kernels(tmp_path):

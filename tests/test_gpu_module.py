@@ -215,11 +215,24 @@ def test_sharded_classes_on_one_rank_use_the_hip_path(mf):
                   pos_idx=batch["pos"])
         want.backward()
         opt.step()
-        got = tr.step(batch, next_b=batch)       # with the next batch's exchange plan prefetched on the side stream
-        assert float(got) == float(want)
+        got = tr.step(batch, next_b=batch)       # no plan yet: capacity-padded exchanges (no host read); the next batch's
+        assert float(got) == float(want)         # exact plan is prefetched on the side stream meanwhile
+        assert tr.padded_steps == 1
         torch.testing.assert_close(tr.item_table, towers["item"].weight.detach(), rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(tr.user_table, towers["user"].weight.detach(), rtol=1e-6, atol=1e-7)
         assert isinstance(tr.comm, mf.distributed.RcclComm)           # the exchanges ran through mf_comm_* on the compute stream
+        assert tr.comm.rccl_ranks == 1 and tr.comm.transport == "mf_comm"
+        # libmf_hip.so took the librccl torch had already mapped (RTLD_NOLOAD): one RCCL runtime per process
+        assert mf._lib.lib().mf_comm_source().decode().startswith("shared"), mf._lib.lib().mf_comm_source()
+        want2 = fn(towers["user"](batch["user"]), towers["item"](batch["item"]), batch["target"], item_idx=batch["item"],
+                   pos_idx=batch["pos"])
+        want2.backward()
+        opt.step()
+        got2 = tr.step(batch)                    # the prefetched exact plan
+        tr.finish()
+        assert float(got2) == float(want2) and tr.padded_steps == 1
+        torch.testing.assert_close(tr.item_table, towers["item"].weight.detach(), rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(tr.user_table, towers["user"].weight.detach(), rtol=1e-6, atol=1e-7)
         q = tr.user_vectors(torch.arange(1, 9, device=DEV))
         s1, i1 = mf.distributed.ShardedIndex(tr.item_shard(), tr.item_offset(), ni, stride=tr.item_stride()).search(q, 10)
         s2, i2 = mf.retrieval.ItemIndex(tr.item_shard()).search(q, 10)

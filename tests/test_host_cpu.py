@@ -223,3 +223,35 @@ def test_interaction_table_split_and_histories_match_the_reference_semantics():
             assert sorted(h_items[int(h_off[s_]): int(h_off[s_ + 1])].tolist()) == sorted(int(item[r]) for r in range(n) if int(user[r]) == u and want_train[r])
             tg = sorted((int(item[r]), float(rating[r])) for r in range(n) if int(user[r]) == u and not want_train[r])
             assert sorted(zip(t_items[int(t_off[s_]): int(t_off[s_ + 1])].tolist(), t_rating[int(t_off[s_]): int(t_off[s_ + 1])].tolist())) == tg
+
+
+def test_bench_starts_its_own_ranks_and_reports_them():
+    """`python bench.py --gpus 2` with no launcher around it: two fresh child processes (started before any GPU call), one
+    JSON line with n_gpus = 2 and the transport fields; a rank count that differs from --gpus is an error, never a smaller
+    job timed under the bigger name (--gpus used to be parsed and ignored).  Runs the launch / barrier /
+    max-over-ranks plumbing on CPU (MF_BENCH_DRY_RUN: gloo, stub step, no kernels)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MF_BENCH_DRY_RUN"] = "1"
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout                       # rank 0 prints, rank 1 does not
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert {"metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "rccl_ranks",
+            "transport"} <= set(line)
+    # under a launcher whose world differs from --gpus: exit 2, nothing printed
+    bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2 and "WORLD_SIZE=3" in bad.stderr and not bad.stdout.strip()
+    # more ranks than GPUs (none here): refused before anything starts
+    env.pop("MF_BENCH_DRY_RUN")
+    if not torch.cuda.is_available():
+        none = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+        assert none.returncode == 2 and "visible" in none.stderr
