@@ -123,6 +123,24 @@ def make_batches(n_batches: int, batch: int, seed: int, device, *, num_users: in
     return out, counts
 
 
+def make_csr_interactions(seed: int = 0, num_users: int = NUM_USERS, num_items: int = NUM_ITEMS, mean_len: float = 123.0,
+                          sigma: float = 1.25, max_len: int = 30_000) -> dict:
+    """MovieLens-25M-shaped interactions WITH the real list-length profile: per-user train-list lengths log-normal
+    (>= 16, mean ~ 123 = 0.8 x 153, the heaviest users > 10^4 items), items Zipf(1); every (user, item) of a list is one
+    training pair, so a batch draws users in proportion to their list length, as real pairs do."""
+    g = torch.Generator().manual_seed(seed)
+    mu = torch.log(torch.tensor(mean_len)) - 0.5 * sigma * sigma
+    lens = torch.exp(mu + sigma * torch.randn(num_users, generator=g, dtype=torch.float64)).clamp(16, max_len).round().to(torch.int64)
+    lens[0] = 0                                               # row 0 is the padding row
+    lens[1] = max_len                                         # at least one user at the cap
+    total = int(lens.sum())
+    items = torch.multinomial(zipf_weights(num_items - 1), total, replacement=True, generator=g) + 1
+    off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens, 0)])
+    users = torch.repeat_interleave(torch.arange(num_users), lens)
+    return {"num_users": num_users, "lens": lens, "pos_off": off, "pos_items": items, "pair_user": users, "pair_item": items,
+            "pair_target": torch.randint(1, 6, (total,), generator=g).float()}
+
+
 def logq_table(device, num_items: int = NUM_ITEMS) -> torch.Tensor:
     """log of the sampling probability of each item row: positives ~ Zipf, negatives ~ uniform."""
     w = zipf_weights(num_items - 1)

@@ -136,12 +136,26 @@ int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64_t* sorted_
 size_t mf_loss_ws_bytes(int64_t B, int64_t N, int d, int P, int num_negatives);
 int mf_loss_masks(int64_t B, int64_t N, int d, int P, int num_negatives, const int64_t* item_idx,
                   const int64_t* pos_idx, void* ws, size_t ws_bytes, mf_stream_t stream);
+/* CSR form of the positives (the batch producer's own lists, mf_sample_batch's pos_off / pos_items): the positives of batch
+ * row i are pos_items[pos_off[u] .. pos_off[u + 1]), u = user_ids[i] (a u outside [0, num_users) has none).  No [B, P]
+ * tensor exists on this path: the reference pads every batch to its longest list (xfmr_rec/data/lightning.py:274-280,
+ * data/load.py:38-55), which for MovieLens-25M means > 10^4 columns.  Same masks, bit for bit, as the padded form of the
+ * same lists (order and duplicates inside a list do not matter; lists need not be sorted). */
+int mf_loss_masks_csr(int64_t B, int64_t N, int d, int num_negatives, const int64_t* item_idx, const int64_t* user_ids,
+                      const int64_t* pos_off, const int64_t* pos_items, int64_t num_users, void* ws, size_t ws_bytes,
+                      mf_stream_t stream);
 enum { MF_LOSS_TARGET_I64 = 1, MF_LOSS_ROWC = 2, MF_LOSS_MASKS_READY = 4 };
 int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
                 int kind_mask, const float* u, const float* v, const void* target,
                 const int64_t* item_idx, const int64_t* pos_idx, const float* logq, int64_t logq_rows,
                 int flags, void* ws, size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits,
                 mf_stream_t stream);
+
+/* mf_loss_fwd with CSR positives (see mf_loss_masks_csr); everything else as above.  mf_loss_ws_bytes(B, N, d, 0, k) sizes ws. */
+int mf_loss_fwd_csr(int64_t B, int64_t N, int d, int num_negatives, float sigma, float margin, int kind_mask, const float* u,
+                    const float* v, const void* target, const int64_t* item_idx, const int64_t* user_ids, const int64_t* pos_off,
+                    const int64_t* pos_items, int64_t num_users, const float* logq, int64_t logq_rows, int flags, void* ws,
+                    size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits, mf_stream_t stream);
 
 /* Backward of one loss of the preceding mf_loss_fwd (same shapes/hyper-parameters,
  * same ws): du[B,d] = grad_out * dloss/du, dv[N,d] = grad_out * dloss/dv, with

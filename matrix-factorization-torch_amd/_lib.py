@@ -36,6 +36,9 @@ SIGNATURES = {
     "mf_loss_masks": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mf_loss_fwd": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp,
                             c_vp, c_vp, c_i64, c_int, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "mf_loss_masks_csr": (c_int, [c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "mf_loss_fwd_csr": (c_int, [c_i64, c_i64, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                c_vp, c_i64, c_int, c_vp, c_sz, c_vp, c_vp, c_vp]),
     "mf_loss_bwd": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_int,
                             c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
     "mf_negative_masks_ws_bytes": (c_sz, [c_i64, c_i64, c_int]),

@@ -26,6 +26,7 @@ enum { ST_CNT = 0, ST_A = 1, ST_MX = 2, ST_SE = 3, ST_H = 4, ST_HC = 5, ST_LG = 
 enum { NEED_CONTR = 1, NEED_LSE = 2, NEED_HINGE = 4, NEED_LOGI = 8 };
 enum { G_EXP = 0, G_STEP = 1, G_SIGM = 2 };
 static constexpr int KSEL_MAX = 64;
+static constexpr int HITS_PLANES = 4;      // planes of the users' hit bit-vectors (= HITS_MAX_SPLIT, mask build)
 
 static int need_flags(int kind_mask) {
     int f = 0;
@@ -52,6 +53,8 @@ struct LossWs {
     long long* gtab;
     int M;
     int32_t *colslot, *gfirst, *colfirst;
+    uint32_t* bmap;               // "some column carries an id hashing here": 2^bmbits bits, the positives' prefilter
+    int bmbits;
     uint32_t* ubits;
     uint32_t* maskW;
     float *part, *stats, *rowloss, *rowc, *dpart, *rpart, *dpart_v, *rpart_v, *stash, *gstash, *blockpart;
@@ -107,7 +110,10 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.gfirst = a.take<int32_t>((size_t)w.M);
     w.colslot = a.take<int32_t>((size_t)w.Np);
     w.colfirst = a.take<int32_t>((size_t)w.Np);
-    w.ubits = a.take<uint32_t>((size_t)w.Np * (w.Bp / 32));      // ubitsT [column][user / 32]
+    w.bmbits = 13;                                                // >= 8 bits per column, 1 KiB .. 16 KiB (every block copies it into LDS)
+    while (w.bmbits < 17 && (1ll << w.bmbits) < 8 * w.Np) ++w.bmbits;
+    w.bmap = a.take<uint32_t>((size_t)1 << (w.bmbits - 5));
+    w.ubits = a.take<uint32_t>((size_t)HITS_PLANES * w.Np * (w.Bp / 32));        // ubitsT [plane][column][user / 32]
     w.maskW = a.take<uint32_t>((size_t)w.NT * w.Bp);
     w.part = a.take<float>((size_t)w.nsplit_f * NSTAT * w.Bp);
     w.stats = a.take<float>((size_t)NSTAT * w.Bp);
@@ -163,6 +169,7 @@ struct PrepParams {
     uint4* gtab; int64_t gtab16;        // fills, in 16-byte units (0 = skip)
     uint4* gfirst; int64_t gfirst16;
     uint4* ubits; int64_t ubits16;
+    uint4* bmap; int64_t bmap16;
     unsigned* ticket;
 };
 
@@ -232,6 +239,7 @@ __global__ __launch_bounds__(64) void prep_kernel(PrepParams p) {
     fill16(p.gtab, p.gtab16, 0x80808080u, i, nthreads);
     fill16(p.gfirst, p.gfirst16, 0x7f7f7f7fu, i, nthreads);
     fill16(p.ubits, p.ubits16, 0u, i, nthreads);
+    fill16(p.bmap, p.bmap16, 0u, i, nthreads);
 }
 
 // ------------------------------------------------------------------ hit masks --
@@ -254,13 +262,23 @@ __device__ __forceinline__ unsigned ht_hash(long long id, unsigned slots_mask) {
     return ((((unsigned)id * 2654435761u) ^ ((unsigned)((unsigned long long)id >> 32) * 40503u)) >> 5) & slots_mask;
 }
 
+// bit of an id in the batch-membership bitmap (2^bits bits): a second, independent mix of the id
+__device__ __forceinline__ unsigned bm_hash(long long id, int bits) {
+    return (unsigned)(((unsigned long long)id * 0x9E3779B97F4A7C15ull) >> (64 - bits));
+}
+
 // (64-thread workgroups: every thread is one chain of dependent memory operations; spread over all CUs)
 __global__ __launch_bounds__(64) void gt_insert_kernel(const int64_t* __restrict__ item_idx, int64_t N, int M,
                                                         long long* __restrict__ gtab, int32_t* __restrict__ gfirst,
-                                                        int32_t* __restrict__ colslot) {
+                                                        int32_t* __restrict__ colslot, uint32_t* __restrict__ bmap, int bmbits) {
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j >= N) return;
     const long long key = item_idx[j];
+    {
+        const unsigned b = bm_hash(key, bmbits);
+        const uint32_t bit = 1u << (b & 31);
+        if (!(*(const volatile uint32_t*)&bmap[b >> 5] & bit)) atomicOr(&bmap[b >> 5], bit);   // (fire and forget)
+    }
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(gtab);
     unsigned hpos = ht_hash(key, M - 1);
     // a Zipf batch repeats its popular items hundreds of times: look before the atomic (a stale read
@@ -299,49 +317,156 @@ __device__ __forceinline__ int32_t ht_find(long long key, int M, const long long
     return -1;
 }
 
-// One launch for both consumers of the finished hash table.  Blocks [0, nb_col): colfirst.  The rest:
-// one block per group of 32 users -- it OWNS word `group` of every column's user bit-vector, so its
-// hits are combined in an LDS table keyed by the first column (LDS atomics; a popular item is the
-// positive of thousands of users) and written out with plain stores: no global atomics.  `cap` = LDS
-// table entries (power of two >= 2 * 32 * (P + 1)), or 0: fall back to global atomicOr.
-__global__ __launch_bounds__(1024) void hits_kernel(const int64_t* __restrict__ item_idx, const int64_t* __restrict__ pos_idx,
-                                                   int64_t B, int64_t N, int64_t Bp, int64_t Np, int P, int M, int nb_col,
-                                                   int cap, const long long* __restrict__ gtab,
-                                                   const int32_t* __restrict__ gfirst, const int32_t* __restrict__ colslot,
-                                                   int32_t* __restrict__ colfirst, uint32_t* __restrict__ ubitsT) {
-    extern __shared__ __attribute__((aligned(16))) int32_t hl[];           // [cap] keys, [cap] bit words
+// Where a user's positives come from: the reference's padded matrix pos_idx[B][P] (0-padded on the right,
+// data/load.py:38-55; the zeros are looked up like any id: they match a column whose item id is 0, as upstream), or the
+// batch producer's own CSR lists -- user_ids[i]'s items are pos_items[pos_off[u] .. pos_off[u + 1]) -- which never
+// materialises a [B, P] tensor: a MovieLens-25M user can hold > 10^4 positives.
+struct PosSrc {
+    const int64_t* pos_idx; int P;
+    const int64_t *user_ids, *pos_off, *pos_items; int64_t num_users;
+};
+__device__ __forceinline__ int pos_list(const PosSrc& s, int64_t i, const int64_t*& base) {
+    if (s.pos_off) {
+        const int64_t u = s.user_ids[i];
+        if (u < 0 || u >= s.num_users) { base = s.pos_items; return 0; }
+        const int64_t o = s.pos_off[u];
+        base = s.pos_items + o;
+        const int64_t len = s.pos_off[u + 1] - o;
+        return (int)(len < 0 ? 0 : (len > 0x7FFFFFF ? 0x7FFFFFF : len));
+    }
+    base = s.pos_idx + i * s.P;
+    return s.P;
+}
+
+// One launch for both consumers of the finished hash table.  Blocks [0, nb_col): colfirst.  The rest: `split` blocks per
+// group of 32 users.  The lists of the 32 users are walked as ONE flat range, cut in `split` equal pieces (a user with
+// 30,000 positives -- and the group it sits in -- is spread over `split` x 512 threads; list lengths are heavy-tailed, and
+// with one block per group the heaviest group set the kernel's time: 198 us at the MovieLens-25M profile, 5.3 M list
+// entries per batch).  Most positives are not in the batch at all: every id is first tested against the batch-membership
+// bitmap (a copy in LDS; ~7 % false positives at 8 bits per column), and only the survivors probe the hash table in L2 --
+// HITS_MLP ids in flight per thread, first probes and first-column reads batched.  A block combines its hits in an LDS table
+// keyed by the first column (LDS atomics; a popular item is the positive of thousands of users) and writes word `group` of
+// every hit column's user bit-vector with plain stores into ITS OWN plane of ubitsT (piece s of every group owns plane s;
+// the sweep ORs the planes): no global atomics on the common path -- per-hit global atomicOr was measured 5 x slower
+// (967 vs 198 us: the first column of a popular item takes a hit from every other user).  The table holds HITS_CAP first
+// columns; what does not find room within HITS_PROBES probes goes out by global atomicOr into the same plane --
+// consistently: slots never free up, so an id that once failed to find room never succeeds later, and the plain stores at
+// the end only touch words of ids in the table.
+static constexpr int HITS_THREADS = 512, HITS_CAP = 2048, HITS_PROBES = 24, HITS_MLP = 8, HITS_MAX_SPLIT = HITS_PLANES;
+
+__global__ __launch_bounds__(HITS_THREADS) void hits_kernel(const int64_t* __restrict__ item_idx, PosSrc src,
+                                                            int64_t B, int64_t N, int64_t Bp, int64_t Np, int M, int nb_col, int split,
+                                                            const long long* __restrict__ gtab,
+                                                            const int32_t* __restrict__ gfirst, const int32_t* __restrict__ colslot,
+                                                            int32_t* __restrict__ colfirst, uint32_t* __restrict__ ubitsT,
+                                                            const uint32_t* __restrict__ bmap, int bmbits) {
+    extern __shared__ __attribute__((aligned(16))) int32_t hl[];           // [HITS_CAP] keys, [HITS_CAP] bit words, the bitmap
+    __shared__ int lstart[33];
+    __shared__ const int64_t* lbase[32];
     if ((int)blockIdx.x < nb_col) {
-        colfirst_body((int64_t)blockIdx.x * 1024 + threadIdx.x, colslot, gfirst, N, Np, colfirst);
+        colfirst_body((int64_t)blockIdx.x * HITS_THREADS + threadIdx.x, colslot, gfirst, N, Np, colfirst);
         return;
     }
-    const int grp = blockIdx.x - nb_col;
+    const int grp = (blockIdx.x - nb_col) / split, sub = (blockIdx.x - nb_col) % split;
     const int64_t wpr = Bp >> 5;                                           // words per column row
+    uint32_t* plane = ubitsT + (int64_t)sub * Np * wpr;
     int32_t* keys = hl;
-    uint32_t* bits = reinterpret_cast<uint32_t*>(hl + cap);
-    for (int e = threadIdx.x; e < cap; e += 1024) { keys[e] = -1; bits[e] = 0u; }
-    __syncthreads();
-    const int per_user = P + 1;
-    for (int t = threadIdx.x; t < 32 * per_user; t += 1024) {
-        const int ul = t / per_user, p = t % per_user;
+    uint32_t* bits = reinterpret_cast<uint32_t*>(hl + HITS_CAP);
+    uint32_t* lbm = reinterpret_cast<uint32_t*>(hl + 2 * HITS_CAP);
+    const int bmw = 1 << (bmbits - 5);
+    for (int e = threadIdx.x; e < HITS_CAP; e += HITS_THREADS) { keys[e] = -1; bits[e] = 0u; }
+    for (int e = threadIdx.x; e < bmw / 4; e += HITS_THREADS) reinterpret_cast<uint4*>(lbm)[e] = reinterpret_cast<const uint4*>(bmap)[e];
+    if (threadIdx.x < 64) {                                                // wave 0: the 32 lists and their flat offsets
+        const int ul = threadIdx.x & 31;
         const int64_t i = (int64_t)grp * 32 + ul;
-        if (i >= B) continue;
-        const long long key = (p == P) ? item_idx[i] : pos_idx[i * P + p];
-        const int32_t f = ht_find(key, M, gtab, gfirst);
-        if (f < 0) continue;
-        if (cap == 0) {
-            atomicOr(&ubitsT[(int64_t)f * wpr + grp], 1u << ul);
-            continue;
+        const int64_t* base = nullptr;
+        int len = 0;
+        if (i < B) len = pos_list(src, i, base);
+        int incl = len;                                                    // inclusive scan over the 32 lanes of a half-wave
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (ul >= o) incl += up;
         }
-        unsigned h = ((unsigned)f * 2654435761u >> 7) & (cap - 1);
-        for (;;) {
-            const int32_t old = atomicCAS(&keys[h], -1, f);
-            if (old == -1 || old == f) { atomicOr(&bits[h], 1u << ul); break; }
-            h = (h + 1) & (cap - 1);
+        if (threadIdx.x < 32) {
+            lstart[ul + 1] = incl;
+            lbase[ul] = base;
+            if (ul == 0) lstart[0] = 0;
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < cap; e += 1024)
-        if (keys[e] >= 0) ubitsT[(int64_t)keys[e] * wpr + grp] = bits[e];
+    const int total = lstart[32];
+    // flat positions [0, total): the lists; [total, total + 32): every user's own item (the accidental-hit term, losses.py:103)
+    const int piece = (total + 32 + split - 1) / split;
+    const int p0 = sub * piece, p1 = min(total + 32, p0 + piece);
+    for (int t0 = p0 + threadIdx.x; t0 < p1; t0 += HITS_THREADS * HITS_MLP) {
+        long long key[HITS_MLP];
+        int ulv[HITS_MLP];
+        bool live[HITS_MLP];
+#pragma unroll
+        for (int j = 0; j < HITS_MLP; ++j) {
+            const int t = t0 + j * HITS_THREADS;
+            live[j] = false; key[j] = 0; ulv[j] = 0;
+            if (t < p1 && t < total) {
+                int lo = 0, hi = 32;                                       // the list holding flat position t: last start <= t
+#pragma unroll
+                for (int sft = 0; sft < 5; ++sft) {
+                    const int mid = (lo + hi) >> 1;
+                    if (lstart[mid] <= t) lo = mid; else hi = mid;
+                }
+                ulv[j] = lo;
+                key[j] = lbase[lo][t - lstart[lo]];
+                live[j] = true;
+            } else if (t < p1) {
+                ulv[j] = t - total;
+                const int64_t i = (int64_t)grp * 32 + ulv[j];
+                if (i < B) { key[j] = item_idx[i]; live[j] = true; }
+            }
+        }
+        unsigned hpos[HITS_MLP];
+        long long sv[HITS_MLP];
+#pragma unroll
+        for (int j = 0; j < HITS_MLP; ++j) {                               // prefilter, then the first probes, all in flight
+            if (live[j]) {
+                const unsigned b = bm_hash(key[j], bmbits);
+                live[j] = (lbm[b >> 5] >> (b & 31)) & 1u;
+            }
+            hpos[j] = ht_hash(key[j], M - 1);
+            sv[j] = live[j] ? gtab[hpos[j]] : HT_EMPTY;
+        }
+        int32_t f[HITS_MLP];
+#pragma unroll
+        for (int j = 0; j < HITS_MLP; ++j) {                               // the first columns of the direct hits, all in flight
+            f[j] = -1;
+            if (live[j] && sv[j] == key[j]) f[j] = gfirst[hpos[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < HITS_MLP; ++j) {
+            if (!live[j] || sv[j] == HT_EMPTY) continue;
+            if (sv[j] != key[j]) {                                         // collision: walk on (rare at load <= 1/2)
+                unsigned hp = (hpos[j] + 1) & (M - 1);
+                for (int probe = 1; probe < M; ++probe) {
+                    const long long v = gtab[hp];
+                    if (v == key[j]) { f[j] = gfirst[hp]; break; }
+                    if (v == HT_EMPTY) break;
+                    hp = (hp + 1) & (M - 1);
+                }
+            }
+            if (f[j] < 0) continue;
+            const uint32_t bit = 1u << ulv[j];
+            unsigned h = ((unsigned)f[j] * 2654435761u >> 7) & (HITS_CAP - 1);
+            bool placed = false;
+            for (int probe = 0; probe < HITS_PROBES; ++probe) {
+                const int32_t old = atomicCAS(&keys[h], -1, f[j]);
+                if (old == -1 || old == f[j]) { atomicOr(&bits[h], bit); placed = true; break; }
+                h = (h + 1) & (HITS_CAP - 1);
+            }
+            if (!placed) atomicOr(&plane[(int64_t)f[j] * wpr + grp], bit);     // (the planes are cleared by the set-up launch)
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < HITS_CAP; e += HITS_THREADS)
+        if (keys[e] >= 0) plane[(int64_t)keys[e] * wpr + grp] = bits[e];
 }
 
 // 32 x 32 bit transpose across the 32 lanes of a half-wave: lane i holds row i; five block-swap steps
@@ -362,7 +487,7 @@ __device__ __forceinline__ uint32_t bit_transpose32(uint32_t w, int lane) {
 // column's user bit-vector, four transposes give the mask words of 4 x 32 users
 __global__ __launch_bounds__(256) void mask_sweep_kernel(const int32_t* __restrict__ colfirst,
                                                          const uint32_t* __restrict__ ubitsT, int64_t B, int64_t Bp,
-                                                         int NT, uint32_t* __restrict__ maskW) {
+                                                         int NT, uint32_t* __restrict__ maskW, int planes, int64_t plane_words) {
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int ngrp = (int)(Bp >> 7);
     const int64_t unit = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + h;
@@ -370,7 +495,13 @@ __global__ __launch_bounds__(256) void mask_sweep_kernel(const int32_t* __restri
     const int tj = (int)(unit / ngrp), g = (int)(unit % ngrp);
     const int32_t f = colfirst[tj * 32 + c];                 // -1: padding column, never a negative
     uint4 w = {~0u, ~0u, ~0u, ~0u};
-    if (f >= 0) w = *reinterpret_cast<const uint4*>(ubitsT + (int64_t)f * (Bp >> 5) + 4 * g);
+    if (f >= 0) {
+        w = *reinterpret_cast<const uint4*>(ubitsT + (int64_t)f * (Bp >> 5) + 4 * g);
+        for (int pl = 1; pl < planes; ++pl) {                   // (the pieces of a split group each own a plane)
+            const uint4 o = *reinterpret_cast<const uint4*>(ubitsT + pl * plane_words + (int64_t)f * (Bp >> 5) + 4 * g);
+            w.x |= o.x; w.y |= o.y; w.z |= o.z; w.w |= o.w;
+        }
+    }
     const uint32_t in[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1238,25 +1369,40 @@ __global__ __launch_bounds__(256) void dv_fix_to_f32_kernel(const long long* __r
 
 // ------------------------------------------------------------------ C ABI ------
 // negative_masks of the reference (losses.py:92-110) into w.maskW
-static void clear_mask_tables(const LossWs& w, hipStream_t s) {     // mf_loss_fwd does this inside prep_kernel
+static void clear_mask_tables(const LossWs& w, int planes, hipStream_t s) {     // mf_loss_fwd does this inside prep_kernel
     (void)hipMemsetAsync(w.gtab, 0x80, (size_t)w.M * 8, s);
     (void)hipMemsetAsync(w.gfirst, 0x7f, (size_t)w.M * 4, s);
-    (void)hipMemsetAsync(w.ubits, 0, (size_t)w.NT * w.Bp * 4, s);
+    (void)hipMemsetAsync(w.ubits, 0, (size_t)planes * w.NT * w.Bp * 4, s);
+    (void)hipMemsetAsync(w.bmap, 0, (size_t)4 << (w.bmbits - 5), s);
+}
+static void prep_clears(PrepParams& pp, const LossWs& w, int planes) {
+    pp.gtab = reinterpret_cast<uint4*>(w.gtab); pp.gtab16 = (int64_t)w.M * 8 / 16;
+    pp.gfirst = reinterpret_cast<uint4*>(w.gfirst); pp.gfirst16 = (int64_t)w.M * 4 / 16;
+    pp.ubits = reinterpret_cast<uint4*>(w.ubits); pp.ubits16 = (int64_t)planes * w.NT * w.Bp * 4 / 16;
+    pp.bmap = reinterpret_cast<uint4*>(w.bmap); pp.bmap16 = ((int64_t)4 << (w.bmbits - 5)) / 16;
 }
 
-// expects gtab / gfirst / ubits cleared
-static void build_masks(const LossWs& w, const int64_t* item_idx, const int64_t* pos_idx, int64_t B, int64_t N, int P,
-                        hipStream_t s) {
-    gt_insert_kernel<<<dim3((unsigned)((N + 63) / 64)), 64, 0, s>>>(item_idx, N, w.M, w.gtab, w.gfirst, w.colslot);
-    const int nb_col = (int)((w.Np + 1023) / 1024);
-    const int nb_u = (int)((B + 31) / 32);
-    int cap = 64;
-    while (cap < 2 * 32 * (P + 1)) cap *= 2;
-    if (cap > 8192) cap = 0;                                 // very long positive lists: global atomics
-    hits_kernel<<<dim3((unsigned)(nb_col + nb_u)), 1024, (size_t)cap * 8, s>>>(item_idx, pos_idx, B, N, w.Bp, w.Np, P, w.M, nb_col, cap,
-                                                                              w.gtab, w.gfirst, w.colslot, w.colfirst, w.ubits);
+// pieces a group's flat list range is cut into (= planes of ubitsT in use): CSR lists are heavy-tailed and unknown to the
+// host -> the maximum; padded lists by their width (P = 64: one piece, as before)
+static int hits_split(const PosSrc& src) {
+    if (src.pos_off) return HITS_MAX_SPLIT;
+    const int per_group = 32 * (src.P + 1);
+    int sp = (per_group + 8191) / 8192;
+    return sp < 1 ? 1 : (sp > HITS_MAX_SPLIT ? HITS_MAX_SPLIT : sp);
+}
+
+// expects gtab / gfirst / bmap and hits_split(src) planes of ubits cleared
+static void build_masks(const LossWs& w, const int64_t* item_idx, const PosSrc& src, int64_t B, int64_t N, hipStream_t s) {
+    gt_insert_kernel<<<dim3((unsigned)((N + 63) / 64)), 64, 0, s>>>(item_idx, N, w.M, w.gtab, w.gfirst, w.colslot, w.bmap, w.bmbits);
+    const int split = hits_split(src);
+    const int nb_col = (int)((w.Np + HITS_THREADS - 1) / HITS_THREADS);
+    const int nb_u = (int)((B + 31) / 32) * split;
+    const size_t lds = (size_t)HITS_CAP * 8 + ((size_t)4 << (w.bmbits - 5));
+    hits_kernel<<<dim3((unsigned)(nb_col + nb_u)), HITS_THREADS, lds, s>>>(item_idx, src, B, N, w.Bp, w.Np, w.M, nb_col, split, w.gtab,
+                                                                           w.gfirst, w.colslot, w.colfirst, w.ubits, w.bmap, w.bmbits);
     const int64_t units = (int64_t)w.NT * (w.Bp >> 7);
-    mask_sweep_kernel<<<dim3((unsigned)((units + 7) / 8)), 256, 0, s>>>(w.colfirst, w.ubits, B, w.Bp, w.NT, w.maskW);
+    mask_sweep_kernel<<<dim3((unsigned)((units + 7) / 8)), 256, 0, s>>>(w.colfirst, w.ubits, B, w.Bp, w.NT, w.maskW, split,
+                                                                       (int64_t)w.Np * (w.Bp >> 5));
 }
 
 template <int D, bool XU>
@@ -1294,61 +1440,81 @@ static int check_loss_args(const char* what, int64_t B, int64_t N, int d, int P,
 // The hit masks depend on the batch's ids only: built ahead of the forward (on another stream, beside the
 // tower gathers) they leave its critical path.  Fills ws's maskW; the forward is then called with
 // item_idx = NULL ("masks are in ws").
-extern "C" int mf_loss_masks(int64_t B, int64_t N, int d, int P, int num_negatives, const int64_t* item_idx,
-                             const int64_t* pos_idx, void* ws, size_t ws_bytes, mf_stream_t stream) {
-    if (B <= 0 || N < B || !mf_width_ok(d) || P < 0 || !item_idx || !ws || (P > 0 && !pos_idx))
-        return mf_set_error(MF_EINVAL, "mf_loss_masks: bad argument");
-    if (N >= (1 << 24)) return mf_set_error(MF_ENOTSUP, "mf_loss_masks: N >= 2^24");
-    if (ws_bytes < mf_loss_ws_bytes(B, N, d, P, num_negatives)) return mf_set_error(MF_ENOSPC, "mf_loss_masks: workspace too small");
+static int loss_masks_impl(const char* what, int64_t B, int64_t N, int d, int num_negatives, const int64_t* item_idx, const PosSrc& src,
+                           void* ws, size_t ws_bytes, mf_stream_t stream) {
+    if (B <= 0 || N < B || !mf_width_ok(d) || !item_idx || !ws) return mf_set_error(MF_EINVAL, "%s: bad argument", what);
+    if (N >= (1 << 24)) return mf_set_error(MF_ENOTSUP, "%s: N >= 2^24", what);
+    if (ws_bytes < mf_loss_ws_bytes(B, N, d, 0, num_negatives)) return mf_set_error(MF_ENOSPC, "%s: workspace too small", what);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    LossWs w = loss_ws(ws, B, N, d, P, num_negatives);
+    LossWs w = loss_ws(ws, B, N, d, 0, num_negatives);
     PrepParams pp{};
-    pp.gtab = reinterpret_cast<uint4*>(w.gtab); pp.gtab16 = (int64_t)w.M * 8 / 16;
-    pp.gfirst = reinterpret_cast<uint4*>(w.gfirst); pp.gfirst16 = (int64_t)w.M * 4 / 16;
-    pp.ubits = reinterpret_cast<uint4*>(w.ubits); pp.ubits16 = (int64_t)w.NT * w.Bp * 4 / 16;
+    prep_clears(pp, w, hits_split(src));
     pp.ticket = w.ticket;
     const int64_t want = (pp.ubits16 + 64 * 8 - 1) / (64 * 8);
     prep_kernel<0><<<dim3((unsigned)(want < 8192 ? (want > 0 ? want : 1) : 8192)), 64, 0, s>>>(pp);   // clears only
-    build_masks(w, item_idx, pos_idx, B, N, P, s);
-    return mf_check_launch("mf_loss_masks");
+    build_masks(w, item_idx, src, B, N, s);
+    return mf_check_launch(what);
 }
 
-extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
-                           int kind_mask, const float* u, const float* v, const void* target,
-                           const int64_t* item_idx, const int64_t* pos_idx, const float* logq, int64_t logq_rows,
-                           int flags, void* ws, size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits,
-                           mf_stream_t stream) {
-    int rc = check_loss_args("mf_loss_fwd", B, N, d, P, num_negatives, u, v, target, ws, ws_bytes);
+static int pos_src_check(const char* what, const PosSrc& src) {
+    if (src.pos_off) {
+        if (!src.user_ids || !src.pos_items || src.num_users <= 0) return mf_set_error(MF_EINVAL, "%s: CSR positives need user_ids, pos_off, pos_items, num_users > 0", what);
+    } else if (src.P < 0 || (src.P > 0 && !src.pos_idx)) {
+        return mf_set_error(MF_EINVAL, "%s: bad positives", what);
+    }
+    return MF_OK;
+}
+
+extern "C" int mf_loss_masks(int64_t B, int64_t N, int d, int P, int num_negatives, const int64_t* item_idx,
+                             const int64_t* pos_idx, void* ws, size_t ws_bytes, mf_stream_t stream) {
+    const PosSrc src{pos_idx, P, nullptr, nullptr, nullptr, 0};
+    if (int rc = pos_src_check("mf_loss_masks", src)) return rc;
+    return loss_masks_impl("mf_loss_masks", B, N, d, num_negatives, item_idx, src, ws, ws_bytes, stream);
+}
+
+extern "C" int mf_loss_masks_csr(int64_t B, int64_t N, int d, int num_negatives, const int64_t* item_idx, const int64_t* user_ids,
+                                 const int64_t* pos_off, const int64_t* pos_items, int64_t num_users, void* ws, size_t ws_bytes,
+                                 mf_stream_t stream) {
+    const PosSrc src{nullptr, 0, user_ids, pos_off, pos_items, num_users};
+    if (!pos_off) return mf_set_error(MF_EINVAL, "mf_loss_masks_csr: pos_off is NULL");
+    if (int rc = pos_src_check("mf_loss_masks_csr", src)) return rc;
+    return loss_masks_impl("mf_loss_masks_csr", B, N, d, num_negatives, item_idx, src, ws, ws_bytes, stream);
+}
+
+static int loss_fwd_impl(const char* what, int64_t B, int64_t N, int d, const PosSrc& src, int num_negatives, float sigma, float margin,
+                         int kind_mask, const float* u, const float* v, const void* target,
+                         const int64_t* item_idx, const float* logq, int64_t logq_rows,
+                         int flags, void* ws, size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits,
+                         mf_stream_t stream) {
+    int rc = check_loss_args(what, B, N, d, 0, num_negatives, u, v, target, ws, ws_bytes);
     if (rc) return rc;
     const bool masks_ready = item_idx == nullptr || (flags & MF_LOSS_MASKS_READY);       // mf_loss_masks ran on this workspace
-    if (!out_losses || (!masks_ready && P > 0 && !pos_idx) || !(kind_mask & 0x7F))
-        return mf_set_error(MF_EINVAL, "mf_loss_fwd: bad argument");
-    if (logq && logq_rows > 0 && !item_idx) return mf_set_error(MF_EINVAL, "mf_loss_fwd: a logQ table needs item_idx");
+    if (!out_losses || !(kind_mask & 0x7F)) return mf_set_error(MF_EINVAL, "%s: bad argument", what);
+    if (!masks_ready && (rc = pos_src_check(what, src))) return rc;
+    if (logq && logq_rows > 0 && !item_idx) return mf_set_error(MF_EINVAL, "%s: a logQ table needs item_idx", what);
     int rowc_kind = -1;
     if (flags & MF_LOSS_ROWC) {
-        if (__builtin_popcount(kind_mask & 0x7F) != 1) return mf_set_error(MF_EINVAL, "mf_loss_fwd: MF_LOSS_ROWC needs exactly one loss kind");
+        if (__builtin_popcount(kind_mask & 0x7F) != 1) return mf_set_error(MF_EINVAL, "%s: MF_LOSS_ROWC needs exactly one loss kind", what);
         rowc_kind = __builtin_ctz(kind_mask & 0x7F);
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    LossWs w = loss_ws(ws, B, N, d, P, num_negatives);
+    LossWs w = loss_ws(ws, B, N, d, 0, num_negatives);
     const int need = need_flags(kind_mask);
     const bool scores_needed = (kind_mask & ~(1 << MF_ALIGNMENT)) != 0 || out_mask_bits;
 
     {
         PrepParams pp{u, v, target, logq, item_idx, logq_rows, (flags & MF_LOSS_TARGET_I64) ? 1 : 0,
                       B, N, w.Bp, w.Np, d, sigma, w.nu, w.nv, w.lii, w.dii, w.sgn, w.logq, w.tgt,
-                      nullptr, 0, nullptr, 0, nullptr, 0, w.ticket};
+                      nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, w.ticket};
         int nb = (int)((w.Np + 63) / 64);
         if (scores_needed && !masks_ready) {
-            pp.gtab = reinterpret_cast<uint4*>(w.gtab); pp.gtab16 = (int64_t)w.M * 8 / 16;
-            pp.gfirst = reinterpret_cast<uint4*>(w.gfirst); pp.gfirst16 = (int64_t)w.M * 4 / 16;
-            pp.ubits = reinterpret_cast<uint4*>(w.ubits); pp.ubits16 = (int64_t)w.NT * w.Bp * 4 / 16;
+            prep_clears(pp, w, hits_split(src));
             const int64_t want = (pp.ubits16 + 64 * 8 - 1) / (64 * 8);       // ~8 stores per thread
             if (want > nb) nb = (int)(want < 8192 ? want : 8192);
         }
         MF_DISPATCH_D(d, { prep_kernel<D><<<dim3((unsigned)nb), 64, 0, s>>>(pp); });
     }
-    if (scores_needed && !masks_ready) build_masks(w, item_idx, pos_idx, B, N, P, s);
+    if (scores_needed && !masks_ready) build_masks(w, item_idx, src, B, N, s);
     // logq is read by whole float4s up to the padded width: prep_kernel keeps a zero-padded copy in ws
     // (all zeros when there is no logQ correction: L - 0 is exact, and the kernels stay branch-free)
     const float* logq_p = w.logq;
@@ -1391,7 +1557,29 @@ extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives
                                                                                        sigma, kind_mask, w.stats, w.rowloss,
                                                                                        w.blockpart, w.ticket, out_losses,
                                                                                        rowc_kind, margin, w.sgn, w.rowc);
-    return mf_check_launch("mf_loss_fwd");
+    return mf_check_launch(what);
+}
+
+extern "C" int mf_loss_fwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
+                           int kind_mask, const float* u, const float* v, const void* target,
+                           const int64_t* item_idx, const int64_t* pos_idx, const float* logq, int64_t logq_rows,
+                           int flags, void* ws, size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits,
+                           mf_stream_t stream) {
+    const PosSrc src{pos_idx, P, nullptr, nullptr, nullptr, 0};
+    return loss_fwd_impl("mf_loss_fwd", B, N, d, src, num_negatives, sigma, margin, kind_mask, u, v, target, item_idx, logq, logq_rows,
+                         flags, ws, ws_bytes, out_losses, out_mask_bits, stream);
+}
+
+extern "C" int mf_loss_fwd_csr(int64_t B, int64_t N, int d, int num_negatives, float sigma, float margin,
+                               int kind_mask, const float* u, const float* v, const void* target,
+                               const int64_t* item_idx, const int64_t* user_ids, const int64_t* pos_off, const int64_t* pos_items,
+                               int64_t num_users, const float* logq, int64_t logq_rows,
+                               int flags, void* ws, size_t ws_bytes, float* out_losses, uint32_t* out_mask_bits,
+                               mf_stream_t stream) {
+    if (!pos_off && !(item_idx == nullptr || (flags & MF_LOSS_MASKS_READY))) return mf_set_error(MF_EINVAL, "mf_loss_fwd_csr: pos_off is NULL");
+    const PosSrc src{nullptr, 0, user_ids, pos_off, pos_items, num_users};
+    return loss_fwd_impl("mf_loss_fwd_csr", B, N, d, src, num_negatives, sigma, margin, kind_mask, u, v, target, item_idx, logq, logq_rows,
+                         flags, ws, ws_bytes, out_losses, out_mask_bits, stream);
 }
 
 extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sigma, float margin,
@@ -1469,8 +1657,9 @@ extern "C" int mf_negative_masks(int64_t B, int64_t N, int P, const int64_t* ite
     if (ws_bytes < mf_negative_masks_ws_bytes(B, N, P)) return mf_set_error(MF_ENOSPC, "mf_negative_masks: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     LossWs w = loss_ws(ws, B, N, 32, P, 1);
-    clear_mask_tables(w, s);
-    build_masks(w, item_idx, pos_idx, B, N, P, s);
+    const PosSrc src{pos_idx, P, nullptr, nullptr, nullptr, 0};
+    clear_mask_tables(w, hits_split(src), s);
+    build_masks(w, item_idx, src, B, N, s);
     mask_export_bool_kernel<<<dim3((unsigned)((B * N + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, out_mask);
     return mf_check_launch("mf_negative_masks");
 }

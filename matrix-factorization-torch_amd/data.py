@@ -31,9 +31,10 @@ class ItemBatchType(TypedDict):
     idx: torch.Tensor
 
 
-class UserBatchType(TypedDict):
+class UserBatchType(TypedDict, total=False):
     idx: torch.Tensor
-    pos_idx: torch.Tensor
+    pos_idx: torch.Tensor                 # the reference's padded positives [B, P] ...
+    pos_csr: tuple                        # ... or (user idx [B], pos_off [U + 1], pos_items): the lists in place (no padding)
 
 
 class InteractionBatchType(TypedDict):
@@ -253,12 +254,14 @@ class DeviceInteractionSampler:
     ``batch(step)`` is example positions ``step * batch_size ...`` of a stream that is reshuffled
     every epoch; the same (seed, step) always gives the same batch.
 
-    ``pos_pad`` = width of ``pos_idx``.  The reference passes ALL of a user's targets and pads to the longest list of
-    the batch (data/lightning.py:275-279, load.py:38-55): ``None`` (default) sizes it to the longest list of the data,
-    so no positive is ever dropped; a smaller explicit value would silently turn positives into negatives and is
-    refused unless ``truncate_positives=True`` says that this is wanted.  ``user_range=(lo, hi)`` keeps only the pairs
-    of users ``lo <= u < hi``: the per-rank stream of a user-sharded job (``distributed.ShardedTrainer`` partitions
-    the training pairs by user shard)."""
+    Positives.  The reference passes ALL of a user's targets and pads to the longest list of the batch
+    (data/lightning.py:275-279, load.py:38-55).  Default (``pos_pad=None``): **no padded tensor at all** -- a batch carries
+    ``user.pos_csr = (user idx, pos_off, pos_items)``, the sampler's own HBM-resident lists, and the mask kernels read them
+    in place (``mf_loss_fwd_csr``): nothing is ever dropped, and a user with 30,000 ratings costs 30,000 list reads, not a
+    30,000-column matrix.  ``pos_pad=P``: the reference's layout, ``user.pos_idx[B, P]`` 0-padded on the right; a P shorter
+    than the longest list of the data would silently turn positives into negatives and is refused unless
+    ``truncate_positives=True`` says that this is wanted.  ``user_range=(lo, hi)`` keeps only the pairs of users
+    ``lo <= u < hi``: the per-rank stream of a user-partitioned job (``distributed.ShardedTrainer(user_mode="partitioned")``)."""
 
     def __init__(self, pair_user, pair_item, pair_target, pos_off, pos_items, *, num_items: int,
                  batch_size: int = BATCH_SIZE, pos_pad: int | None = None, seed: int = 0, device="cuda",
@@ -286,7 +289,7 @@ class DeviceInteractionSampler:
             raise ValueError(msg)
         longest = int((self.pos_off[1:] - self.pos_off[:-1]).max()) if self.pos_off.numel() > 1 else 0
         if pos_pad is None:
-            pos_pad = max(longest, 1)
+            pos_pad = 0                      # CSR mode: batches carry the lists themselves
         elif longest > pos_pad and not truncate_positives:
             msg = (f"pos_pad = {pos_pad} would drop positives (longest list: {longest}); the dropped items would enter the "
                    "losses as negatives.  Pass pos_pad=None (sized from the data) or truncate_positives=True")
@@ -303,14 +306,14 @@ class DeviceInteractionSampler:
         user = torch.empty(b, dtype=torch.int64, device=dev)
         item = torch.empty(2 * b, dtype=torch.int64, device=dev)
         target = torch.empty(b, dtype=torch.float32, device=dev)
-        pos = torch.empty(b, p, dtype=torch.int64, device=dev)
+        pos = torch.empty(b, p, dtype=torch.int64, device=dev) if p > 0 else None
         lib = self._lib
         lib.check(lib.lib().mf_sample_batch(self.pair_user.data_ptr(), self.pair_item.data_ptr(), self.pair_target.data_ptr(),
                                             self.pair_user.numel(), self.pos_off.data_ptr(), self.pos_items.data_ptr(),
                                             self.num_items, self.seed, int(step) * b, b, p, user.data_ptr(), item.data_ptr(),
-                                            target.data_ptr(), pos.data_ptr(), lib.stream_ptr()))
-        return {"target": target, "user": {"idx": user, "pos_idx": pos}, "item": {"idx": item[:b]},
-                "neg_item": {"idx": item[b:]}}
+                                            target.data_ptr(), None if pos is None else pos.data_ptr(), lib.stream_ptr()))
+        ub = {"idx": user, "pos_idx": pos} if pos is not None else {"idx": user, "pos_csr": (user, self.pos_off, self.pos_items)}
+        return {"target": target, "user": ub, "item": {"idx": item[:b]}, "neg_item": {"idx": item[b:]}}
 
     def __iter__(self) -> Iterator[InteractionBatchType]:
         step = 0

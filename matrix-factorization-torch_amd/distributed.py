@@ -259,12 +259,13 @@ class HipOps:
                                                     unit.shape[1], graw.data_ptr(), _lib.stream_ptr()))
         return graw.repeat_interleave(num_hashes, dim=0) if num_hashes > 1 else graw
 
-    def loss_and_grads(self, kind, u, v, target, item_idx, pos_idx, logq_table, num_negatives, sigma, margin):
-        """``logq_table``: logQ of every GLOBAL item row (looked up by ``item_idx`` inside the kernel), or None."""
+    def loss_and_grads(self, kind, u, v, target, item_idx, pos_idx, logq_table, num_negatives, sigma, margin, pos_csr=None):
+        """``logq_table``: logQ of every GLOBAL item row (looked up by ``item_idx`` inside the kernel), or None.
+        ``pos_csr``: (user ids, pos_off, pos_items) instead of the padded ``pos_idx``."""
         u = u.detach().requires_grad_()
         v = v.detach().requires_grad_()
         fn = getattr(self.mf.losses, kind)(num_negatives=num_negatives, sigma=sigma, margin=margin)
-        loss = fn(u, v, target, item_idx=item_idx, pos_idx=pos_idx, logq_table=logq_table)
+        loss = fn(u, v, target, item_idx=item_idx, pos_idx=pos_idx, logq_table=logq_table, pos_csr=pos_csr)
         one = getattr(self, "_one", None)
         if one is None or one.device != u.device:
             one = self._one = torch.ones((), device=u.device)
@@ -628,7 +629,8 @@ class ShardedTrainer:
     # -- one step -----------------------------------------------------------------------------
     def step(self, b, next_b=None) -> torch.Tensor:
         """``b``: ``user`` (global user rows -- any, or this rank's block in "partitioned" mode; any ids with hashed
-        towers), ``item`` (2B global rows: positives then negatives), ``target``, ``pos``.  ``next_b``: the batch
+        towers), ``item`` (2B global rows: positives then negatives), ``target``, ``pos`` (padded positives) or ``pos_csr``
+        ((user ids, pos_off, pos_items): the lists in place).  ``next_b``: the batch
         after it, if known (its exchange plan is then prefetched behind this step's compute)."""
         self.steps += 1
         self._raise_failed(block=False)           # flags of earlier steps whose host copies have landed by now
@@ -665,7 +667,8 @@ class ShardedTrainer:
             user_local = b["user"] - self.user_lo
             v = plan.item.fetch(ops.gather(self.item_table, plan.item.local_ids, True))
             u = ops.gather(self.user_table, user_local, True)
-        loss, du, dv = ops.loss_and_grads(self.kind, u, v, b["target"], b["item"], b["pos"], self.logq, self.num_negatives, 1.0, 1.0)
+        kw = {"pos_csr": b["pos_csr"]} if b.get("pos_csr") is not None else {}      # (CSR lists: HipOps only)
+        loss, du, dv = ops.loss_and_grads(self.kind, u, v, b["target"], b["item"], b.get("pos"), self.logq, self.num_negatives, 1.0, 1.0, **kw)
         if next_b is not None:
             self.prefetch(next_b, after=entry)    # the GPU is busy with the sweeps just queued
         if H:

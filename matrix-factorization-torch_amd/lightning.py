@@ -148,7 +148,8 @@ class MatrixFactorizationLitModule(_Base):
             msg = "`loss_fns` must be initialised first"
             raise ValueError(msg)
         target = batch["target"]
-        pos_idx = batch["user"]["pos_idx"]
+        pos_idx = batch["user"].get("pos_idx")            # the reference's padded positives, or ...
+        pos_csr = batch["user"].get("pos_csr")            # ... the producer's CSR lists (data.DeviceInteractionSampler)
         user_embed = self(batch["user"]["idx"], tower="user")
         # positives then sampled negatives, as xfmr_rec/lightning.py:133-134
         item_idx = torch.cat([batch["item"]["idx"], batch["neg_item"]["idx"]])
@@ -159,12 +160,12 @@ class MatrixFactorizationLitModule(_Base):
         if cfg.fused_losses:
             vals = mf_losses.fused_losses(user_embed, item_embed, target, item_idx=item_idx, pos_idx=pos_idx,
                                           num_negatives=cfg.num_negatives, sigma=cfg.sigma, margin=cfg.margin,
-                                          logq_table=logq_table,
+                                          logq_table=logq_table, pos_csr=pos_csr,
                                           train_loss=cfg.train_loss if step_name == "train" else None)
             return {f"{step_name}/{name}": v for name, v in vals.items()}
         return {
             f"{step_name}/{fn.__class__.__name__}": fn(user_embed=user_embed, item_embed=item_embed, target=target,
-                                                       item_idx=item_idx, pos_idx=pos_idx, logq_table=logq_table)
+                                                       item_idx=item_idx, pos_idx=pos_idx, logq_table=logq_table, pos_csr=pos_csr)
             for fn in self.loss_fns
         }
 

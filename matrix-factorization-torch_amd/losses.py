@@ -8,9 +8,11 @@ item_idx, pos_idx)``; losses.py:39-52) and ``ValueError`` behaviour
 in ``libmf_hip.so`` (``mf_loss_fwd`` / ``mf_loss_bwd``); there is no torch fallback.
 
 Extensions (absent upstream, default off): ``logq=`` (logQ correction
-``L_ij -= logq[j]``) and :func:`fused_losses` (all seven values from ONE pass over
+``L_ij -= logq[j]``), :func:`fused_losses` (all seven values from ONE pass over
 the score tiles, as ``compute_losses`` evaluates all seven every step,
-xfmr_rec/lightning.py:137-146).
+xfmr_rec/lightning.py:137-146) and ``pos_csr=(user_ids, pos_off, pos_items)``: the users' positive lists as the batch
+producer keeps them in HBM (CSR over ALL users) instead of the padded ``pos_idx[B, P]`` -- the reference pads every batch
+to its longest list (xfmr_rec/data/lightning.py:274-280), > 10^4 columns for MovieLens-25M; the masks are the same bits.
 """
 from __future__ import annotations
 
@@ -81,6 +83,20 @@ def weighted_mean(values: torch.Tensor, sample_weights: torch.Tensor, *, dim: in
     return (values * sample_weights / denominator).sum(dim=dim, keepdim=keepdim)
 
 
+def _csr_args(pos_csr, batch: int):
+    """(user_ids [B], pos_off [U + 1], pos_items, U) as contiguous int64 GPU tensors, checked."""
+    if len(pos_csr) != 3:  # noqa: PLR2004
+        msg = "pos_csr should be (user_ids, pos_off, pos_items)"
+        raise ValueError(msg)
+    uid, off, items = (_lib.dev_i64(t, name) for t, name in zip(pos_csr, ("pos_csr user_ids", "pos_csr pos_off", "pos_csr pos_items")))
+    if uid.numel() != batch or off.numel() < 2:  # noqa: PLR2004
+        msg = f"pos_csr needs one user id per batch row and at least one list: {uid.numel() = }, {batch = }, {off.numel() = }"
+        raise ValueError(msg)
+    if items.numel() == 0:
+        items = torch.zeros(1, dtype=torch.int64, device=uid.device)     # keeps the pointer valid
+    return uid, off, items, off.numel() - 1
+
+
 def _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq, logq_table=None):
     u = _lib.dev_f32(user_embed, "user_embed")
     v = _lib.dev_f32(item_embed, "item_embed")
@@ -133,11 +149,15 @@ class PreparedMasks:
 _side_stream: dict = {}
 
 
-def prepare_masks(item_idx, pos_idx, *, batch_size: int, embedding_dim: int, num_negatives: int = 0) -> PreparedMasks:
+def prepare_masks(item_idx, pos_idx, *, batch_size: int, embedding_dim: int, num_negatives: int = 0, pos_csr=None) -> PreparedMasks:
     ii = _lib.dev_i64(item_idx, "item_idx")
     pi = None if pos_idx is None or pos_idx.shape[1] == 0 else _lib.dev_i64(pos_idx, "pos_idx")
     p = 0 if pi is None else pi.shape[1]
     b, n, dp = int(batch_size), ii.numel(), _lib.padded_width(int(embedding_dim))
+    csr = None if pos_csr is None else _csr_args(pos_csr, b)
+    if csr is not None and pi is not None:
+        msg = "pass either pos_idx (padded) or pos_csr, not both"
+        raise ValueError(msg)
     lib = _lib.lib()
     cur = torch.cuda.current_stream()
     side = _side_stream.get(ii.device)
@@ -147,13 +167,18 @@ def prepare_masks(item_idx, pos_idx, *, batch_size: int, embedding_dim: int, num
     ws = lease.tensor
     side.wait_stream(cur)                       # the ids, and the workspace's previous use, are on the caller's stream
     with torch.cuda.stream(side):
-        _lib.check(lib.mf_loss_masks(b, n, dp, p, int(num_negatives), _lib.ptr(ii), _lib.ptr(pi), _lib.ptr(ws), ws.numel(),
-                                     _lib.stream_ptr()))
+        if csr is None:
+            _lib.check(lib.mf_loss_masks(b, n, dp, p, int(num_negatives), _lib.ptr(ii), _lib.ptr(pi), _lib.ptr(ws), ws.numel(),
+                                         _lib.stream_ptr()))
+        else:
+            _lib.check(lib.mf_loss_masks_csr(b, n, dp, int(num_negatives), _lib.ptr(ii), _lib.ptr(csr[0]), _lib.ptr(csr[1]),
+                                             _lib.ptr(csr[2]), csr[3], _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
         event = torch.cuda.Event()
         event.record(side)
-    for t in (ii,) + (() if pi is None else (pi,)):
+    for t in (ii,) + (() if pi is None else (pi,)) + (() if csr is None else csr[:3]):
         t.record_stream(side)
-    return PreparedMasks(lease, event, (b, n, dp, p, int(num_negatives), ii.data_ptr(), None if pi is None else pi.data_ptr()))
+    pos_key = (None if pi is None else pi.data_ptr()) if csr is None else ("csr", csr[0].data_ptr(), csr[1].data_ptr())
+    return PreparedMasks(lease, event, (b, n, dp, p, int(num_negatives), ii.data_ptr(), pos_key))
 
 
 class _LossFunction(torch.autograd.Function):
@@ -161,12 +186,17 @@ class _LossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, user_embed, item_embed, target, item_idx, pos_idx, logq, kind_mask, bwd_kind,
-                num_negatives, sigma, margin, prepared=None, logq_table=None, train_kind=None):
+                num_negatives, sigma, margin, prepared=None, logq_table=None, train_kind=None, pos_csr=None):
         u, v, t, ii, pi, p, (lq, lq_rows), d, dp = _prepare(user_embed, item_embed, target, item_idx, pos_idx, logq, logq_table)
         b, n = u.shape[0], v.shape[0]
+        csr = None if pos_csr is None else _csr_args(pos_csr, b)
+        if csr is not None and pi is not None:
+            msg = "pass either pos_idx (padded) or pos_csr, not both"
+            raise ValueError(msg)
         lib = _lib.lib()
         if prepared is not None:
-            if prepared.key != (b, n, dp, p, int(num_negatives), ii.data_ptr(), None if pi is None else pi.data_ptr()):
+            pos_key = (None if pi is None else pi.data_ptr()) if csr is None else ("csr", csr[0].data_ptr(), csr[1].data_ptr())
+            if prepared.key != (b, n, dp, p, int(num_negatives), ii.data_ptr(), pos_key):
                 msg = "prepared masks belong to another batch / shape"
                 raise ValueError(msg)
             torch.cuda.current_stream().wait_event(prepared.event)
@@ -177,9 +207,15 @@ class _LossFunction(torch.autograd.Function):
         ctx.lease = lease                            # back to the pool when autograd drops this node
         out = torch.empty(len(KINDS), dtype=torch.float32, device=u.device)      # mf_loss_fwd writes all 7 entries
         flags = (_lib.LOSS_TARGET_I64 if t.dtype == torch.int64 else 0) | (_lib.LOSS_ROWC if bwd_kind is not None else 0) | ready
-        _lib.check(lib.mf_loss_fwd(b, n, dp, p, num_negatives, sigma, margin, kind_mask, _lib.ptr(u), _lib.ptr(v),
-                                   _lib.ptr(t), _lib.ptr(ii_arg), _lib.ptr(pi), _lib.ptr(lq), lq_rows, flags, _lib.ptr(ws),
-                                   ws.numel(), _lib.ptr(out), None, _lib.stream_ptr()))
+        if csr is None:
+            _lib.check(lib.mf_loss_fwd(b, n, dp, p, num_negatives, sigma, margin, kind_mask, _lib.ptr(u), _lib.ptr(v),
+                                       _lib.ptr(t), _lib.ptr(ii_arg), _lib.ptr(pi), _lib.ptr(lq), lq_rows, flags, _lib.ptr(ws),
+                                       ws.numel(), _lib.ptr(out), None, _lib.stream_ptr()))
+        else:
+            _lib.check(lib.mf_loss_fwd_csr(b, n, dp, num_negatives, sigma, margin, kind_mask, _lib.ptr(u), _lib.ptr(v),
+                                           _lib.ptr(t), _lib.ptr(ii_arg), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(csr[2]), csr[3],
+                                           _lib.ptr(lq), lq_rows, flags, _lib.ptr(ws), ws.numel(), _lib.ptr(out), None,
+                                           _lib.stream_ptr()))
         ctx.save_for_backward(u, v, ws)              # targets and logQ values live on in the workspace
         ctx.meta = (b, n, d, dp, p, num_negatives, sigma, margin, bwd_kind, user_embed.dtype, item_embed.dtype)
         ctx.train_kind = train_kind
@@ -215,7 +251,7 @@ class _LossFunction(torch.autograd.Function):
             du, dv = torch.zeros_like(u), torch.zeros_like(v)
         if dp != d:
             du, dv = du[:, :d], dv[:, :d]
-        return (du.to(u_dtype), dv.to(v_dtype)) + (None,) * 12
+        return (du.to(u_dtype), dv.to(v_dtype)) + (None,) * 13
 
 
 def check_inputs(user_embed: torch.Tensor, item_embed: torch.Tensor, target: torch.Tensor) -> None:
@@ -242,7 +278,7 @@ def _check_num_negatives(k: int, n_items: int) -> None:
 
 
 def fused_losses(user_embed, item_embed, target, *, item_idx, pos_idx, num_negatives=0, sigma=1.0, margin=1.0,
-                 logq=None, logq_table=None, kinds=KINDS, train_loss: str | None = None) -> dict[str, torch.Tensor]:
+                 logq=None, logq_table=None, kinds=KINDS, train_loss: str | None = None, pos_csr=None) -> dict[str, torch.Tensor]:
     """All requested losses from one sweep over the score tiles.  Every returned value is
     differentiable; backward runs one HIP backward per loss that receives gradient.  ``train_loss`` names the one
     loss that will be back-propagated (xfmr_rec/lightning.py:192): the others are then constants of the backward,
@@ -257,7 +293,7 @@ def fused_losses(user_embed, item_embed, target, *, item_idx, pos_idx, num_negat
         raise ValueError(msg)
     out = _LossFunction.apply(user_embed, item_embed, target, item_idx, pos_idx, logq, mask, None,
                               int(num_negatives), float(sigma), float(margin), None, logq_table,
-                              None if train_loss is None else KINDS.index(train_loss))
+                              None if train_loss is None else KINDS.index(train_loss), pos_csr)
     return {name: out[KINDS.index(name)] for name in kinds}
 
 
@@ -278,21 +314,23 @@ class EmbeddingLoss(torch.nn.Module, abc.ABC):
         check_inputs(user_embed, item_embed, target)
 
     def forward(self, user_embed: torch.Tensor, item_embed: torch.Tensor, target: torch.Tensor, *,
-                item_idx: torch.Tensor, pos_idx: torch.Tensor | None, logq: torch.Tensor | None = None,
-                prepared: PreparedMasks | None = None, logq_table: torch.Tensor | None = None) -> torch.Tensor:
+                item_idx: torch.Tensor, pos_idx: torch.Tensor | None = None, logq: torch.Tensor | None = None,
+                prepared: PreparedMasks | None = None, logq_table: torch.Tensor | None = None, pos_csr=None) -> torch.Tensor:
         """``logq`` (one value per item row of the batch) or ``logq_table`` (a table over all item rows, looked up by
-        ``item_idx`` inside the kernel) switch on the logQ correction ``L_ij -= logq_j`` (our extension)."""
+        ``item_idx`` inside the kernel) switch on the logQ correction ``L_ij -= logq_j`` (our extension).
+        ``pos_csr = (user_ids [B], pos_off [U + 1], pos_items)`` gives the positives as CSR lists over all users
+        instead of the padded ``pos_idx`` (module docstring)."""
         self.check_inputs(user_embed, item_embed, target)
         return self.loss(user_embed, item_embed, target, item_idx=item_idx, pos_idx=pos_idx, logq=logq, prepared=prepared,
-                         logq_table=logq_table)
+                         logq_table=logq_table, pos_csr=pos_csr)
 
     def prepare_masks(self, item_idx: torch.Tensor, pos_idx: torch.Tensor | None, *, batch_size: int,
-                      embedding_dim: int) -> PreparedMasks:
+                      embedding_dim: int, pos_csr=None) -> PreparedMasks:
         """Optional (no reference counterpart): build this batch's hit masks NOW, on a side stream -- they
         depend on the ids only -- and hand the result to ``forward(..., prepared=...)`` with the SAME
         ``item_idx`` / ``pos_idx`` tensors.  Takes ~35 us of small kernels off the step's critical path."""
         return prepare_masks(item_idx, pos_idx, batch_size=batch_size, embedding_dim=embedding_dim,
-                             num_negatives=int(self.num_negatives))
+                             num_negatives=int(self.num_negatives), pos_csr=pos_csr)
 
     # ---- the reference's public helper methods, on caller-provided tensors (API parity; not the hot path)
     @torch.no_grad()
@@ -326,18 +364,18 @@ class EmbeddingLoss(torch.nn.Module, abc.ABC):
         """losses.py:134-162 on a materialised logits matrix (the losses themselves mine on the fly)."""
         return self._mine(logits, negative_masks, semi_hard=True)
 
-    def _loss_of_kind(self, kind: int, user_embed, item_embed, target, *, item_idx, pos_idx, logq=None, prepared=None,
-                      logq_table=None) -> torch.Tensor:
+    def _loss_of_kind(self, kind: int, user_embed, item_embed, target, *, item_idx, pos_idx=None, logq=None, prepared=None,
+                      logq_table=None, pos_csr=None) -> torch.Tensor:
         k = int(self.num_negatives)
         if kind != 0:
             _check_num_negatives(k, item_embed.size(0))
         return _LossFunction.apply(user_embed, item_embed, target, item_idx, pos_idx, logq, 1 << kind, kind,
-                                   k, float(self.sigma), float(self.margin), prepared, logq_table)
+                                   k, float(self.sigma), float(self.margin), prepared, logq_table, None, pos_csr)
 
-    def loss(self, user_embed, item_embed, target, *, item_idx, pos_idx, logq=None, prepared=None,
-             logq_table=None) -> torch.Tensor:
+    def loss(self, user_embed, item_embed, target, *, item_idx, pos_idx=None, logq=None, prepared=None,
+             logq_table=None, pos_csr=None) -> torch.Tensor:
         return self._loss_of_kind(self.kind, user_embed, item_embed, target, item_idx=item_idx, pos_idx=pos_idx, logq=logq,
-                                  prepared=prepared, logq_table=logq_table)
+                                  prepared=prepared, logq_table=logq_table, pos_csr=pos_csr)
 
     # ---- the reference's per-loss methods (losses.py:164-246): any instance can evaluate any of them, with ITS
     # num_negatives / sigma / margin, exactly like upstream where the subclasses only pick one
@@ -399,8 +437,8 @@ class PairwiseHingeLoss(PairwiseEmbeddingLoss):  # losses.py:357-359 (default tr
 
 
 @torch.no_grad()
-def negative_mask(user_embed, item_embed, target, *, item_idx, pos_idx, num_negatives=0, sigma=1.0,
-                  logq=None) -> torch.Tensor:
+def negative_mask(user_embed, item_embed, target, *, item_idx, pos_idx=None, num_negatives=0, sigma=1.0,
+                  logq=None, pos_csr=None) -> torch.Tensor:
     """Boolean ``[B, N]`` mask of the negatives that enter the loss: ``negative_masks``
     followed by ``semi_hard_mining`` (losses.py:92-162), computed by the HIP path
     (``out_mask_bits`` of ``mf_loss_fwd``).  Diagnostic / test helper."""
@@ -412,9 +450,15 @@ def negative_mask(user_embed, item_embed, target, *, item_idx, pos_idx, num_nega
     ws = _lib.workspace(lib.mf_loss_ws_bytes(b, n, dp, p, int(num_negatives)), u.device)
     out = torch.zeros(len(KINDS), dtype=torch.float32, device=u.device)
     bits = torch.zeros(b, nw, dtype=torch.int32, device=u.device)
-    _lib.check(lib.mf_loss_fwd(b, n, dp, p, int(num_negatives), float(sigma), 1.0, 1 << 1, _lib.ptr(u), _lib.ptr(v),
-                               _lib.ptr(t), _lib.ptr(ii), _lib.ptr(pi), _lib.ptr(lq), lq_rows,
-                               _lib.LOSS_TARGET_I64 if t.dtype == torch.int64 else 0, _lib.ptr(ws), ws.numel(),
-                               _lib.ptr(out), _lib.ptr(bits), _lib.stream_ptr()))
+    flags = _lib.LOSS_TARGET_I64 if t.dtype == torch.int64 else 0
+    if pos_csr is None:
+        _lib.check(lib.mf_loss_fwd(b, n, dp, p, int(num_negatives), float(sigma), 1.0, 1 << 1, _lib.ptr(u), _lib.ptr(v),
+                                   _lib.ptr(t), _lib.ptr(ii), _lib.ptr(pi), _lib.ptr(lq), lq_rows, flags, _lib.ptr(ws), ws.numel(),
+                                   _lib.ptr(out), _lib.ptr(bits), _lib.stream_ptr()))
+    else:
+        uid, off, items, nu = _csr_args(pos_csr, b)
+        _lib.check(lib.mf_loss_fwd_csr(b, n, dp, int(num_negatives), float(sigma), 1.0, 1 << 1, _lib.ptr(u), _lib.ptr(v),
+                                       _lib.ptr(t), _lib.ptr(ii), _lib.ptr(uid), _lib.ptr(off), _lib.ptr(items), nu, _lib.ptr(lq),
+                                       lq_rows, flags, _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.ptr(bits), _lib.stream_ptr()))
     shifts = torch.arange(32, device=u.device, dtype=torch.int32)
     return ((bits[:, :, None] >> shifts) & 1).bool().reshape(b, nw * 32)[:, :n]

@@ -699,6 +699,54 @@ def test_negative_masks_random_ids_bit_exact(mf, cfg):
     assert torch.equal(got, want), int((got != want).sum())
 
 
+def _csr_case(seed, b, n, n_users, n_items, lens, dup_user=None):
+    """Ragged per-user lists (CSR over all users), a batch of users drawn with repetition, columns with duplicates."""
+    g = torch.Generator().manual_seed(seed)
+    lists = [torch.randperm(n_items - 1, generator=g)[: int(ln)] + 1 for ln in lens]
+    off = torch.tensor([0] + list(np.cumsum([x.numel() for x in lists])), dtype=torch.int64)
+    items = torch.cat(lists) if int(off[-1]) else torch.zeros(0, dtype=torch.int64)
+    users = torch.randint(0, n_users, (b,), generator=g)
+    if dup_user is not None:
+        users[:3] = dup_user                                     # the heavy user several times in one 32-user group
+        users[b // 2] = dup_user
+    item_idx = torch.randint(1, n_items, (n,), generator=g)
+    item_idx[n // 2: n // 2 + 5] = item_idx[0]                   # duplicate columns
+    return lists, off, items, users, item_idx
+
+
+@pytest.mark.parametrize("cfg", [(70, 300, 40_000, 30_000), (40, 6000, 6_001, 6_000), (33, 64, 500, 0)], ids=lambda c: "x".join(map(str, c)))
+def test_csr_positives_masks_bit_exact(mf, cfg):
+    """Positives as CSR lists read in place (mf_loss_fwd_csr) -- no [B, P] tensor: the mask equals the oracle's on the padded
+    form of the same lists, incl. a 30,000-item user, empty lists, a user id outside the table (no positives),
+    duplicates of the heavy user inside one 32-user group, and a group whose lists hit more first columns than the LDS
+    table holds (6,000 > 4,096: the overflow goes out by global atomics).  The padded form through the same kernel too."""
+    b, n, n_items, heavy = cfg
+    n_users = 50
+    g = torch.Generator().manual_seed(sum(cfg))
+    lens = torch.randint(0, 40, (n_users,), generator=g)
+    lens[3] = 0
+    if heavy:
+        lens[7] = heavy
+        if n == 6000:
+            lens[:] = heavy                                          # every user holds (nearly) every item: every column is a hit
+    lists, off, items, users, item_idx = _csr_case(sum(cfg), b, n, n_users, n_items, lens.tolist(), dup_user=7)
+    users[5] = n_users + 3                                           # outside pos_off: treated as an empty list
+    longest = max(int(lens.max()), 1)
+    pos_idx = torch.zeros(b, longest, dtype=torch.int64)
+    for r, u in enumerate(users.tolist()):
+        if u < n_users:
+            pos_idx[r, : lists[u].numel()] = lists[u]
+    want = ol.negative_masks(item_idx, pos_idx, b)
+    u_, v_ = torch.zeros(b, 32, device=DEV), torch.zeros(n, 32, device=DEV)
+    tgt = torch.ones(b, device=DEV)
+    got = mf.losses.negative_mask(u_, v_, tgt, item_idx=item_idx.to(DEV), pos_csr=(users.to(DEV), off.to(DEV), items.to(DEV))).cpu()
+    assert torch.equal(got, want), int((got != want).sum())
+    got_p = mf.losses.negative_mask(u_, v_, tgt, item_idx=item_idx.to(DEV), pos_idx=pos_idx.to(DEV)).cpu()
+    assert torch.equal(got_p, want), int((got_p != want).sum())
+    if heavy:
+        assert int((~want).sum()) > b                               # the lists do hit columns beyond the diagonal
+
+
 # --------------------------------------------------------- hash / bloom towers (config 5) ---
 @pytest.mark.parametrize("d", [32, 256])
 @pytest.mark.parametrize("num_hashes", [1, 2, 4])
@@ -798,10 +846,22 @@ def test_device_batch_producer_matches_oracle_and_feeds_the_module(mf):
     with pytest.raises(ValueError, match="needs a row in pos_off"):
         mf.data.DeviceInteractionSampler(pu, pi, pt, off[:50], items, num_items=n_items, batch_size=64, device=DEV)
     full = mf.data.DeviceInteractionSampler(pu, pi, pt, off, items, num_items=n_items, batch_size=64, seed=77, device=DEV)
-    assert full.pos_pad == longest                                          # sized from the data: nothing is dropped
+    assert full.pos_pad == 0                                                # default: CSR lists in place, no [B, P] tensor at all
     fb = full.batch(3)
-    for r, u in enumerate(fb["user"]["idx"].cpu().tolist()):
-        assert [x for x in fb["user"]["pos_idx"][r].cpu().tolist() if x] == lists[u]
+    assert "pos_idx" not in fb["user"]
+    uid, poff, pitems = fb["user"]["pos_csr"]
+    assert uid is fb["user"]["idx"] and poff.data_ptr() == full.pos_off.data_ptr() and pitems.data_ptr() == full.pos_items.data_ptr()
+    padded = mf.data.DeviceInteractionSampler(pu, pi, pt, off, items, num_items=n_items, batch_size=64, seed=77, device=DEV,
+                                              pos_pad=longest)                # the reference's layout, sized so that nothing is dropped
+    pb = padded.batch(3)
+    assert torch.equal(pb["user"]["idx"], fb["user"]["idx"]) and torch.equal(pb["item"]["idx"], fb["item"]["idx"])
+    for r, u in enumerate(pb["user"]["idx"].cpu().tolist()):
+        assert [x for x in pb["user"]["pos_idx"][r].cpu().tolist() if x] == lists[u]
+    # the same batch through both forms of the positives: identical losses, bit for bit (the masks are the same bits)
+    mm = mf.lightning.MatrixFactorizationLitModule({"num_users": n_users, "num_items": n_items, "hidden_size": 32, "num_negatives": 0})
+    mm.configure_model(device=DEV)
+    la, lb = mm.compute_losses(fb), mm.compute_losses(pb)
+    assert all(torch.equal(la[k], lb[k]) for k in la), {k: (float(la[k]), float(lb[k])) for k in la}
     # the per-rank stream of a user-sharded job: only pairs of users lo <= u < hi, each exactly once per epoch
     mine = mf.data.DeviceInteractionSampler(pu, pi, pt, off, items, num_items=n_items, batch_size=32, seed=5, device=DEV,
                                             user_range=(50, 120))
