@@ -60,6 +60,9 @@ LDS_DMA_CHIP_GBS = 6400.0          # measured chip-wide LDS-DMA fill rate (MI355
 PEAK_F32_MFMA_TFLOPS = 157.3                            # MI355X_MICROARCH.md, fp32 matrix
 PEAK_HBM_GBS = 8000.0
 TOP_K, POS_PAD = 20, 64
+REPS = int(os.environ.get("MF_BENCH_REPS", "5"))      # repetitions of every timed region (K steps each): median / min / max
+CPU_MAX_THREADS = 64                                  # thread counts the CPU baseline sweeps up to (256-thread hosts oversubscribe)
+CPU_BUDGET_S = 15.0                                   # time box of the CPU training sweep
 
 
 def csrc_sha() -> str:
@@ -141,6 +144,26 @@ def make_csr_interactions(seed: int = 0, num_users: int = NUM_USERS, num_items: 
             "pair_target": torch.randint(1, 6, (total,), generator=g).float()}
 
 
+def hashed_batches(n_batches: int, batch: int, device, *, users: int, items: int, pos_pad: int = POS_PAD, seed: int = 5):
+    """Batches over an id space far larger than any table (config C5: hash / bloom towers): users uniform, items
+    log-uniform (~ Zipf(1) without a 100 M-entry weight vector), positives of the same law."""
+    import math
+
+    g = torch.Generator().manual_seed(seed)
+    zipf = lambda n: (torch.rand(n, generator=g, dtype=torch.float64) * math.log(items)).exp().long().clamp(1, items - 1)  # noqa: E731
+    out = []
+    for _ in range(n_batches):
+        item = zipf(batch)
+        pos = zipf(batch * pos_pad).reshape(batch, pos_pad)
+        pos[:, 0] = item
+        n_pos = torch.randint(min(8, pos_pad), pos_pad + 1, (batch,), generator=g)
+        pos[torch.arange(pos_pad)[None, :] >= n_pos[:, None]] = 0
+        out.append({k: v.to(device) for k, v in dict(user=torch.randint(1, users, (batch,), generator=g),
+                                                     item=torch.cat([item, torch.randint(1, items, (batch,), generator=g)]),
+                                                     target=torch.randint(1, 6, (batch,), generator=g), pos=pos).items()})
+    return out
+
+
 def logq_table(device, num_items: int = NUM_ITEMS) -> torch.Tensor:
     """log of the sampling probability of each item row: positives ~ Zipf, negatives ~ uniform."""
     w = zipf_weights(num_items - 1)
@@ -153,8 +176,8 @@ class Trainer:
 
     def __init__(self, mf, device, optimizer: str, num_negatives: int, *, num_users: int = NUM_USERS,
                  num_items: int = NUM_ITEMS, dim: int = DIM, loss: str = "InfomationNoiseContrastiveEstimationLoss",
-                 use_logq: bool = True):
-        cfg = mf.models.ModelConfig(num_users=num_users, num_items=num_items, hidden_size=dim)
+                 use_logq: bool = True, num_hashes: int = 0):
+        cfg = mf.models.ModelConfig(num_users=num_users, num_items=num_items, hidden_size=dim, num_hashes=num_hashes)
         torch.manual_seed(0)
         self.towers = mf.models.init_towers(cfg, device=device)
         self.loss_fn = getattr(mf.losses, loss)(num_negatives=num_negatives, sigma=1.0)
@@ -177,13 +200,15 @@ class Trainer:
         # equal (1.1718 vs 1.1732 ms / step: the cross-stream join costs what the overlap saves), so off by default.
         # (Building the NEXT batch's masks at the start of a step -- a whole step of slack -- also measured equal,
         # 1.0085 vs 1.0088 ms: kernels of a second stream do not slip in beside the sweeps, they queue.)
-        masks = (self.loss_fn.prepare_masks(b["item"], b["pos"], batch_size=b["user"].numel(), embedding_dim=self.dim)
+        masks = (self.loss_fn.prepare_masks(b["item"], b.get("pos"), batch_size=b["user"].numel(), embedding_dim=self.dim,
+                                            pos_csr=b.get("pos_csr"))
                  if os.environ.get("MF_BENCH_PREPARE", "0") == "1" else None)
         u = self.towers["user"](b["user"])
         v = self.towers["item"](b["item"])
-        # the int64 targets and the logQ table go to the kernel as they are (converted / looked up in its set-up launch)
-        loss = self.loss_fn(u, v, b["target"], item_idx=b["item"], pos_idx=b["pos"], logq_table=self.logq,
-                            prepared=masks)
+        # the int64 targets and the logQ table go to the kernel as they are (converted / looked up in its set-up launch);
+        # positives: the padded [B, P] matrix, or the producer's CSR lists read in place (b["pos_csr"])
+        loss = self.loss_fn(u, v, b["target"], item_idx=b["item"], pos_idx=b.get("pos"), logq_table=self.logq,
+                            prepared=masks, pos_csr=b.get("pos_csr"))
         loss.backward(self.one)
         self.opt.step()
         return loss
@@ -265,17 +290,37 @@ def kernel_span(lib, name: str):
 TRAIN_KERNELS = ("loss_fwd_dense", "loss_bwd_du", "loss_bwd_dv", "mining_select", "gather_rows", "update_rows")
 
 
+def flat_batch(b) -> dict:
+    """A producer's nested batch (InteractionBatchType) as the flat dict the bench trainers take."""
+    out = {"user": b["user"]["idx"], "item": torch.cat([b["item"]["idx"], b["neg_item"]["idx"]]), "target": b["target"]}
+    if b["user"].get("pos_csr") is not None:
+        out["pos_csr"] = (out["user"],) + tuple(b["user"]["pos_csr"][1:])
+    else:
+        out["pos"] = b["user"]["pos_idx"]
+    return out
+
+
+def spread(ms: list) -> dict:
+    srt = sorted(ms)
+    return {"n": len(ms), "median": round(srt[len(srt) // 2], 4), "min": round(srt[0], 4), "max": round(srt[-1], 4)}
+
+
 def run_train_leg(mf, lib, device, *, batch: int, steps: int, warmup: int, optimizer: str = "adam", num_negatives: int = 0,
                   loss: str = "InfomationNoiseContrastiveEstimationLoss", num_users: int = NUM_USERS, num_items: int = NUM_ITEMS,
                   dim: int = DIM, pos_pad: int = POS_PAD, use_logq: bool = True, spin: bool = True, graph: bool = False,
-                  seed: int = 1000) -> dict:
-    """One single-GPU training leg: fresh tables, `warmup` untimed steps, `steps` timed ones; HIP-event spans of the
-    dominant kernels every TIME_EVERY-th launch.  graph=True: the step is captured in a hipGraph and replayed."""
+                  seed: int = 1000, reps: int = 1, batches=None, num_hashes: int = 0, id_space=None) -> dict:
+    """One single-GPU training leg: fresh tables, `warmup` untimed steps, then `reps` timed regions of `steps` steps each
+    (the reported ms / step is the MEDIAN region); HIP-event spans of the dominant kernels every TIME_EVERY-th launch.
+    graph=True: the step is captured in a hipGraph and replayed.  `batches`: pre-built flat batches (else synthetic padded
+    ones); `id_space` = (users, items): ranges the synthetic ids are drawn from when they differ from the table heights
+    (hash towers: ids far beyond the bucket counts)."""
     n_batches = min(steps + warmup, 8)
-    batches, _ = make_batches(n_batches, batch, seed=seed, device=device, num_users=num_users, num_items=num_items,
-                              pos_pad=pos_pad)
+    if batches is None:
+        nu, ni = id_space if id_space is not None else (num_users, num_items)
+        batches, _ = make_batches(n_batches, batch, seed=seed, device=device, num_users=nu, num_items=ni, pos_pad=pos_pad)
+    n_batches = len(batches)
     trainer = Trainer(mf, device, optimizer, num_negatives, num_users=num_users, num_items=num_items, dim=dim, loss=loss,
-                      use_logq=use_logq)
+                      use_logq=use_logq, num_hashes=num_hashes)
     step = trainer.step
     if graph:
         step = mf.graph.CapturedStep(trainer.step, batches[0], optimizers=[trainer.opt], warmup=3)
@@ -286,10 +331,14 @@ def run_train_leg(mf, lib, device, *, batch: int, steps: int, warmup: int, optim
     lib.mf_timing_reset()
     if not graph:                                   # (event records inside a replayed graph would time nothing)
         lib.mf_timing_enable(TIME_EVERY)
-    dt = timed(lambda i: step(batches[(warmup + i) % n_batches]), steps, False)
+    ms = []
+    for r in range(reps):
+        dt = timed(lambda i, r=r: step(batches[(warmup + r * steps + i) % n_batches]), steps, False)
+        ms.append(dt / steps * 1e3)
     lib.mf_timing_enable(0)
     spans = {n: kernel_span(lib, n)[0] for n in TRAIN_KERNELS}
-    return {"ms_per_step": dt / steps * 1e3, "pairs_per_s": batch * steps / dt, "spans": {k: v for k, v in spans.items() if v},
+    med = sorted(ms)[len(ms) // 2]
+    return {"ms_per_step": med, "pairs_per_s": batch / (med * 1e-3), "reps_ms": ms, "spans": {k: v for k, v in spans.items() if v},
             "trainer": trainer, "batches": batches}
 
 
@@ -357,22 +406,20 @@ def cpu_topk_once(q: torch.Tensor, items: torch.Tensor, k: int, excl_rows: torch
 
 
 def cpu_baselines(args, batches, queries, items, pieces) -> dict:
-    """CPU baseline on the host cores of this box (rank 0, N = 1): the oracle's restatement of the SAME workload, on a
-    bounded sample.  The thread count is swept on a reduced sample first (oversubscribing a 256-thread host is slower
-    than 32 .. 64 threads) and the best setting runs the full-size sample."""
+    """CPU baseline on the host cores of this box (rank 0, N = 1): the oracle's restatement of the SAME workload.  Thread
+    counts up to CPU_MAX_THREADS are tried on the FULL batch, one step each, inside a CPU_BUDGET_S time box (a 256-thread
+    host is slower oversubscribed than at 32 .. 64 threads, and one step is 2 .. 4 s); the best step is the figure."""
     b = batches[0]["user"].numel()
     cores = os.cpu_count() or 1
-    cands = sorted({t for t in (8, 16, 32, 64, 128, cores) if t <= cores})
-    small = [{k: (v[:2048] if k != "item" else torch.cat([v[:2048], v[b: b + 2048]])) for k, v in bt.items()} for bt in batches[:1]]
+    cands = [t for t in (32, 64, 16, 8) if t <= min(cores, CPU_MAX_THREADS)] or [cores]
     lq = logq_table("cpu")
-    sweep = {}
+    sweep, t_start = {}, time.perf_counter()
     for t in cands:
+        if sweep and time.perf_counter() - t_start > CPU_BUDGET_S:
+            break
         torch.set_num_threads(t)
-        cpu_train_baseline(small, lq, args.optimizer, 1, args.num_negatives)          # warm
-        sweep[t] = cpu_train_baseline(small, lq, args.optimizer, 1, args.num_negatives)
+        sweep[t] = cpu_train_baseline(batches[:1], lq, args.optimizer, 1, args.num_negatives)
     best_t = min(sweep, key=sweep.get)
-    torch.set_num_threads(best_t)
-    dt_cpu = cpu_train_baseline(batches[: args.cpu_steps], lq, args.optimizer, args.cpu_steps, args.num_negatives)
     # top-k
     qn = queries.shape[0]
     rows = torch.cat([torch.full((p.numel(),), r, dtype=torch.int64) for r, p in enumerate(pieces)])
@@ -386,12 +433,12 @@ def cpu_baselines(args, batches, queries, items, pieces) -> dict:
             cpu_topk_once(queries, items, TOP_K, rows, cols)
         tk[t] = (time.perf_counter() - t0) / 3
     best_k = min(tk, key=tk.get)
-    return {"value": round(b * args.cpu_steps / dt_cpu, 1), "unit": "pairs/s", "cores": best_t, "kind": "port",
+    return {"value": round(b / sweep[best_t], 1), "unit": "pairs/s", "cores": best_t, "kind": "port",
             "cpu_model": cpu_model(), "host_threads_available": cores,
-            "thread_sweep_s_per_reduced_step": {str(t): round(v, 3) for t, v in sweep.items()},
-            "sample": f"{args.cpu_steps} steps of the same workload (B={b}, N={2 * b}, d={DIM}, InfoNCE+logQ, "
-                      f"{args.optimizer}) by oracle/ on torch CPU at the best thread count of a sweep over {cands} "
-                      f"(swept on B=2048); top-k: 3 batches of Q={qn} per thread count, best kept",
+            "thread_sweep_s_per_step": {str(t): round(v, 3) for t, v in sweep.items()},
+            "sample": f"one step of the same workload (B={b}, N={2 * b}, d={DIM}, InfoNCE+logQ, {args.optimizer}) by oracle/ on "
+                      f"torch CPU per thread count in {list(sweep)} (<= {CPU_MAX_THREADS} threads, {CPU_BUDGET_S:.0f} s time box), best "
+                      f"kept; top-k: 3 batches of Q={qn} per thread count, best kept",
             "topk_value": round(qn / tk[best_k], 1), "topk_unit": "queries/s", "topk_cores": best_k,
             "topk_thread_sweep_ms": {str(t): round(v * 1e3, 1) for t, v in tk.items()}}
 
@@ -529,6 +576,7 @@ def main() -> None:
 
     # ------------------------------------------------------------------ training leg --
     cold_ms = None
+    data_tag, ml_meta = "synthetic", None
     if dist_on:
         n_batches = min(K + W, 8)
         batches, _ = make_batches(n_batches, B, seed=1000 + rank, device=device)
@@ -555,7 +603,8 @@ def main() -> None:
             run_step(i)
         lib.mf_timing_reset()
         lib.mf_timing_enable(TIME_EVERY)
-        dt_train = timed(lambda i: run_step(W + i), K, dist_on)
+        train_reps = [timed(lambda i, r=r: run_step(W + r * K + i), K, dist_on) / K * 1e3 for r in range(REPS)]
+        dt_train = sorted(train_reps)[len(train_reps) // 2] * K / 1e3
         lib.mf_timing_enable(0)
         trainer.finish()                        # deferred error flags (id range / exchange capacity) of the timed steps
         spans = {n: kernel_span(lib, n)[0] for n in TRAIN_KERNELS}
@@ -567,20 +616,34 @@ def main() -> None:
                              num_negatives=args.num_negatives, spin=False)
         cold_ms = cold["ms_per_step"]
         del cold
+        # the reference's own inputs when the box has them (there is no network here, so normally it has not): the ids of a
+        # MovieLens ratings file through the device batch producer, CSR positives, table heights from the data
+        ml_batches, data_tag, ml_meta = None, "synthetic", None
+        ml_file = mf.data.find_movielens()
+        if ml_file is not None and os.environ.get("MF_BENCH_SYNTHETIC") != "1":
+            table, ml_meta = mf.data.movielens_interactions(ml_file)
+            sampler = table.sampler(num_items=ml_meta["num_items"], batch_size=B, seed=0, device=device)
+            ml_batches = [flat_batch(sampler.batch(j)) for j in range(8)]
+            data_tag = "movielens"
         leg = run_train_leg(mf, lib, device, batch=B, steps=K, warmup=W, optimizer=args.optimizer,
-                            num_negatives=args.num_negatives, spin=True)
+                            num_negatives=args.num_negatives, spin=True, reps=REPS, batches=ml_batches,
+                            **({} if ml_meta is None else {"num_users": ml_meta["num_users"], "num_items": ml_meta["num_items"],
+                                                           "use_logq": False}))
         dt_train, spans, trainer, batches = leg["ms_per_step"] * K / 1e3, leg["spans"], leg["trainer"], leg["batches"]
+        train_reps = leg["reps_ms"]
     pairs_per_s = world * B * K / dt_train
     N = 2 * B
     train_roof = train_roofline(spans, B, DIM, world, args.optimizer)
 
     # ----------------------------------------------------------------- retrieval leg --
+    n_users_leg = ml_meta["num_users"] if ml_meta else NUM_USERS
+    n_items_leg = ml_meta["num_items"] if ml_meta else NUM_ITEMS
     with torch.no_grad():
         items = trainer.item_matrix()
-        qrows = torch.arange(1 + rank * Q, 1 + (rank + 1) * Q, device=device) % NUM_USERS
+        qrows = torch.arange(1 + rank * Q, 1 + (rank + 1) * Q, device=device) % n_users_leg
         queries = trainer.user_vectors(qrows)
     g = torch.Generator().manual_seed(7 + rank)
-    item_w = zipf_weights(NUM_ITEMS - 1)
+    item_w = zipf_weights(n_items_leg - 1)
     pieces, offs = [], [0]                         # per-query history (sorted unique item rows)
     for n in torch.randint(20, 300, (Q,), generator=g).tolist():
         pieces.append(torch.unique(torch.multinomial(item_w, n, replacement=True, generator=g) + 1))
@@ -588,7 +651,7 @@ def main() -> None:
     csr = (torch.tensor(offs, dtype=torch.int64, device=device), torch.cat(pieces).to(device))
     index = None
     if dist_on:
-        searcher = mf.distributed.ShardedIndex(trainer.item_shard(), trainer.item_offset(), NUM_ITEMS, stride=trainer.item_stride())
+        searcher = mf.distributed.ShardedIndex(trainer.item_shard(), trainer.item_offset(), n_items_leg, stride=trainer.item_stride())
         run_topk = lambda i: searcher.search(queries, TOP_K, exclude_csr=csr)   # noqa: E731
     else:
         index = mf.retrieval.ItemIndex(items)
@@ -598,7 +661,8 @@ def main() -> None:
         run_topk(i)
     lib.mf_timing_reset()
     lib.mf_timing_enable(TIME_EVERY)
-    dt_topk = timed(run_topk, K, dist_on)
+    topk_reps = [timed(run_topk, K, dist_on) / K * 1e3 for _ in range(REPS)]
+    dt_topk = sorted(topk_reps)[len(topk_reps) // 2] * K / 1e3
     lib.mf_timing_enable(0)
     qps = world * Q * K / dt_topk
     span, _n = kernel_span(lib, "topk_select")
@@ -650,10 +714,63 @@ def main() -> None:
         leg = run_train_leg(mf, lib, device, batch=B, steps=40, warmup=5, num_users=6041, num_items=3884, dim=64, use_logq=False)
         extras["c2_ml1m_d64"] = {"workload": "C2: MovieLens-1M shape (6,040 x 3,883), d=64, InfoNCE, row-adam", **brief(leg, B, 64)}
         del leg
-        # positive lists of 1024 ids per user (SURVEY 8d stress: hits_kernel leaves its LDS table for global atomics)
+        # positive lists of 1024 ids per user (SURVEY 8d stress)
         leg = run_train_leg(mf, lib, device, batch=B, steps=20, warmup=3, pos_pad=1024)
         extras["pos_pad_1024"] = {"workload": "C3 shape, InfoNCE + logQ, P = 1024 padded positives per user", **brief(leg, B, DIM)}
         del leg
+        # ALL of a user's positives, as the reference passes them (data/lightning.py:274-280), at MovieLens-25M's list-length
+        # profile (log-normal, heaviest users >= 10^4 items, users drawn in proportion to their list length): the producer's
+        # CSR lists read in place by the mask kernels -- no [B, P] tensor.  To hold against the P = 64 headline step.
+        inter = make_csr_interactions(seed=0)
+        sampler = mf.data.DeviceInteractionSampler(inter["pair_user"], inter["pair_item"], inter["pair_target"], inter["pos_off"],
+                                                   inter["pos_items"], num_items=NUM_ITEMS, batch_size=B, seed=1, device=device)
+        csr_batches = [flat_batch(sampler.batch(j)) for j in range(8)]
+        per_batch = float(sum(int(inter["lens"].to(device)[b_["user"]].sum()) for b_ in csr_batches)) / len(csr_batches)
+        leg = run_train_leg(mf, lib, device, batch=B, steps=40, warmup=5, batches=csr_batches, reps=3)
+        extras["csr_positives_ml25m_lists"] = {
+            "workload": "C3 shape, InfoNCE + logQ, ALL positives of every user as CSR lists (log-normal lengths, mean "
+                        f"{float(inter['lens'].double().mean()):.0f}, longest {int(inter['lens'].max())}; {per_batch / 1e6:.2f} M list "
+                        "entries looked up per batch), device batch producer", "reps_ms_per_step": spread(leg["reps_ms"]),
+            "vs_headline_P64": round(leg["ms_per_step"] / (dt_train / K * 1e3), 4), **brief(leg, B, DIM)}
+        del leg, sampler, csr_batches, inter
+        # the same headline workload with the SGD update (36 d bytes / pair against HBM)
+        leg = run_train_leg(mf, lib, device, batch=B, steps=40, warmup=5, optimizer="sgd", reps=3)
+        extras["c3_sgd"] = {"workload": "C3 shape, InfoNCE + logQ, sparse SGD update", "reps_ms_per_step": spread(leg["reps_ms"]),
+                            **brief(leg, B, DIM, "sgd")}
+        del leg
+        # config C5's width: d = 256, dense tables of the C3 shape, then hash / bloom towers over ONE GPU's share of C5
+        # (100 M items x 10 M users / 8 ranks: 12.5 M + 1.25 M bucket rows x 256 = 12.8 + 1.3 GB of tables, x 3 with Adam's
+        # moments; ids drawn from the full 10 M x 100 M id space, items log-uniform ~ Zipf(1))
+        leg = run_train_leg(mf, lib, device, batch=B, steps=20, warmup=3, dim=256, reps=3)
+        extras["c5_d256_dense"] = {"workload": "C3 table shape at C5's width d=256, InfoNCE + logQ, row-adam",
+                                   "reps_ms_per_step": spread(leg["reps_ms"]), **brief(leg, B, 256)}
+        del leg
+        torch.cuda.empty_cache()
+        hb = hashed_batches(8, B, device, users=10_000_000, items=100_000_000)
+        leg = run_train_leg(mf, lib, device, batch=B, steps=20, warmup=3, dim=256, reps=3, batches=hb, num_users=1_250_000,
+                            num_items=12_500_000, num_hashes=2, use_logq=False)
+        extras["c5_d256_hashed"] = {"workload": "C5 per-GPU share: hash / bloom towers (2 hashes), 12.5 M item + 1.25 M user bucket "
+                                                "rows x d=256 (12.8 + 1.3 GB tables + Adam moments), ids from 10 M users x 100 M "
+                                                "items, InfoNCE, row-adam", "reps_ms_per_step": spread(leg["reps_ms"]),
+                                    **brief(leg, B, 256)}
+        # ... and the full-shard top-k of that catalog share: 1024 queries against 12.5 M rows x 256
+        with torch.no_grad():
+            shard = leg["trainer"].towers["item"].weight.detach()
+            qv = torch.nn.functional.normalize(torch.randn(Q, 256, device=device), dim=-1)
+            big = mf.retrieval.ItemIndex(shard)
+            for _ in range(2):
+                big.search(qv, TOP_K)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                big.search(qv, TOP_K)
+            torch.cuda.synchronize()
+            dt_big = (time.perf_counter() - t0) / 3
+        extras["c5_shard_topk"] = {"workload": f"top-{TOP_K} of {Q} queries over 12.5 M rows x d=256 (one GPU's share of the 100 M-item catalog)",
+                                   "ms_per_call": round(dt_big * 1e3, 3), "queries_per_s": round(Q / dt_big, 1),
+                                   "algorithmic_TFLOPs": round(2.0 * Q * shard.shape[0] * 256 / dt_big / 1e12, 1)}
+        del leg, big, shard, hb
+        torch.cuda.empty_cache()
         # small batches: eager against one hipGraph replay per step
         for name, bsz, kw in (("b1024", 1024, {}), ("b32", 32, {}),
                               ("b32_reference_default", 32, {"loss": "PairwiseHingeLoss", "num_negatives": 4, "use_logq": False})):
@@ -668,7 +785,9 @@ def main() -> None:
     # --------------------------------------------------------------------- CPU leg ----
     cpu = None
     if rank == 0 and world == 1 and not dist_on and not args.no_cpu_baseline:
-        cb = [{k: v.cpu() for k, v in b.items()} for b in batches[: max(args.cpu_steps, 1)]]
+        if ml_meta is not None:      # (the CPU restatement takes padded positives: it runs the synthetic C3 batch in that case)
+            batches, _ = make_batches(1, B, seed=1000, device=device)
+        cb = [{k: v.cpu() for k, v in b.items()} for b in batches[:1]]
         cpu = cpu_baselines(args, cb, queries.cpu(), items.cpu(), pieces)
 
     if rank == 0:
@@ -676,8 +795,12 @@ def main() -> None:
             "metric": "train pairs/sec + full-catalog top-k queries/sec, ML-25M d=128",
             "value": round(pairs_per_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt_train / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: MovieLens-25M shape (162,541 users x 62,423 items), d=128, InfoNCE + logQ, "
+            "vs_baseline": None, "dtype": "f32", "data": data_tag,
+            "reps_ms_per_step": spread(train_reps),      # REPS timed regions of K steps each; value / ms_per_step = the median one
+            "config": {"workload": (f"MovieLens ratings file {ml_meta['path']} ({ml_meta['num_users'] - 1:,} users x "
+                                    f"{ml_meta['num_items'] - 1:,} items, {ml_meta['train_pairs']:,} train pairs), d=128, InfoNCE, CSR positives, "
+                                    if ml_meta else
+                                    "C3: MovieLens-25M shape (162,541 users x 62,423 items), d=128, InfoNCE + logQ, ") +
                                    f"num_negatives={args.num_negatives}, row-{args.optimizer} update",
                        "batch_per_gpu": B, "items_per_step": N, "pos_pad": POS_PAD,
                        "parallelism": f"dp{world}" + (f" + both tables row-sharded, {trainer.user_mode} users" if dist_on else "")},
@@ -686,7 +809,8 @@ def main() -> None:
             "cold_ms_per_step": None if cold_ms is None else round(cold_ms, 4),
             "roofline": train_roof,
             "topk": {"value": round(qps, 1), "unit": "queries/s", "ms_per_step": round(dt_topk / K * 1e3, 4),
-                     "queries_per_gpu": Q, "k": TOP_K, "catalog_rows": NUM_ITEMS, "roofline": topk_roof},
+                     "reps_ms_per_step": spread(topk_reps), "queries_per_gpu": Q, "k": TOP_K, "catalog_rows": n_items_leg,
+                     "roofline": topk_roof},
             "extras": extras,
             "cpu_baseline": cpu,
         }

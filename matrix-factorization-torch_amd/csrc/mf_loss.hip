@@ -26,7 +26,7 @@ enum { ST_CNT = 0, ST_A = 1, ST_MX = 2, ST_SE = 3, ST_H = 4, ST_HC = 5, ST_LG = 
 enum { NEED_CONTR = 1, NEED_LSE = 2, NEED_HINGE = 4, NEED_LOGI = 8 };
 enum { G_EXP = 0, G_STEP = 1, G_SIGM = 2 };
 static constexpr int KSEL_MAX = 64;
-static constexpr int HITS_PLANES = 4;      // planes of the users' hit bit-vectors (= HITS_MAX_SPLIT, mask build)
+static constexpr int HITS_PLANES = 2;      // planes of the users' hit bit-vectors (= HITS_MAX_SPLIT, mask build)
 
 static int need_flags(int kind_mask) {
     int f = 0;
@@ -113,7 +113,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.bmbits = 13;                                                // >= 8 bits per column, 1 KiB .. 16 KiB (every block copies it into LDS)
     while (w.bmbits < 17 && (1ll << w.bmbits) < 8 * w.Np) ++w.bmbits;
     w.bmap = a.take<uint32_t>((size_t)1 << (w.bmbits - 5));
-    w.ubits = a.take<uint32_t>((size_t)HITS_PLANES * w.Np * (w.Bp / 32));        // ubitsT [plane][column][user / 32]
+    w.ubits = a.take<uint32_t>((size_t)HITS_PLANES * w.Np * (w.Bp / 32));        // ubits [plane][user / 32][column]
     w.maskW = a.take<uint32_t>((size_t)w.NT * w.Bp);
     w.part = a.take<float>((size_t)w.nsplit_f * NSTAT * w.Bp);
     w.stats = a.take<float>((size_t)NSTAT * w.Bp);
@@ -268,30 +268,36 @@ __device__ __forceinline__ unsigned bm_hash(long long id, int bits) {
 }
 
 // (64-thread workgroups: every thread is one chain of dependent memory operations; spread over all CUs)
+// Round trips per column: the id; then the slot, its first-column word and the bitmap word TOGETHER (a Zipf batch repeats its
+// popular items hundreds of times: looking before every atomic saves most of them -- a stale read only costs the atomic it
+// would have saved; slots never change once taken, gfirst only decreases, bitmap bits are only set); then the claiming CAS
+// when the slot was empty.  The two updates behind it return nothing and are not waited for.
 __global__ __launch_bounds__(64) void gt_insert_kernel(const int64_t* __restrict__ item_idx, int64_t N, int M,
                                                         long long* __restrict__ gtab, int32_t* __restrict__ gfirst,
                                                         int32_t* __restrict__ colslot, uint32_t* __restrict__ bmap, int bmbits) {
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j >= N) return;
     const long long key = item_idx[j];
-    {
-        const unsigned b = bm_hash(key, bmbits);
-        const uint32_t bit = 1u << (b & 31);
-        if (!(*(const volatile uint32_t*)&bmap[b >> 5] & bit)) atomicOr(&bmap[b >> 5], bit);   // (fire and forget)
-    }
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(gtab);
-    unsigned hpos = ht_hash(key, M - 1);
-    // a Zipf batch repeats its popular items hundreds of times: look before the atomic (a stale read
-    // only costs the atomic it would have saved; slots never change once taken, gfirst only decreases)
     const volatile unsigned long long* vtab = tab;
+    unsigned hpos = ht_hash(key, M - 1);
+    const unsigned b = bm_hash(key, bmbits);
+    const uint32_t bit = 1u << (b & 31);
+    unsigned long long old = vtab[hpos];                                   // three independent loads in flight
+    int32_t first_seen = *(const volatile int32_t*)&gfirst[hpos];
+    const uint32_t bm_seen = *(const volatile uint32_t*)&bmap[b >> 5];
     for (int probe = 0; probe < M; ++probe) {
-        unsigned long long old = vtab[hpos];
+        if (probe) {
+            old = vtab[hpos];
+            first_seen = *(const volatile int32_t*)&gfirst[hpos];
+        }
         if (old == (unsigned long long)HT_EMPTY)
             old = atomicCAS(&tab[hpos], (unsigned long long)HT_EMPTY, (unsigned long long)key);
         if (old == (unsigned long long)HT_EMPTY || old == (unsigned long long)key) break;
         hpos = (hpos + 1) & (M - 1);
     }
-    if (*(const volatile int32_t*)&gfirst[hpos] > (int32_t)j) atomicMin(&gfirst[hpos], (int32_t)j);   // cleared to 0x7f7f7f7f
+    if (first_seen > (int32_t)j) atomicMin(&gfirst[hpos], (int32_t)j);     // cleared to 0x7f7f7f7f
+    if (!(bm_seen & bit)) atomicOr(&bmap[b >> 5], bit);
     colslot[j] = (int32_t)hpos;
 }
 
@@ -339,28 +345,27 @@ __device__ __forceinline__ int pos_list(const PosSrc& s, int64_t i, const int64_
 }
 
 // One launch for both consumers of the finished hash table.  Blocks [0, nb_col): colfirst.  The rest: `split` blocks per
-// group of 32 users.  The lists of the 32 users are walked as ONE flat range, cut in `split` equal pieces (a user with
-// 30,000 positives -- and the group it sits in -- is spread over `split` x 512 threads; list lengths are heavy-tailed, and
-// with one block per group the heaviest group set the kernel's time: 198 us at the MovieLens-25M profile, 5.3 M list
-// entries per batch).  Most positives are not in the batch at all: every id is first tested against the batch-membership
-// bitmap (a copy in LDS; ~7 % false positives at 8 bits per column), and only the survivors probe the hash table in L2 --
-// HITS_MLP ids in flight per thread, first probes and first-column reads batched.  A block combines its hits in an LDS table
-// keyed by the first column (LDS atomics; a popular item is the positive of thousands of users) and writes word `group` of
-// every hit column's user bit-vector with plain stores into ITS OWN plane of ubitsT (piece s of every group owns plane s;
-// the sweep ORs the planes): no global atomics on the common path -- per-hit global atomicOr was measured 5 x slower
-// (967 vs 198 us: the first column of a popular item takes a hit from every other user).  The table holds HITS_CAP first
-// columns; what does not find room within HITS_PROBES probes goes out by global atomicOr into the same plane --
-// consistently: slots never free up, so an id that once failed to find room never succeeds later, and the plain stores at
-// the end only touch words of ids in the table.
-static constexpr int HITS_THREADS = 512, HITS_CAP = 2048, HITS_PROBES = 24, HITS_MLP = 8, HITS_MAX_SPLIT = HITS_PLANES;
+// group of 32 users.  ubits is laid out [plane][group][column]: a block owns ONE ROW -- word `column` of its group, in its
+// plane -- keeps that row in LDS (64 KiB at N = 16,384), sets a bit per hit with a fire-and-forget LDS atomic indexed by the
+// hit's first column, and writes the whole row out with coalesced 16-byte stores: nothing needs clearing, no hash table of
+// hits, no scattered 4-byte global stores (the [column][group] layout of round 2 scattered ~4 M of them per batch at the
+// MovieLens-25M list profile, and per-hit global atomics were 5 x slower still: 967 us).
+// The lists of the 32 users are walked as ONE flat range, cut in `split` equal pieces, one block and one plane each (a user
+// with 30,000 positives -- and the group it sits in -- is spread over `split` x 1024 threads; list lengths are heavy-tailed:
+// with one block per group the heaviest group set the kernel's time); the sweep ORs the planes.  Most positives are not in
+// the batch at all: every id is first tested against the batch-membership bitmap (a copy in LDS; ~7 % false positives at
+// 8 bits per column), and only the survivors probe the hash table in L2 -- HITS_MLP ids in flight per thread, first probes
+// and first-column reads batched.  Batches wider than HITS_WIN columns are handled in windows (the lists are walked once
+// per window).
+static constexpr int HITS_THREADS = 1024, HITS_MLP = 8, HITS_MAX_SPLIT = HITS_PLANES, HITS_WIN = 32768;
 
 __global__ __launch_bounds__(HITS_THREADS) void hits_kernel(const int64_t* __restrict__ item_idx, PosSrc src,
                                                             int64_t B, int64_t N, int64_t Bp, int64_t Np, int M, int nb_col, int split,
-                                                            const long long* __restrict__ gtab,
+                                                            int win, const long long* __restrict__ gtab,
                                                             const int32_t* __restrict__ gfirst, const int32_t* __restrict__ colslot,
-                                                            int32_t* __restrict__ colfirst, uint32_t* __restrict__ ubitsT,
+                                                            int32_t* __restrict__ colfirst, uint32_t* __restrict__ ubits,
                                                             const uint32_t* __restrict__ bmap, int bmbits) {
-    extern __shared__ __attribute__((aligned(16))) int32_t hl[];           // [HITS_CAP] keys, [HITS_CAP] bit words, the bitmap
+    extern __shared__ __attribute__((aligned(16))) uint32_t hl[];          // [win] the row, then the bitmap
     __shared__ int lstart[33];
     __shared__ const int64_t* lbase[32];
     if ((int)blockIdx.x < nb_col) {
@@ -368,13 +373,11 @@ __global__ __launch_bounds__(HITS_THREADS) void hits_kernel(const int64_t* __res
         return;
     }
     const int grp = (blockIdx.x - nb_col) / split, sub = (blockIdx.x - nb_col) % split;
-    const int64_t wpr = Bp >> 5;                                           // words per column row
-    uint32_t* plane = ubitsT + (int64_t)sub * Np * wpr;
-    int32_t* keys = hl;
-    uint32_t* bits = reinterpret_cast<uint32_t*>(hl + HITS_CAP);
-    uint32_t* lbm = reinterpret_cast<uint32_t*>(hl + 2 * HITS_CAP);
+    const int64_t ngrp = Bp >> 5;
+    uint32_t* out_row = ubits + ((int64_t)sub * ngrp + grp) * Np;
+    uint32_t* row = hl;
+    uint32_t* lbm = hl + win;
     const int bmw = 1 << (bmbits - 5);
-    for (int e = threadIdx.x; e < HITS_CAP; e += HITS_THREADS) { keys[e] = -1; bits[e] = 0u; }
     for (int e = threadIdx.x; e < bmw / 4; e += HITS_THREADS) reinterpret_cast<uint4*>(lbm)[e] = reinterpret_cast<const uint4*>(bmap)[e];
     if (threadIdx.x < 64) {                                                // wave 0: the 32 lists and their flat offsets
         const int ul = threadIdx.x & 31;
@@ -394,79 +397,76 @@ __global__ __launch_bounds__(HITS_THREADS) void hits_kernel(const int64_t* __res
             if (ul == 0) lstart[0] = 0;
         }
     }
-    __syncthreads();
-    const int total = lstart[32];
-    // flat positions [0, total): the lists; [total, total + 32): every user's own item (the accidental-hit term, losses.py:103)
-    const int piece = (total + 32 + split - 1) / split;
-    const int p0 = sub * piece, p1 = min(total + 32, p0 + piece);
-    for (int t0 = p0 + threadIdx.x; t0 < p1; t0 += HITS_THREADS * HITS_MLP) {
-        long long key[HITS_MLP];
-        int ulv[HITS_MLP];
-        bool live[HITS_MLP];
+    for (int64_t w0 = 0; w0 < Np; w0 += win) {
+        const int nw = (int)min((int64_t)win, Np - w0);                    // (Np is a multiple of 128)
+        for (int e = threadIdx.x; e < nw / 4; e += HITS_THREADS) reinterpret_cast<uint4*>(row)[e] = uint4{0u, 0u, 0u, 0u};
+        __syncthreads();
+        const int total = lstart[32];
+        // flat positions [0, total): the lists; [total, total + 32): every user's own item (the accidental-hit term, losses.py:103)
+        const int piece = (total + 32 + split - 1) / split;
+        const int p0 = sub * piece, p1 = min(total + 32, p0 + piece);
+        for (int t0 = p0 + threadIdx.x; t0 < p1; t0 += HITS_THREADS * HITS_MLP) {
+            long long key[HITS_MLP];
+            int ulv[HITS_MLP];
+            bool live[HITS_MLP];
 #pragma unroll
-        for (int j = 0; j < HITS_MLP; ++j) {
-            const int t = t0 + j * HITS_THREADS;
-            live[j] = false; key[j] = 0; ulv[j] = 0;
-            if (t < p1 && t < total) {
-                int lo = 0, hi = 32;                                       // the list holding flat position t: last start <= t
+            for (int j = 0; j < HITS_MLP; ++j) {
+                const int t = t0 + j * HITS_THREADS;
+                live[j] = false; key[j] = 0; ulv[j] = 0;
+                if (t < p1 && t < total) {
+                    int lo = 0, hi = 32;                                   // the list holding flat position t: last start <= t
 #pragma unroll
-                for (int sft = 0; sft < 5; ++sft) {
-                    const int mid = (lo + hi) >> 1;
-                    if (lstart[mid] <= t) lo = mid; else hi = mid;
-                }
-                ulv[j] = lo;
-                key[j] = lbase[lo][t - lstart[lo]];
-                live[j] = true;
-            } else if (t < p1) {
-                ulv[j] = t - total;
-                const int64_t i = (int64_t)grp * 32 + ulv[j];
-                if (i < B) { key[j] = item_idx[i]; live[j] = true; }
-            }
-        }
-        unsigned hpos[HITS_MLP];
-        long long sv[HITS_MLP];
-#pragma unroll
-        for (int j = 0; j < HITS_MLP; ++j) {                               // prefilter, then the first probes, all in flight
-            if (live[j]) {
-                const unsigned b = bm_hash(key[j], bmbits);
-                live[j] = (lbm[b >> 5] >> (b & 31)) & 1u;
-            }
-            hpos[j] = ht_hash(key[j], M - 1);
-            sv[j] = live[j] ? gtab[hpos[j]] : HT_EMPTY;
-        }
-        int32_t f[HITS_MLP];
-#pragma unroll
-        for (int j = 0; j < HITS_MLP; ++j) {                               // the first columns of the direct hits, all in flight
-            f[j] = -1;
-            if (live[j] && sv[j] == key[j]) f[j] = gfirst[hpos[j]];
-        }
-#pragma unroll
-        for (int j = 0; j < HITS_MLP; ++j) {
-            if (!live[j] || sv[j] == HT_EMPTY) continue;
-            if (sv[j] != key[j]) {                                         // collision: walk on (rare at load <= 1/2)
-                unsigned hp = (hpos[j] + 1) & (M - 1);
-                for (int probe = 1; probe < M; ++probe) {
-                    const long long v = gtab[hp];
-                    if (v == key[j]) { f[j] = gfirst[hp]; break; }
-                    if (v == HT_EMPTY) break;
-                    hp = (hp + 1) & (M - 1);
+                    for (int sft = 0; sft < 5; ++sft) {
+                        const int mid = (lo + hi) >> 1;
+                        if (lstart[mid] <= t) lo = mid; else hi = mid;
+                    }
+                    ulv[j] = lo;
+                    key[j] = lbase[lo][t - lstart[lo]];
+                    live[j] = true;
+                } else if (t < p1) {
+                    ulv[j] = t - total;
+                    const int64_t i = (int64_t)grp * 32 + ulv[j];
+                    if (i < B) { key[j] = item_idx[i]; live[j] = true; }
                 }
             }
-            if (f[j] < 0) continue;
-            const uint32_t bit = 1u << ulv[j];
-            unsigned h = ((unsigned)f[j] * 2654435761u >> 7) & (HITS_CAP - 1);
-            bool placed = false;
-            for (int probe = 0; probe < HITS_PROBES; ++probe) {
-                const int32_t old = atomicCAS(&keys[h], -1, f[j]);
-                if (old == -1 || old == f[j]) { atomicOr(&bits[h], bit); placed = true; break; }
-                h = (h + 1) & (HITS_CAP - 1);
+            unsigned hpos[HITS_MLP];
+            long long sv[HITS_MLP];
+#pragma unroll
+            for (int j = 0; j < HITS_MLP; ++j) {                           // prefilter, then the first probes, all in flight
+                if (live[j]) {
+                    const unsigned b = bm_hash(key[j], bmbits);
+                    live[j] = (lbm[b >> 5] >> (b & 31)) & 1u;
+                }
+                hpos[j] = ht_hash(key[j], M - 1);
+                sv[j] = live[j] ? gtab[hpos[j]] : HT_EMPTY;
             }
-            if (!placed) atomicOr(&plane[(int64_t)f[j] * wpr + grp], bit);     // (the planes are cleared by the set-up launch)
+            int32_t f[HITS_MLP];
+#pragma unroll
+            for (int j = 0; j < HITS_MLP; ++j) {                           // the first columns of the direct hits, all in flight
+                f[j] = -1;
+                if (live[j] && sv[j] == key[j]) f[j] = gfirst[hpos[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < HITS_MLP; ++j) {
+                if (!live[j] || sv[j] == HT_EMPTY) continue;
+                if (sv[j] != key[j]) {                                     // collision: walk on (rare at load <= 1/2)
+                    unsigned hp = (hpos[j] + 1) & (M - 1);
+                    for (int probe = 1; probe < M; ++probe) {
+                        const long long v = gtab[hp];
+                        if (v == key[j]) { f[j] = gfirst[hp]; break; }
+                        if (v == HT_EMPTY) break;
+                        hp = (hp + 1) & (M - 1);
+                    }
+                }
+                const int64_t fw = (int64_t)f[j] - w0;
+                if (f[j] >= 0 && fw >= 0 && fw < nw) atomicOr(&row[fw], 1u << ulv[j]);   // (LDS, no return value)
+            }
         }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nw / 4; e += HITS_THREADS)
+            reinterpret_cast<uint4*>(out_row + w0)[e] = reinterpret_cast<const uint4*>(row)[e];
+        __syncthreads();
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < HITS_CAP; e += HITS_THREADS)
-        if (keys[e] >= 0) plane[(int64_t)keys[e] * wpr + grp] = bits[e];
 }
 
 // 32 x 32 bit transpose across the 32 lanes of a half-wave: lane i holds row i; five block-swap steps
@@ -483,26 +483,28 @@ __device__ __forceinline__ uint32_t bit_transpose32(uint32_t w, int lane) {
     return bit_transpose_step<1, 0x55555555u>(w, lane);
 }
 
-// one half-wave per (column tile, group of 128 users): lane = column fetches 16 bytes of its first
-// column's user bit-vector, four transposes give the mask words of 4 x 32 users
+// one half-wave per (column tile, group of 128 users): lane = column fetches word `first column` of the four 32-user groups
+// (ubits [plane][group][column]: a coalesced 128-byte read per group and half-wave, duplicates of a column simply read
+// another word; the planes of a split group are ORed), four transposes give the mask words of 4 x 32 users
 __global__ __launch_bounds__(256) void mask_sweep_kernel(const int32_t* __restrict__ colfirst,
-                                                         const uint32_t* __restrict__ ubitsT, int64_t B, int64_t Bp,
-                                                         int NT, uint32_t* __restrict__ maskW, int planes, int64_t plane_words) {
+                                                         const uint32_t* __restrict__ ubits, int64_t B, int64_t Bp, int64_t Np,
+                                                         int NT, uint32_t* __restrict__ maskW, int planes) {
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int ngrp = (int)(Bp >> 7);
     const int64_t unit = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + h;
     if (unit >= (int64_t)NT * ngrp) return;
     const int tj = (int)(unit / ngrp), g = (int)(unit % ngrp);
     const int32_t f = colfirst[tj * 32 + c];                 // -1: padding column, never a negative
-    uint4 w = {~0u, ~0u, ~0u, ~0u};
+    uint32_t in[4] = {~0u, ~0u, ~0u, ~0u};
     if (f >= 0) {
-        w = *reinterpret_cast<const uint4*>(ubitsT + (int64_t)f * (Bp >> 5) + 4 * g);
-        for (int pl = 1; pl < planes; ++pl) {                   // (the pieces of a split group each own a plane)
-            const uint4 o = *reinterpret_cast<const uint4*>(ubitsT + pl * plane_words + (int64_t)f * (Bp >> 5) + 4 * g);
-            w.x |= o.x; w.y |= o.y; w.z |= o.z; w.w |= o.w;
+        const int64_t plane_words = (Bp >> 5) * Np;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) in[q] = ubits[((int64_t)4 * g + q) * Np + f];
+        for (int pl = 1; pl < planes; ++pl) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) in[q] |= ubits[pl * plane_words + ((int64_t)4 * g + q) * Np + f];
         }
     }
-    const uint32_t in[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t word = bit_transpose32(in[q], c);
@@ -1369,40 +1371,44 @@ __global__ __launch_bounds__(256) void dv_fix_to_f32_kernel(const long long* __r
 
 // ------------------------------------------------------------------ C ABI ------
 // negative_masks of the reference (losses.py:92-110) into w.maskW
-static void clear_mask_tables(const LossWs& w, int planes, hipStream_t s) {     // mf_loss_fwd does this inside prep_kernel
+static void clear_mask_tables(const LossWs& w, hipStream_t s) {     // mf_loss_fwd does this inside prep_kernel
     (void)hipMemsetAsync(w.gtab, 0x80, (size_t)w.M * 8, s);
     (void)hipMemsetAsync(w.gfirst, 0x7f, (size_t)w.M * 4, s);
-    (void)hipMemsetAsync(w.ubits, 0, (size_t)planes * w.NT * w.Bp * 4, s);
     (void)hipMemsetAsync(w.bmap, 0, (size_t)4 << (w.bmbits - 5), s);
 }
-static void prep_clears(PrepParams& pp, const LossWs& w, int planes) {
+static void prep_clears(PrepParams& pp, const LossWs& w) {
     pp.gtab = reinterpret_cast<uint4*>(w.gtab); pp.gtab16 = (int64_t)w.M * 8 / 16;
     pp.gfirst = reinterpret_cast<uint4*>(w.gfirst); pp.gfirst16 = (int64_t)w.M * 4 / 16;
-    pp.ubits = reinterpret_cast<uint4*>(w.ubits); pp.ubits16 = (int64_t)planes * w.NT * w.Bp * 4 / 16;
+    pp.ubits = nullptr; pp.ubits16 = 0;                  // (the hit rows are written whole: nothing to clear)
     pp.bmap = reinterpret_cast<uint4*>(w.bmap); pp.bmap16 = ((int64_t)4 << (w.bmbits - 5)) / 16;
 }
 
-// pieces a group's flat list range is cut into (= planes of ubitsT in use): CSR lists are heavy-tailed and unknown to the
-// host -> the maximum; padded lists by their width (P = 64: one piece, as before)
+// pieces a group's flat list range is cut into (= planes of ubits in use): CSR lists are heavy-tailed and unknown to the
+// host -> two; padded lists by their width (P = 64: one piece)
 static int hits_split(const PosSrc& src) {
-    if (src.pos_off) return HITS_MAX_SPLIT;
+    if (src.pos_off) return 2;
     const int per_group = 32 * (src.P + 1);
-    int sp = (per_group + 8191) / 8192;
+    int sp = (per_group + 16383) / 16384;
     return sp < 1 ? 1 : (sp > HITS_MAX_SPLIT ? HITS_MAX_SPLIT : sp);
 }
 
-// expects gtab / gfirst / bmap and hits_split(src) planes of ubits cleared
+// expects gtab / gfirst / bmap cleared (ubits needs no clearing: every word in use is written)
 static void build_masks(const LossWs& w, const int64_t* item_idx, const PosSrc& src, int64_t B, int64_t N, hipStream_t s) {
     gt_insert_kernel<<<dim3((unsigned)((N + 63) / 64)), 64, 0, s>>>(item_idx, N, w.M, w.gtab, w.gfirst, w.colslot, w.bmap, w.bmbits);
     const int split = hits_split(src);
     const int nb_col = (int)((w.Np + HITS_THREADS - 1) / HITS_THREADS);
-    const int nb_u = (int)((B + 31) / 32) * split;
-    const size_t lds = (size_t)HITS_CAP * 8 + ((size_t)4 << (w.bmbits - 5));
-    hits_kernel<<<dim3((unsigned)(nb_col + nb_u)), HITS_THREADS, lds, s>>>(item_idx, src, B, N, w.Bp, w.Np, w.M, nb_col, split, w.gtab,
+    const int nb_u = (int)(w.Bp / 32) * split;               // (padding groups too: their rows are read by the sweep)
+    const int win = (int)(w.Np < HITS_WIN ? w.Np : HITS_WIN);
+    const size_t lds = (size_t)win * 4 + ((size_t)4 << (w.bmbits - 5));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)hits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HITS_WIN * 4 + (4 << 12));
+        attr_set = true;
+    }
+    hits_kernel<<<dim3((unsigned)(nb_col + nb_u)), HITS_THREADS, lds, s>>>(item_idx, src, B, N, w.Bp, w.Np, w.M, nb_col, split, win, w.gtab,
                                                                            w.gfirst, w.colslot, w.colfirst, w.ubits, w.bmap, w.bmbits);
     const int64_t units = (int64_t)w.NT * (w.Bp >> 7);
-    mask_sweep_kernel<<<dim3((unsigned)((units + 7) / 8)), 256, 0, s>>>(w.colfirst, w.ubits, B, w.Bp, w.NT, w.maskW, split,
-                                                                       (int64_t)w.Np * (w.Bp >> 5));
+    mask_sweep_kernel<<<dim3((unsigned)((units + 7) / 8)), 256, 0, s>>>(w.colfirst, w.ubits, B, w.Bp, w.Np, w.NT, w.maskW, split);
 }
 
 template <int D, bool XU>
@@ -1448,9 +1454,9 @@ static int loss_masks_impl(const char* what, int64_t B, int64_t N, int d, int nu
     hipStream_t s = static_cast<hipStream_t>(stream);
     LossWs w = loss_ws(ws, B, N, d, 0, num_negatives);
     PrepParams pp{};
-    prep_clears(pp, w, hits_split(src));
+    prep_clears(pp, w);
     pp.ticket = w.ticket;
-    const int64_t want = (pp.ubits16 + 64 * 8 - 1) / (64 * 8);
+    const int64_t want = (pp.gtab16 + pp.gfirst16 + pp.bmap16 + 64 * 8 - 1) / (64 * 8);
     prep_kernel<0><<<dim3((unsigned)(want < 8192 ? (want > 0 ? want : 1) : 8192)), 64, 0, s>>>(pp);   // clears only
     build_masks(w, item_idx, src, B, N, s);
     return mf_check_launch(what);
@@ -1508,8 +1514,8 @@ static int loss_fwd_impl(const char* what, int64_t B, int64_t N, int d, const Po
                       nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, w.ticket};
         int nb = (int)((w.Np + 63) / 64);
         if (scores_needed && !masks_ready) {
-            prep_clears(pp, w, hits_split(src));
-            const int64_t want = (pp.ubits16 + 64 * 8 - 1) / (64 * 8);       // ~8 stores per thread
+            prep_clears(pp, w);
+            const int64_t want = (pp.gtab16 + pp.gfirst16 + pp.bmap16 + 64 * 8 - 1) / (64 * 8);       // ~8 stores per thread
             if (want > nb) nb = (int)(want < 8192 ? want : 8192);
         }
         MF_DISPATCH_D(d, { prep_kernel<D><<<dim3((unsigned)nb), 64, 0, s>>>(pp); });
@@ -1658,7 +1664,7 @@ extern "C" int mf_negative_masks(int64_t B, int64_t N, int P, const int64_t* ite
     hipStream_t s = static_cast<hipStream_t>(stream);
     LossWs w = loss_ws(ws, B, N, 32, P, 1);
     const PosSrc src{pos_idx, P, nullptr, nullptr, nullptr, 0};
-    clear_mask_tables(w, hits_split(src), s);
+    clear_mask_tables(w, s);
     build_masks(w, item_idx, src, B, N, s);
     mask_export_bool_kernel<<<dim3((unsigned)((B * N + 255) / 256)), 256, 0, s>>>(w.maskW, B, N, w.Bp, out_mask);
     return mf_check_launch("mf_negative_masks");

@@ -322,6 +322,98 @@ class DeviceInteractionSampler:
             step += 1
 
 
+# ------------------------------------------------------------------ MovieLens ratings files (ids only) ---
+def _read_id_column(path, sep: str, skip_header: bool):
+    """First field of every line of an ids file (movies.dat / users.dat / movies.csv): the reference numbers its rows
+    ``movie_rn`` / ``user_rn`` in FILE order from 1 (``with_row_index(..., offset=1)``, prepare.py:85,121)."""
+    import numpy as np
+
+    ids = []
+    with open(path, encoding="iso-8859-1") as f:
+        if skip_header:
+            next(f, None)
+        for line in f:
+            if line.strip():
+                ids.append(int(line.split(sep, 1)[0]))
+    return np.asarray(ids, dtype=np.int64)
+
+
+def read_ratings(path) -> dict[str, torch.Tensor]:
+    """A MovieLens ratings file as id vectors: ``ml-1m/ratings.dat`` (``UserID::MovieID::Rating::Timestamp``, the file
+    ``load_ratings`` reads, xfmr_rec/data/prepare.py:132-152) or ``ml-25m/ratings.csv`` (``userId,movieId,rating,timestamp``
+    with a header; half-star ratings).  Returns ``user_id``, ``movie_id``, ``timestamp`` (int64) and ``rating`` (float32)."""
+    import io
+    import pathlib
+
+    import numpy as np
+    import pandas as pd
+
+    path = pathlib.Path(path)
+    if path.suffix == ".dat":           # "::" is not a single-character separator: rewrite it and let the C parser run
+        raw = path.read_bytes().replace(b"::", b",")
+        df = pd.read_csv(io.BytesIO(raw), header=None, names=["user_id", "movie_id", "rating", "timestamp"],
+                         dtype={"user_id": np.int64, "movie_id": np.int64, "rating": np.float32, "timestamp": np.int64})
+    else:
+        df = pd.read_csv(path, header=0, names=["user_id", "movie_id", "rating", "timestamp"],
+                         dtype={"user_id": np.int64, "movie_id": np.int64, "rating": np.float32, "timestamp": np.int64})
+    return {k: torch.from_numpy(df[k].to_numpy().copy()) for k in ("user_id", "movie_id", "rating", "timestamp")}
+
+
+def find_movielens(root=None):
+    """The first MovieLens ratings file under ``root`` (default: ``$MF_MOVIELENS_DIR``, then ``./data``): the reference's
+    ``data/ml-1m/ratings.dat``, or ``ml-25m/ratings.csv`` / ``ml-latest*/ratings.csv``.  ``None`` when there is none
+    (there is no network here: benchmarks and fixtures never depend on the files)."""
+    import os
+    import pathlib
+
+    roots = [root] if root is not None else [os.environ.get("MF_MOVIELENS_DIR"), "data"]
+    for r in roots:
+        if not r:
+            continue
+        r = pathlib.Path(r)
+        for rel in ("ml-25m/ratings.csv", "ratings.csv", "ml-1m/ratings.dat", "ratings.dat", "ml-20m/ratings.csv",
+                    "ml-latest/ratings.csv", "ml-latest-small/ratings.csv", "ml-100k/ratings.csv"):
+            if (r / rel).is_file():
+                return r / rel
+    return None
+
+
+def movielens_interactions(ratings_path, *, train_prop: float = 0.8, val_prop: float = 0.2):
+    """``(InteractionTable, meta)`` of a MovieLens ratings file.  Item rows are the reference's ``movie_rn``: the 1-based
+    position of the movie in ``movies.dat`` / ``movies.csv`` next to the ratings file (file order, prepare.py:85); users
+    likewise from ``users.dat``; without those files, the rank of the id among the ids that occur (the same numbers whenever
+    the side files are sorted by id and complete, as ML-1M's are).  Row 0 of both tables stays the padding row."""
+    import pathlib
+
+    import numpy as np
+
+    ratings_path = pathlib.Path(ratings_path)
+    r = read_ratings(ratings_path)
+
+    def row_numbers(ids: torch.Tensor, side_files):
+        for name, sep, header in side_files:
+            f = ratings_path.parent / name
+            if f.is_file():
+                order = _read_id_column(f, sep, header)
+                break
+        else:
+            order = np.unique(ids.numpy())
+        lut = np.full(int(max(order.max(), int(ids.max()))) + 1, -1, dtype=np.int64)
+        lut[order] = np.arange(1, order.size + 1)
+        rn = lut[ids.numpy()]
+        if (rn < 0).any():
+            msg = f"{ratings_path}: ids without a row in the side file"
+            raise ValueError(msg)
+        return torch.from_numpy(rn), int(order.size) + 1
+
+    item, num_items = row_numbers(r["movie_id"], (("movies.dat", "::", False), ("movies.csv", ",", True)))
+    user, num_users = row_numbers(r["user_id"], (("users.dat", "::", False),))
+    table = InteractionTable(user, item, r["rating"], r["timestamp"], train_prop=train_prop, val_prop=val_prop)
+    meta = {"path": str(ratings_path), "num_users": num_users, "num_items": num_items, "ratings": int(user.numel()),
+            "train_pairs": int(table.pair_user.numel())}
+    return table, meta
+
+
 def to_device(batch, device):
     if isinstance(batch, dict):
         return {k: to_device(v, device) for k, v in batch.items()}

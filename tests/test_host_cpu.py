@@ -255,3 +255,31 @@ def test_bench_starts_its_own_ranks_and_reports_them():
     if not torch.cuda.is_available():
         none = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
         assert none.returncode == 2 and "visible" in none.stderr
+
+
+def test_movielens_ratings_reader(mf, tmp_path):
+    """ids-only reader of the reference's inputs (xfmr_rec/data/prepare.py:132-152 reads ml-1m/ratings.dat; ml-25m ships
+    ratings.csv): both layouts give the same interaction table; movie_rn / user_rn follow the side files' order."""
+    rows = [(1, 10, 5, 100), (1, 30, 3, 200), (1, 20, 4, 300), (1, 50, 2, 400), (1, 40, 1, 500),
+            (2, 30, 4, 150), (2, 10, 2, 250), (7, 50, 5, 50), (7, 20, 3, 60), (7, 30, 1, 70), (7, 10, 4, 80), (7, 40, 2, 90)]
+    d1 = tmp_path / "ml-1m"
+    d1.mkdir()
+    (d1 / "ratings.dat").write_text("".join(f"{u}::{m}::{r}::{t}\n" for u, m, r, t in rows))
+    (d1 / "movies.dat").write_text("".join(f"{m}::Title {m} (1999)::Drama|Comedy\n" for m in (10, 20, 25, 30, 40, 50)), encoding="iso-8859-1")
+    (d1 / "users.dat").write_text("".join(f"{u}::F::25::3::12345\n" for u in (1, 2, 5, 7)))
+    d2 = tmp_path / "ml-25m"
+    d2.mkdir()
+    (d2 / "ratings.csv").write_text("userId,movieId,rating,timestamp\n" + "".join(f"{u},{m},{r}.0,{t}\n" for u, m, r, t in rows))
+    assert mf.data.find_movielens(tmp_path) == d2 / "ratings.csv"
+    assert mf.data.find_movielens(d1.parent / "ml-1m") == d1 / "ratings.dat"
+    raw = mf.data.read_ratings(d1 / "ratings.dat")
+    assert raw["user_id"].tolist() == [r[0] for r in rows] and raw["rating"].dtype == torch.float32
+    t1, m1 = mf.data.movielens_interactions(d1 / "ratings.dat")
+    t2, m2 = mf.data.movielens_interactions(d2 / "ratings.csv")
+    # side files: movie 25 has no rating but owns row 3; user 5 owns row 3
+    assert (m1["num_items"], m1["num_users"]) == (7, 5) and (m2["num_items"], m2["num_users"]) == (6, 4)
+    rn1 = {10: 1, 20: 2, 30: 4, 40: 5, 50: 6}
+    assert sorted(t1.pair_item.tolist()) == sorted(rn1[m] for (u, m, r, t), tr in zip(rows, t1.is_train.tolist()) if tr)
+    assert torch.equal(t1.is_train, t2.is_train) and torch.equal(t1.pos_off[[1, 2]], t2.pos_off[[1, 2]])
+    # user 1: 5 ratings in time order 10, 30, 20, 50, 40 -> the first 80 % are train
+    assert t1.pos_items[t1.pos_off[1]: t1.pos_off[2]].tolist() == [rn1[10], rn1[30], rn1[20], rn1[50]]
