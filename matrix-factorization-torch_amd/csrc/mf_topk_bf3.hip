@@ -5,14 +5,24 @@
 // accumulation) and a RIGOROUS error bound decides which rows are rescored with the canonical fp32 fmaf chain:
 //
 //   index      yb = bf16(y) for every catalog row (round to nearest even), ymax = max row norm      (built once)
-//   pass A     a(q, y) = xb_q . yb_y for every (query, row); per query only the maximum of every GROUP of 128
-//              rows (by lane half: two values per group) is kept -- each is the score of a distinct row, so the
-//              k-th largest of them, tau_q, is a lower bound of the k-th largest a(q, .)
+//   prep       per query: its exclusion list as a row of bit words, its bf16 fragments in MFMA operand order, counters
+//   seed       a(q, y) = xb_q . yb_y for a SAMPLE of the catalog (one 4-tile block in every `bs`: half of a long
+//              catalog, all of a short one); per query only the maximum of every block (by lane half: two values per
+//              block) is kept -- each is the score of a distinct, non-excluded row, so the k-th largest of them,
+//              tau_q, is a lower bound of the k-th largest a(q, .) over the WHOLE catalog
 //   bound      |a - s| <= eps_q for the exact chain score s (below), so k distinct rows have s >= tau_q - eps_q and
 //              every row of the true top k has a >= tau_q - 2 eps_q =: thr_q
-//   pass B     the same scan again; rows with a >= thr_q (a few dozen per query) go to lane-private lists
+//   scan       every (query, row) once; rows with a >= thr_q (a few dozen to a few hundred per query) are appended to
+//              the query's candidate list
 //   final      one wave per query rescoring its candidates with mf_dot_chain (bit for bit the fp32 MFMA element of
 //              mf_topk) and selecting the k best 64-bit keys: the result is IDENTICAL to mf_topk's
+//
+// Geometry of the two scans (round 3; round 2 staged the catalog once per 256-query block and pass -- 8 x 16 MB at
+// Q = 1024 -- and spent more time in workgroup prologues than in MFMAs).  A workgroup is four waves, ONE per SIMD, with the
+// whole 512-register file each: a wave keeps XT = 8 query tiles (256 queries) as MFMA B operands, so a workgroup covers
+// 1024 queries and every catalog tile is staged ONCE for all of them; per tile a wave reads the 8 catalog fragments from LDS
+// and runs 8 x 8 MFMAs, the (short) epilogue of query tile xt threaded between the MFMAs of query tile xt + 1.  Exclusion
+// words come straight into registers, four tiles per 16-byte load (a query's row of words is contiguous).
 //
 // Error bound.  bf16 keeps 8 significant bits: |xb - x| <= 2^-8 |x| elementwise, so
 // |xb yb - x y| <= (2^-7 + 2^-16) |x||y| per product and, by Cauchy-Schwarz, (2^-7 + 2^-16) |x|_2 |y|_2 for the sum;
@@ -20,10 +30,9 @@
 // and the chain's) each stay within d 2^-24 sum |terms| (1 + O(d 2^-24)) of the real sum.  With 1 % slack for the
 // fp32 evaluation of the norms:  eps_q = 1.01 (2^-7 + 2^-16 + d 2^-22) |x_q|_2 ymax.
 //
-// A query whose candidates do not fit (more than BF3_LCAP rows above thr in one lane's share of a chunk, or more
-// than BF3_CAND in all: a zero query, thousands of duplicate rows, a catalog whose best rows all sit in one group)
-// is answered by the same wave scanning the whole catalog with the exact chain: slow, but exact.
-// Two scans of a catalog HALF the size of the fp32 one, 1/16 of the matrix time each: DMA-bound, not MFMA-bound.
+// A query whose candidates do not fit (more than BF3_LCAP hits in one lane's share of a chunk, or more than BF3_CAND
+// in all: a zero query, thousands of duplicate rows) is answered by the final wave scanning the whole catalog with the
+// exact chain: slow, but exact.
 #include <cstdlib>
 
 #include "mf_common.h"
@@ -31,11 +40,11 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-static constexpr int BF3_NS = 4;            // ring slots (units of ST tiles); NS - 1 units in flight
-static constexpr int BF3_GROUP = 4;         // tiles per maxima group (128 rows)
-static constexpr int BF3_LIST = 16;         // words per lane-private list (per chunk, query, lane half): the count, then <= 15 rows
-static constexpr int BF3_LCAP = BF3_LIST - 1;
+static constexpr int BF3_BLOCK = 4;         // tiles per block: the unit of sampling, of maxima groups and of exclusion-word loads
+static constexpr int BF3_SLOTS = 2;         // hits a lane keeps per query tile and chunk, in registers (more: the query's overflow list)
+static constexpr int BF3_OVF = 256;         // entries of a query's overflow list
 static constexpr int BF3_CAND = 1024;       // candidates rescored per query
+static constexpr int BF3_WAVES = 8;         // waves per scan workgroup
 
 __device__ __forceinline__ unsigned short bf3_round(float x) {
     const __bf16 b = (__bf16)x;
@@ -97,35 +106,44 @@ extern "C" int mf_topk_bf3_build(const float* items, int64_t N, int d, void* ind
 
 // -------------------------------------------------------------------- plan ----
 struct Bf3Plan {
-    int NT;             // 32-row tiles of the catalog
-    int ST;             // tiles per ring unit
-    int upc, nchunk;    // units per chunk (workgroup), chunks
-    int gpc;            // maxima groups per chunk
-    int nvals;          // group maxima per query: nchunk * gpc * 2
-    int XT;             // 32-query tiles per wave (1 or 2): a workgroup scans for 128 XT queries
-    int64_t Qp;         // queries padded to 128 XT
+    int NT, NTp;        // 32-row tiles of the catalog; row stride of the exclusion words (a multiple of 4, + 4)
+    int nblk;           // 4-tile blocks
+    int XT, xw;         // query tiles per wave; distinct query-tile sets among a workgroup's eight waves (1, 2, 4 or 8)
+    int64_t Qp;         // queries padded to a workgroup's 32 * XT * xw
     int gy;             // query blocks
+    int bs;             // the seed scan takes one block in every bs
+    int nvb_seed, bpc_seed, nwg_seed;   // seed scan: virtual blocks, blocks per workgroup, workgroups
+    int bpc, nwg;       // full scan
+    int nvals;          // seed maxima per query: nvb_seed * 2 * (BF3_WAVES / xw)
 };
 static Bf3Plan bf3_plan(int64_t Q, int64_t N, int d) {
     Bf3Plan p{};
     p.NT = (int)((N + 31) / 32);
-    p.ST = d >= 256 ? 1 : 2;                                   // 16 KiB per unit
-    // every block of queries stages the whole catalog through LDS: twice the queries per workgroup, half the traffic
-    p.XT = (Q > 256 && d <= 128) ? 2 : 1;
-    p.Qp = (Q + 128 * p.XT - 1) / (128 * p.XT) * (128 * p.XT);
-    p.gy = (int)(p.Qp / (128 * p.XT));
-    const int units = (p.NT + p.ST - 1) / p.ST;
-    int want = (512 + p.gy - 1) / p.gy;                        // two workgroups per CU
-    if (want > 128) want = 128;                                // (bf3_final_kernel: at most 256 lists per query)
-    if (want > units) want = units;
-    if (want < 1) want = 1;
-    p.upc = (units + want - 1) / want;
-    // whole groups per chunk: a chunk is a multiple of BF3_GROUP tiles
-    const int tiles_pc = (p.upc * p.ST + BF3_GROUP - 1) / BF3_GROUP * BF3_GROUP;
-    p.upc = tiles_pc / p.ST;
-    p.nchunk = (units + p.upc - 1) / p.upc;
-    p.gpc = tiles_pc / BF3_GROUP;
-    p.nvals = p.nchunk * p.gpc * 2;
+    p.nblk = (p.NT + BF3_BLOCK - 1) / BF3_BLOCK;
+    p.NTp = p.nblk * BF3_BLOCK + 4;
+    const int qt = (int)((Q + 31) / 32);
+    // eight waves per workgroup, two per SIMD (one's epilogue beside the other's MFMAs), XT query tiles each: 1024 queries
+    // per workgroup at d <= 128 (512 at d = 256: its fragments are twice as long), one workgroup per CU
+    const int xt_big = d >= 256 ? 2 : 4;
+    if (qt <= BF3_WAVES) { p.XT = 1; p.xw = qt <= 1 ? 1 : qt <= 2 ? 2 : qt <= 4 ? 4 : 8; }
+    else { p.XT = xt_big; p.xw = BF3_WAVES; }
+    const int per_wg = 32 * p.XT * p.xw;
+    p.Qp = (Q + per_wg - 1) / per_wg * per_wg;
+    p.gy = (int)(p.Qp / per_wg);
+    // long catalogs: the bound comes from a quarter of the rows; short ones are sampled whole (few maxima otherwise)
+    p.bs = p.nblk >= 256 ? 2 : 1;          // (measured at Q = 1024, N = 62,423: every 4th / 2nd / every block -> 76.5 / 70.4 / 75.9 us, 151 / 78 / 40 candidates per query)
+    if (const char* e = getenv("MF_BF3_BS")) { const int v = atoi(e); if (v >= 1 && p.nblk >= 64 * v) p.bs = v; }   // lab knob
+    p.nvb_seed = (p.nblk + p.bs - 1) / p.bs;
+    auto cut = [&](int blocks, int* bpc, int* nwg) {
+        int want = (256 + p.gy - 1) / p.gy;                 // one workgroup per CU
+        if (want > blocks) want = blocks;
+        if (want < 1) want = 1;
+        *bpc = (blocks + want - 1) / want;
+        *nwg = (blocks + *bpc - 1) / *bpc;
+    };
+    cut(p.nvb_seed, &p.bpc_seed, &p.nwg_seed);
+    cut(p.nblk, &p.bpc, &p.nwg);
+    p.nvals = p.nvb_seed * 2 * (BF3_WAVES / p.xw);               // per block: two lane halves x the waves that share a query-tile set
     return p;
 }
 
@@ -133,9 +151,12 @@ struct Bf3Ws {
     Bf3Plan plan;
     float* gmax;            // [Qp][nvals]
     float* thr;             // [Qp]
-    bf16x8* xfrag;          // [Qp / 32][d / 16][64]: the queries as pass A rounded them, in MFMA operand order
-    uint32_t* lists;        // [nchunk][Qp][2][BF3_LIST]: word 0 the number of rows found (> BF3_LCAP: overflow), then the rows
-    uint32_t* exclW;        // [Qp][NT]: bit r of word t = row 32 t + r is excluded for the query
+    bf16x8* xfrag;          // [Qp / 32][d / 16][64]: the queries rounded to bf16, in MFMA operand order
+    uint32_t* cand;         // [nwg x waves per set][Qp][2][BF3_SLOTS]: candidate rows by scan workgroup, query, lane half (0xFFFFFFFF: none)
+    uint32_t* ovf_list;     // [Qp][BF3_OVF]: hits beyond a lane's slots
+    int32_t* ovf_cnt;       // [Qp]: their number
+    int32_t* ovf;           // [Qp]: the overflow list overflowed too (thousands of duplicate rows, a zero query): exact path
+    uint32_t* exclW;        // [Qp][NTp]: bit r of word t = row 32 t + r is excluded for the query
     size_t total;
 };
 static Bf3Ws bf3_ws(void* base, int64_t Q, int64_t N, int d) {
@@ -145,8 +166,11 @@ static Bf3Ws bf3_ws(void* base, int64_t Q, int64_t N, int d) {
     w.gmax = a.take<float>((size_t)w.plan.Qp * w.plan.nvals);
     w.thr = a.take<float>((size_t)w.plan.Qp);
     w.xfrag = a.take<bf16x8>((size_t)w.plan.Qp * d / 8);
-    w.lists = a.take<uint32_t>((size_t)w.plan.nchunk * w.plan.Qp * 2 * BF3_LIST);
-    w.exclW = a.take<uint32_t>((size_t)w.plan.NT * w.plan.Qp + 64);
+    w.cand = a.take<uint32_t>((size_t)w.plan.nwg * (BF3_WAVES / w.plan.xw) * w.plan.Qp * 2 * BF3_SLOTS);
+    w.ovf_list = a.take<uint32_t>((size_t)w.plan.Qp * BF3_OVF);
+    w.ovf_cnt = a.take<int32_t>((size_t)w.plan.Qp);
+    w.ovf = a.take<int32_t>((size_t)w.plan.Qp);
+    w.exclW = a.take<uint32_t>((size_t)w.plan.NTp * w.plan.Qp + 64);
     w.total = a.used();
     return w;
 }
@@ -157,269 +181,287 @@ extern "C" size_t mf_topk_bf3_ws_bytes(int64_t Q, int64_t N, int d, int k) {
 
 // -------------------------------------------------------------------- scan ----
 struct Bf3Scan {
-    const float* q;             // [Q][D] fp32 queries
     int64_t Q, Qp;
     const unsigned short* plane;
     int64_t N;
-    int NT, upc, gpc, nvals;
-    const uint32_t* exclW;      // [Qp][NT]
-    float* gmax;                // pass A out
-    const float* thr;           // pass B in
-    bf16x8* xfrag;              // pass A out (chunk 0), pass B in
-    uint32_t* lists;
-    int abl;                    // lab knob (MF_BF3_ABL): 1 = no staging, 2 = no arithmetic -- wrong results, for timing only
+    int NT, NTp, nblk;
+    int bs, bpc, nvb;           // this launch: block stride of the sample, virtual blocks per workgroup, virtual blocks in all
+    int xw;                     // distinct query-tile sets among the four waves
+    int nvals;
+    const uint32_t* exclW;      // [Qp][NTp]
+    float* gmax;                // PASS 0 out: [Qp][nvals]
+    const float* thr;           // PASS 1 in
+    const bf16x8* xfrag;
+    uint32_t* cand;
+    uint32_t* ovf_list;
+    int32_t* ovf_cnt;
+    int32_t* ovf;
+    int abl;                    // lab knob (MF_BF3_ABL): 1 = no arithmetic, 2 = hits are not parked, 4 = no query fragments -- wrong results, for timing only
 };
 
-template <int D, int ST, int XT, bool EXCL>
+// The scans stage tiles with all eight waves: the tile geometry of mf_stream.h is written for four, so a tile's pieces are
+// dealt to the waves explicitly here (piece j of a tile = 1 KiB of its LDS image: wave j % 8 stages it).
+template <int D, int XT>
 struct Bf3Lds {
-    using G = TileGeom<D / 2>;                               // a bf16 row is as long as a fp32 row of half the width
-    static constexpr int UNITB = ST * G::TILEB;
-    static constexpr int AUXW = XT * 256;                    // per wave and unit: one exclusion word per lane and query tile ([xt][tile of the unit][query])
-    static constexpr int AUX0 = BF3_NS * UNITB;
-    static constexpr int BYTES = AUX0 + (EXCL ? BF3_NS * G::NW * AUXW : 0);
-    static constexpr int SI = ST * G::PPW + (EXCL ? XT : 0); // memory instructions per wave and stage
+    static constexpr int ROWB = D * 2;                        // bytes of a bf16 row
+    static constexpr int TILEB = 32 * ROWB;
+    static constexpr int PIECES = TILEB / 1024;               // 4 (d = 64), 8, 16
+    static constexpr int PPW = (PIECES + BF3_WAVES - 1) / BF3_WAVES;    // DMA instructions per wave and tile (1, 1, 2)
+    static constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row
+    static __device__ __forceinline__ int swz(int row) { return CPR >= 16 ? (row & 15) : ((row >> 1) & 7); }
+    static constexpr int NS = D <= 128 ? 10 : 6;              // ring slots (one 32-row tile each); NS - 1 tiles in flight
+    static constexpr int RING = NS * TILEB;
+    static constexpr int EX0 = RING;
+    static constexpr int EXW = XT * 512;                      // exclusion words of one block: per query tile 32 queries x 4 tiles
+    static constexpr int EXS = (NS - 2) / BF3_BLOCK + 2;      // blocks in rotation per wave: in use, in flight behind it, being staged
+    static constexpr int EXB = BF3_WAVES * EXS * EXW;
+    static constexpr int DUMP0 = EX0 + EXB;                   // where the (zero) pieces of waves without a share of a short tile land
+    static constexpr int BYTES = DUMP0 + 1024;
+    // vector-memory instructions per wave behind the stage of a tile, among the NS - 2 = BLOCK stages that follow it: their
+    // tile pieces, and the XT exclusion DMAs of the one block start among them
+    static_assert((NS - 2) % BF3_BLOCK == 0, "a fixed number of block starts among the stages in flight behind a tile");
 };
 
-#ifdef BF3_PROBE
-// tools/lab/bf3_probe.py: cycles of wave 0 of every workgroup, summed: 0 total, 1 prologue, 2 wait + barrier, 3 stage issue,
-// 4 LDS reads + MFMAs, 5 epilogue, 6 tail, 7 workgroups
-static __device__ unsigned long long bf3_dbg[2][8];
-#define BF3_T(v) const unsigned long long v = __builtin_readcyclecounter()
-#define BF3_ADD(i, x) dbg[i] += (x)
-#else
-#define BF3_T(v)
-#define BF3_ADD(i, x)
-#endif
-
-// PASS 0: group maxima; PASS 1: candidate lists
-template <int D, int ST, int XT, bool EXCL, int PASS>
-__global__ __launch_bounds__(256, 2) void bf3_scan_kernel(Bf3Scan p) {
+// PASS 0: block maxima of the sample; PASS 1: candidate lists of the whole catalog
+template <int D, int XT, bool EXCL, int PASS>
+__global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using L = Bf3Lds<D, ST, XT, EXCL>;
-    using G = typename L::G;
+    using L = Bf3Lds<D, XT>;
     constexpr int KS = D / 16;                               // MFMA steps per tile
+    constexpr int NS = L::NS;
+    constexpr int INFLIGHT = (NS - 2) * L::PPW + (EXCL ? XT * ((NS - 2) / BF3_BLOCK) : 0);
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int wave = mf_wave_id();
-    const int chunk = blockIdx.x;
-    const int64_t x0 = ((int64_t)blockIdx.y * G::NW + wave) * (32 * XT);     // this wave's XT query tiles
-    const int u0 = chunk * p.upc;
-    const int units = (p.NT + ST - 1) / ST;
-    const int u1 = min(units, u0 + p.upc);
-#ifdef BF3_PROBE
-    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 1};
-#endif
-    BF3_T(pt0);
+    const int nsub = BF3_WAVES / p.xw, set = wave % p.xw, sub = wave / p.xw;   // waves of one set deal the chunk's tiles round-robin
+    const int64_t xb0 = (int64_t)blockIdx.y * p.xw * XT * 32;               // first query of the workgroup
+    const int64_t x0 = xb0 + (int64_t)set * XT * 32;                        // this wave's XT query tiles
+    const int vb0 = blockIdx.x * p.bpc, vb1 = min(p.nvb, vb0 + p.bpc);      // virtual blocks of this workgroup
+    // virtual tile v (0 .. nv) of the chunk is real tile (vb0 + v / 4) * bs * 4 + v % 4
+    const int nv = (vb1 - vb0) * BF3_BLOCK;
+    auto real_tile = [&](int v) { return (vb0 + (v >> 2)) * p.bs * BF3_BLOCK + (v & 3); };
 
-    TileSrc<D / 2> tsrc;
-    mf_tile_src_init<D / 2>(tsrc, reinterpret_cast<const float*>(p.plane), p.N, (int64_t)u0 * ST * 32);
-    mf_rsrc_t arsrc;
-    uint32_t aoff[XT], astep = 0u;
-    if (EXCL) {
-        // exclusion words of a unit: lane (c, j) fetches the word of query x0 + 32 xt + c for tile j of the unit (4-byte DMA)
-        // the descriptor starts at the first query of this WORKGROUP (blockIdx only: provably uniform), so a lane's offset
-        // stays below 128 XT queries x NT words whatever Q is (the host refuses catalogs beyond that: bf3_excl_fits)
-        const int64_t xb0 = (int64_t)blockIdx.y * G::NW * (32 * XT);
-#pragma unroll
-        for (int xt = 0; xt < XT; ++xt)
-            aoff[xt] = h < ST ? (uint32_t)((((int64_t)(x0 - xb0 + 32 * xt + c)) * p.NT + u0 * ST + h) * 4) : MF_SRD_DEAD;
-        astep = h < ST ? (uint32_t)(ST * 4) : 0u;
+    // tile source: a raw buffer descriptor over the rows from the chunk's first (hardware range check: rows past N arrive as
+    // zeros), per-lane source offsets of this wave's pieces computed once (piece = 1 KiB of the tile's LDS image; lane l
+    // writes 16 bytes at + 16 l and reads them from row r, chunk ch ^ swz(r) of the source tile)
+    const int64_t row0 = (int64_t)real_tile(0) * 32;
+    mf_rsrc_t trsrc;
+    unsigned toff[L::PPW];
+    {
+        int64_t bytes = (p.N - row0) * (int64_t)L::ROWB;
+        bytes = bytes < 0 ? 0 : (bytes > (int64_t)MF_SRD_MAX_BYTES ? (int64_t)MF_SRD_MAX_BYTES : bytes);
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint64_t ab = ((uint64_t)p.NT * (uint64_t)(p.Qp - xb0) + 64u) * 4u;
-        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.exclW + xb0 * p.NT), 0,
+        trsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.plane + row0 * D), 0, (int)(unsigned)bytes, 0x00020000);
+#else
+        (void)trsrc;
+#endif
+#pragma unroll
+        for (int q = 0; q < L::PPW; ++q) {
+            const int piece = wave + q * BF3_WAVES;
+            const int off = piece * 1024 + lane * 16;
+            const int row = off / L::ROWB;
+            const int ch = ((off % L::ROWB) >> 4) ^ L::swz(row);
+            toff[q] = piece < L::PIECES ? (unsigned)(row * L::ROWB + ch * 16) : MF_SRD_DEAD;
+            asm volatile("" : "+v"(toff[q]));
+        }
+    }
+    // exclusion words: lane c (lower half-wave) fetches the 16 bytes = 4 tiles of its query's row; the descriptor starts at the
+    // workgroup's first query (blockIdx only: provably uniform), so offsets stay below 32 XT xw rows of NTp words
+    mf_rsrc_t arsrc;
+    uint32_t aoff = MF_SRD_DEAD;
+    if (EXCL) {
+        if (lane < 32) aoff = (uint32_t)(((x0 - xb0 + c) * (int64_t)p.NTp) * 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint64_t ab = ((uint64_t)p.NTp * (uint64_t)(p.Qp - xb0) + 64u) * 4u;
+        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.exclW + xb0 * p.NTp), 0,
                                                   (int)(ab > MF_SRD_MAX_BYTES ? MF_SRD_MAX_BYTES : ab), 0x00020000);
 #else
-        (void)arsrc; (void)aoff;
+        (void)arsrc;
 #endif
     }
-    // memory instruction j (0 .. SI-1) of the staging of unit u into slot (u - u0) % NS
-    auto stage_piece = [&](int u, int j, bool live) {
-        if (j < ST * G::PPW) {
-            char* slot = smem + ((u - u0) % BF3_NS) * L::UNITB;
-            const int st = j / G::PPW, q = j % G::PPW;
-            mf_stage_tile_piece<D / 2>(slot + st * G::TILEB, (u * ST + st) * 32, q, tsrc, live);
-        } else if (EXCL) {
-            const int xt = j - ST * G::PPW;
+    (void)aoff;
+    char* exl = smem + L::EX0 + wave * L::EXS * L::EXW;
+    auto stage = [&](int v) {                                // every wave issues the same instructions for every tile, live or not
+        const int t = real_tile(v < nv ? v : 0);
+        const bool live = v < nv && t < p.NT;
 #if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (mf_lds_ptr)(smem + L::AUX0 + (((u - u0) % BF3_NS) * G::NW + wave) * L::AUXW + xt * 256), 4,
-                                                     (int)aoff[xt], live ? 0 : (int)MF_SRD_DEAD, 0, 0);
-#endif
-            aoff[xt] += astep;
+        char* slot = smem + (v % NS) * L::TILEB;
+        const int soff = live ? (int)(((int64_t)t * 32 - row0) * L::ROWB) : (int)MF_SRD_DEAD;
+#pragma unroll
+        for (int q = 0; q < L::PPW; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(trsrc, (mf_lds_ptr)((wave + q * BF3_WAVES) < L::PIECES ? slot + (wave + q * BF3_WAVES) * 1024 : smem + L::DUMP0),
+                                                     16, (int)toff[q], soff, 0, 0);
+        if (EXCL && (v & 3) == 0) {
+            char* dst = exl + ((v >> 2) % L::EXS) * L::EXW;
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt)
+                if (lane < 32)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (mf_lds_ptr)(dst + xt * 512), 16,
+                                                             (int)(aoff + (uint32_t)(xt * 32 * p.NTp * 4 + t * 4)), live ? 0 : (int)MF_SRD_DEAD, 0, 0);
         }
+#else
+        (void)live;
+#endif
     };
-    auto stage = [&](int u, bool live) {
 #pragma unroll
-        for (int j = 0; j < L::SI; ++j) stage_piece(u, j, live);
-    };
-    // the first units are on their way while the queries are fetched and rounded
-    if (u0 < u1) {
-#pragma unroll
-        for (int j = 0; j < BF3_NS - 1; ++j) stage(u0 + j, u0 + j < u1 && !(p.abl & 1));
-    }
+    for (int j = 0; j < NS - 1; ++j) stage(j);
 
-    // the queries' bf16 fragments: step s covers k = 16 s + 8 h .. + 7.  Reading the fp32 rows here (one row per lane:
-    // every load instruction touches 64 cache lines) costs ~6 us of address processing per workgroup, so it happens at
-    // most once: pass A does it when nothing else ran before (no exclusion lists) and, in chunk 0, leaves the rounded
-    // fragments in operand order; with exclusion lists bf3_excl_rows_kernel has written them already.  Everything else
-    // reads the fragments back with coalesced 1 KiB loads
+    // the queries' bf16 fragments (written once, in operand order, by the prep launch): coalesced 1 KiB loads
     bf16x8 xb[XT][KS];
     float thr[XT];
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt) {
         const int64_t x = x0 + 32 * xt + c;
-        const bool ok = x < p.Q;
-        bf16x8* xf = p.xfrag + ((x0 / 32 + xt) * KS) * 64 + lane;
-        if (PASS == 0 && !EXCL) {
-            // (padding lanes read the last query: no branch around the loads, and nothing of theirs is ever stored)
-            const float* xr = p.q + (ok ? x : p.Q - 1) * D;
+        const bf16x8* xf = p.xfrag + ((x0 / 32 + xt) * KS) * 64 + lane;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s + 8 * h);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 8 * h + 4);
-                xb[xt][s] = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
-            }
-            if (chunk == 0) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) xf[s * 64] = xb[xt][s];
-            }
-        } else {
-            const bf16x8 zero8 = {};
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const bf16x8 f = xf[s * 64];
-                xb[xt][s] = ok ? f : zero8;         // (the fragments of padding queries were never written)
-            }
-        }
-        thr[xt] = (PASS == 1 && ok) ? p.thr[x] : __builtin_inff();      // (bf3_bound_kernel: already nudged below the bound)
+        for (int s = 0; s < KS; ++s) xb[xt][s] = (p.abl & 4) ? bf16x8{} : xf[s * 64];          // (padding queries: zero fragments, written by prep)
+        thr[xt] = (PASS == 1 && x < p.Q) ? p.thr[x] : __builtin_inff();      // (bf3_bound_kernel: already nudged below the bound)
     }
-
-    float gm[XT];                                            // running maximum of the current group (this lane's 16 rows per tile)
-    int lc[XT];                                              // PASS 1: entries in this lane's lists
+    uint32_t slot_[XT][BF3_SLOTS];                            // PASS 1: this lane's hits per query tile, newest first (0xFFFFFFFF: free)
 #pragma unroll
-    for (int xt = 0; xt < XT; ++xt) { gm[xt] = -__builtin_inff(); lc[xt] = 0; }
-    const int tail_tile = (p.N & 31) ? p.NT - 1 : -1;        // its rows past N score 0: never a maximum, never a candidate
+    for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+        for (int j = 0; j < BF3_SLOTS; ++j) slot_[xt][j] = 0xFFFFFFFFu;
+    float gm[XT];                                            // PASS 0: running maximum of the current block
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) gm[xt] = -__builtin_inff();
+    const int tail_tile = (p.N & 31) ? p.NT - 1 : -1;        // its rows past N score 0: they are not rows
     const int tail_rows = (int)(p.N & 31);
 
-    BF3_T(pt1);
-    BF3_ADD(1, pt1 - pt0);
-    if (u0 < u1) {
-        for (int u = u0; u < u1; ++u) {
-            BF3_T(pa);
-            // unit u is older than the NS - 2 stages issued after it (every stage issues SI instructions, live or not)
-            mf_wait_vmcnt<(BF3_NS - 2) * L::SI>();
-            mf_block_barrier();                              // ... for every wave; and unit u - 1's slot is free
-            BF3_T(pb);
-            const bool live_n = u + BF3_NS - 1 < u1 && !(p.abl & 1);
-            BF3_T(pc);
-            BF3_ADD(2, pb - pa);
-            BF3_ADD(3, pc - pb);
-            if (p.abl & 2) { stage(u + BF3_NS - 1, live_n); continue; }
-            const char* slot = smem + ((u - u0) % BF3_NS) * L::UNITB;
-            // every catalog fragment of the unit first (one LDS latency per unit, not per step), then its MFMAs
-            bf16x8 afr[ST][KS];
-            {
-                const char* rowp = slot + c * G::ROWB;
-                const int sw = G::swz(c);
+    for (int v = 0; v < nv; ++v) {
+        // tile v (and, at a block start, the block's exclusion words) is older than what the BLOCK stages behind it issued
+        mf_wait_vmcnt<INFLIGHT>();
+        mf_block_barrier();                                  // ... for every wave; and tile v - 1's slot is free
+        stage(v + NS - 1);
+        const int t = real_tile(v);
+        const bool mine = (v % nsub) == sub && t < p.NT && !(p.abl & 1);
+        if (mine) {
+            const char* slot = smem + (v % NS) * L::TILEB;
+            constexpr int KH = D <= 128 ? KS : KS / 2;               // fragments held at a time (d = 256: half a row, read per query tile)
+            bf16x8 afr[KH];
+            const char* rowp = slot + c * L::ROWB;
+            const int sw = L::swz(c);
+            if constexpr (D <= 128) {
 #pragma unroll
-                for (int st = 0; st < ST; ++st)
-#pragma unroll
-                    for (int s = 0; s < KS; ++s)
-                        afr[st][s] = *reinterpret_cast<const bf16x8*>(rowp + st * G::TILEB + (((2 * s + h) ^ sw) << 4));
+                for (int s = 0; s < KS; ++s) afr[s] = *reinterpret_cast<const bf16x8*>(rowp + (((2 * s + h) ^ sw) << 4));
             }
-            // the staging of unit u + NS - 1 (into the slot unit u - 1 left) goes out one instruction per few MFMAs
-            f32x16 accs[ST][XT];
-            constexpr int NMF = ST * XT * KS, GAP = NMF / L::SI;
-            int issued = 0;
+            const uint32_t tdead = t == tail_tile ? (~0u << tail_rows) : 0u;
+            uint32_t hmw[(XT + 1) / 2];                      // PASS 1: 16 hit bits per query tile
 #pragma unroll
-            for (int st = 0; st < ST; ++st)
+            for (int i = 0; i < (XT + 1) / 2; ++i) hmw[i] = 0u;
+            // epilogue of one query tile's 32 x 32 block (branch-free: it is threaded between the next block's MFMAs):
+            // PASS 0 the running maximum, PASS 1 the hit bits
+            auto epi = [&](int xt, const f32x16& acc) {
+                uint32_t dead = tdead;
+                if (EXCL) dead |= reinterpret_cast<const uint32_t*>(exl + ((v >> 2) % L::EXS) * L::EXW + xt * 512 + c * 16)[v & 3];
+                // bit e of m: element e (row mf_acc_row(e, h) of the tile) does not count for this lane's query
+                const uint32_t d4 = dead >> (4 * h);
+                const uint32_t m = (d4 & 0xFu) | ((d4 >> 4) & 0xF0u) | ((d4 >> 8) & 0xF00u) | ((d4 >> 12) & 0xF000u);
+                if (PASS == 0) {
+                    // (v_med3(a, b, +inf) = max(a, b) on finite scores, without the NaN-quieting moves fmaxf asks for)
 #pragma unroll
-                for (int xt = 0; xt < XT; ++xt) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) accs[st][xt][e] = 0.f;
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        const int i = (st * XT + xt) * KS + s;
-                        if (i % GAP == 0 && i / GAP < L::SI) { stage_piece(u + BF3_NS - 1, i / GAP, live_n); ++issued; }
-                        accs[st][xt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st][s], xb[xt][s], accs[st][xt], 0, 0, 0);
+                    for (int e = 0; e < 16; ++e) {
+                        const float x = (EXCL || true) ? (((m >> e) & 1u) ? -__builtin_inff() : acc[e]) : acc[e];
+                        gm[xt] = __builtin_amdgcn_fmed3f(gm[xt], x, __builtin_inff());
                     }
-                }
-            static_assert(GAP >= 1, "more staging instructions than MFMAs");
-            (void)issued;
-#ifdef BF3_PROBE
-            asm volatile("s_nop 0" :: "v"(accs[ST - 1][XT - 1][15]));       // (the stamp waits for the last MFMA)
-#endif
-            BF3_T(pd);
-            BF3_ADD(4, pd - pc);
+                } else {
+                    // bit e: element e is above the bound.  Two instructions per element: the sign of thr - score is shifted in
+                    // (v_alignbit), last element first; "score > thr" instead of ">=" is why thr is nudged down by the bound kernel
+                    uint32_t hm = 0u;
 #pragma unroll
-            for (int st = 0; st < ST; ++st) {
-                const int t = u * ST + st;
-                if (t >= p.NT) break;
-                const f32x16 (&acc)[XT] = accs[st];
-                const int tl = t - u0 * ST;                  // tile of the chunk
+                    for (int e = 15; e >= 0; --e) hm = __builtin_amdgcn_alignbit(hm, __builtin_bit_cast(uint32_t, thr[xt] - acc[e]), 31);
+                    hm &= 0xFFFFu & ~m;
+                    hmw[xt >> 1] |= hm << (16 * (xt & 1));
+                }
+            };
+            if constexpr (D <= 128) {
+                // two accumulator sets: the epilogue of query tile xt - 1 is threaded between the MFMAs of query tile xt
+                f32x16 accA, accB;
 #pragma unroll
                 for (int xt = 0; xt < XT; ++xt) {
-                    const int64_t x = x0 + 32 * xt + c;
-                    uint32_t dead = 0u;                      // rows of this tile that do not count for this lane's query
-                    if (EXCL) dead = reinterpret_cast<const uint32_t*>(smem + L::AUX0 + (((u - u0) % BF3_NS) * G::NW + wave) * L::AUXW + xt * 256)[st * 32 + c];
-                    if (PASS == 0) {
-                        // (v_med3(a, b, +inf) = max(a, b) on finite scores, without the NaN-quieting moves fmaxf asks for)
-                        if (EXCL && __any(dead != 0u)) {
+                    f32x16& cur = (xt & 1) ? accB : accA;
+                    const f32x16& prev = (xt & 1) ? accA : accB;
 #pragma unroll
-                            for (int e = 0; e < 16; ++e)
-                                gm[xt] = __builtin_amdgcn_fmed3f(gm[xt], ((dead >> mf_acc_row(e, h)) & 1u) ? -__builtin_inff() : acc[xt][e], __builtin_inff());
-                        } else {
+                    for (int e = 0; e < 16; ++e) cur[e] = 0.f;
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) gm[xt] = __builtin_amdgcn_fmed3f(gm[xt], acc[xt][e], __builtin_inff());
+                    for (int s = 0; s < KS; ++s) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], xb[xt][s], cur, 0, 0, 0);
+                    if (xt > 0) {
+                        epi(xt - 1, prev);
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x006, 64 / KS, 0);
                         }
-                        if ((tl % BF3_GROUP) == BF3_GROUP - 1 || t == p.NT - 1) {
-                            // the zero rows past N in the last tile are not rows: its group tells the bound nothing
-                            if (x < p.Q) p.gmax[x * p.nvals + ((int64_t)chunk * p.gpc + tl / BF3_GROUP) * 2 + h] = (t == tail_tile) ? -__builtin_inff() : gm[xt];
-                            gm[xt] = -__builtin_inff();
-                        }
-                    } else {
-                        // bit (15 - e) of hm: element e is above the bound.  Two instructions per element: the sign of
-                        // thr - score is shifted in (v_alignbit); "score > thr" instead of ">=" is why thr is nudged down below
-                        uint32_t hm = 0u;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                epi(XT - 1, ((XT - 1) & 1) ? accB : accA);
+            } else {
+                // d = 256: the fragments alone take half the registers -- one accumulator set, the partner wave of the SIMD
+                // covers the epilogues
 #pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            hm = __builtin_amdgcn_alignbit(hm, __builtin_bit_cast(uint32_t, thr[xt] - acc[xt][e]), 31);
-                        if (__any(hm != 0u)) {
-                            if (t == tail_tile) dead |= ~0u << tail_rows;
-                            uint32_t* mylist = p.lists + (((int64_t)chunk * p.Qp + x) * 2 + h) * BF3_LIST;
-                            while (hm) {
-                                const int e = 15 - __builtin_ctz(hm);
-                                hm &= hm - 1;
-                                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                                if (!((dead >> rr) & 1u)) {
-                                    if (lc[xt] < BF3_LCAP) mylist[1 + lc[xt]] = (uint32_t)t * 32u + (uint32_t)rr;
-                                    ++lc[xt];
-                                }
+                for (int xt = 0; xt < XT; ++xt) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                    for (int s0 = 0; s0 < KS; s0 += KH) {
+#pragma unroll
+                        for (int s = 0; s < KH; ++s) afr[s] = *reinterpret_cast<const bf16x8*>(rowp + (((2 * (s0 + s) + h) ^ sw) << 4));
+#pragma unroll
+                        for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], xb[xt][s0 + s], acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);        // (the next half's fragments are not read ahead: registers)
+                    }
+                    epi(xt, acc);
+                }
+            }
+            if (PASS == 1) {
+                bool any = false;
+#pragma unroll
+                for (int i = 0; i < (XT + 1) / 2; ++i) any = any || hmw[i] != 0u;
+                if (__any(any) && !(p.abl & 2)) {
+                    const unsigned row0t = (unsigned)t * 32u + 4u * (unsigned)h;
+#pragma unroll
+                    for (int xt = 0; xt < XT; ++xt) {
+                        uint32_t w = (hmw[xt >> 1] >> (16 * (xt & 1))) & 0xFFFFu;
+                        while (w) {                              // (a few per query and workgroup: rarely more than one trip)
+                            const int e = __builtin_ctz(w);
+                            w &= w - 1;
+                            const unsigned row = row0t + (unsigned)((e & 3) + 8 * (e >> 2));
+                            if (slot_[xt][BF3_SLOTS - 1] == 0xFFFFFFFFu) {      // a free slot left
+#pragma unroll
+                                for (int j = BF3_SLOTS - 1; j > 0; --j) slot_[xt][j] = slot_[xt][j - 1];
+                                slot_[xt][0] = row;
+                            } else {                              // beyond the slots: the query's overflow list (an atomic: rare)
+                                const int64_t x = x0 + 32 * xt + c;
+                                const int at = atomicAdd(&p.ovf_cnt[x], 1);
+                                if (at < BF3_OVF) p.ovf_list[x * BF3_OVF + at] = row;
+                                else p.ovf[x] = 1;
                             }
                         }
                     }
                 }
             }
         }
-        mf_wait_vmcnt<0>();                                  // nothing of this workgroup may still be on its way into LDS when it ends
-    }
-#ifdef BF3_PROBE
-    {
-        BF3_T(pe);
-        dbg[0] = pe - pt0;
-        dbg[6] = pe - pt1 - dbg[2] - dbg[3] - dbg[4];
-        if (threadIdx.x == 0)
-            for (int i = 0; i < 8; ++i) atomicAdd(&bf3_dbg[PASS][i], dbg[i]);
-    }
-#endif
+        if (PASS == 0 && (v & 3) == 3) {
+            // one block done: the maximum per (query, lane half) over THIS wave's tiles of the block (the waves of a set deal
+            // the tiles among them: each writes its own value -- scores of distinct rows either way)
+            const int vb = vb0 + (v >> 2);
 #pragma unroll
-    for (int xt = 0; xt < XT; ++xt) {
-        const int64_t x = x0 + 32 * xt + c;
-        if (x >= p.Q) continue;
-        if (PASS == 0) {
-            // groups this chunk never reached (short last chunk): no rows
-            const int done = u0 < u1 ? (min(u1 * ST, p.NT) - u0 * ST + BF3_GROUP - 1) / BF3_GROUP : 0;
-            for (int g = done; g < p.gpc; ++g) p.gmax[x * p.nvals + ((int64_t)chunk * p.gpc + g) * 2 + h] = -__builtin_inff();
-        } else {
-            p.lists[(((int64_t)chunk * p.Qp + x) * 2 + h) * BF3_LIST] = (uint32_t)lc[xt];      // > BF3_LCAP: overflow
+            for (int xt = 0; xt < XT; ++xt) {
+                const int64_t x = x0 + 32 * xt + c;
+                if (x < p.Q) p.gmax[x * p.nvals + ((int64_t)vb * 2 + h) * nsub + sub] = gm[xt];
+                gm[xt] = -__builtin_inff();
+            }
+        }
+    }
+    mf_wait_vmcnt<0>();                                      // nothing of this workgroup may still be on its way into LDS when it ends
+    if (PASS == 1) {
+        // this lane's slots of every query tile: 8 bytes each, a wave's 32 queries x 2 halves contiguous (no counters, no atomics)
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) {
+            const int64_t x = x0 + 32 * xt + c;
+            *reinterpret_cast<uint2*>(p.cand + ((((int64_t)blockIdx.x * nsub + sub) * p.Qp + x) * 2 + h) * BF3_SLOTS) =
+                uint2{slot_[xt][0], slot_[xt][1]};
         }
     }
 }
@@ -474,13 +516,19 @@ struct Bf3Final {
     const float* q;
     const float* items;
     int64_t N;
-    int d, k, nchunk, NT;
+    int d, k, NT, NTp;
     int64_t Qp;
-    const uint32_t* lists;
+    int nlists;                 // candidate blocks per query: scan workgroups x waves sharing a query tile
+    const uint32_t* cand;       // [nlists][Qp][2][BF3_SLOTS]
+    const uint32_t* ovf_list;
+    const int32_t* ovf_cnt;
+    const int32_t* ovf;
     const uint32_t* exclW;      // NULL: nothing excluded
     int64_t idx_base;
     float* out_scores;
     int64_t* out_idx;
+    int abl;                    // lab knob (MF_BF3_ABL): 8 = no rescoring, 16 = no selection -- wrong results, for timing only
+    unsigned long long* dbg;    // lab: [0] += candidates gathered, [1] += queries (NULL: off)
 };
 
 // the canonical chain (mf_dot_chain's order) with up to 128 floats of the row in flight at a time
@@ -506,64 +554,112 @@ __device__ __forceinline__ float bf3_exact_dot(const float* xq, const float* __r
 
 template <int D>
 __global__ __launch_bounds__(64) void bf3_final_kernel(Bf3Final p) {
+    constexpr int CH = 64;                                   // floats of a row staged at a time (the chain runs chunk after chunk)
+    constexpr int ROWF = CH + 4;                             // LDS row stride in floats: + 16 bytes, so 16 lanes reading 16 bytes at the
+                                                             // same offset of 16 different rows hit 64 different banks
+    __shared__ __attribute__((aligned(16))) float rows_lds[64 * ROWF];      // 17 KiB: six of these workgroups fit a CU
     __shared__ unsigned long long keys[BF3_CAND];
     __shared__ unsigned long long win[64], sorted[64];
-    __shared__ float xq[256];
-    __shared__ int s_n;
+    __shared__ __attribute__((aligned(16))) float xq[256];
     const int64_t r = blockIdx.x;
     const int lane = mf_lane();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // everything the wave needs first, in ONE round trip: the query, the overflow counters, its 16 bytes (two lane halves x
+    // BF3_SLOTS rows) of every scan workgroup's candidate block
+    static_assert(BF3_SLOTS == 2, "one 16-byte load = the two lane halves of a block");
     for (int i = lane; i < p.d; i += 64) xq[i] = p.q[r * p.d + i];
-    if (lane == 0) s_n = 0;
-    __syncthreads();
-    // gather the lane-private lists of every chunk: list j = (chunk, half)
-    bool overflow = false;
-    const int nl = p.nchunk * 2;
-    // (nchunk <= 128: at most four lists per lane; their heads -- the count and the first three rows -- in one trip)
-    uint4 head[4];
+    const int novf = p.ovf_cnt[r];
+    bool overflow = p.ovf[r] != 0 || novf > BF3_OVF;
+    int n = 0;
+    for (int j0 = 0; j0 < p.nlists; j0 += 64 * 4) {          // four 16-byte loads in flight per lane (256 blocks: one trip)
+        uint4 v4[4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = jj * 64 + lane;
-        head[jj] = uint4{0u, 0u, 0u, 0u};
-        if (j < nl) head[jj] = *reinterpret_cast<const uint4*>(p.lists + (((int64_t)(j >> 1) * p.Qp + r) * 2 + (j & 1)) * BF3_LIST);
-    }
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = j0 + jj * 64 + lane;                 // block j: {half 0 slots, half 1 slots}
+            v4[jj] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (j < p.nlists) v4[jj] = *reinterpret_cast<const uint4*>(p.cand + (((int64_t)j * p.Qp + r) * 2) * BF3_SLOTS);
+        }
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = jj * 64 + lane;
-        const int cnt = (int)head[jj].x;
-        if (cnt > BF3_LCAP) overflow = true;
-        const int take = min(cnt, BF3_LCAP);
-        int at = 0;
-        if (take > 0) at = atomicAdd(&s_n, take);
-        const uint32_t* src = p.lists + (((int64_t)(j >> 1) * p.Qp + r) * 2 + (j & 1)) * BF3_LIST;
-        for (int e = 0; e < take; ++e) {
-            const uint32_t row = e == 0 ? head[jj].y : e == 1 ? head[jj].z : e == 2 ? head[jj].w : src[1 + e];
-            if (at + e < BF3_CAND) keys[at + e] = (unsigned long long)row;     // (row ids for now)
+        for (int jj = 0; jj < 4; ++jj) {
+            const uint32_t w4[4] = {v4[jj].x, v4[jj].z, v4[jj].y, v4[jj].w};      // (slots fill from the front: first slots first)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool ok = w4[t] != 0xFFFFFFFFu;
+                const unsigned long long bal = __ballot(ok);
+                if (!bal) continue;
+                const int at = n + __popcll(bal & below);
+                if (ok && at < BF3_CAND) keys[at] = (unsigned long long)w4[t];    // (row ids for now)
+                n += __popcll(bal);
+            }
         }
     }
+    for (int i0 = 0; i0 < min(novf, BF3_OVF); i0 += 64) {
+        const bool ok = i0 + lane < novf;
+        const uint32_t row = ok ? p.ovf_list[r * BF3_OVF + i0 + lane] : 0u;
+        const unsigned long long bal = __ballot(ok);
+        const int at = n + __popcll(bal & below);
+        if (ok && at < BF3_CAND) keys[at] = (unsigned long long)row;
+        n += __popcll(bal);
+    }
+    overflow = overflow || n > BF3_CAND;
+    if (p.dbg && lane == 0) { atomicAdd(p.dbg, (unsigned long long)n); atomicAdd(p.dbg + 1, 1ull); }
     __syncthreads();
-    int n = s_n;
-    overflow = __any(overflow) || n > BF3_CAND;
     int m;
     if (!overflow) {
-        // exact rescoring: one candidate per lane and round
-        for (int i = lane; i < n; i += 64) {
-            const unsigned row = (unsigned)keys[i];
-            const float s = bf3_exact_dot<D>(xq, p.items + (int64_t)row * D);
-            keys[i] = mf_key_retrieval(s, row);
+        // Exact rescoring, 64 candidates a round.  The rows are fetched by the WAVE -- D/4 lanes per row, whole 512-byte rows
+        // per half-wave instruction -- into LDS, then every lane runs the canonical chain over ITS candidate's row from there
+        // (one row per lane straight from memory meant 64 cache lines per load instruction and each line fetched four times:
+        // 6.7 us per round).  A candidate on the query's exclusion list gets no key (the scan does not look at exclusions).
+        constexpr int LPR = CH / 4, RPI = 64 / LPR;          // lanes per row chunk (256 bytes), rows per load instruction
+        const uint32_t* xrow = p.exclW ? p.exclW + r * p.NTp : nullptr;
+        for (int base = 0; base < n && !(p.abl & 8); base += 64) {
+            const bool have = base + lane < n;
+            const unsigned row = have ? (unsigned)keys[base + lane] : 0u;
+            bool ex = false;
+            if (have && xrow) ex = (xrow[row >> 5] >> (row & 31)) & 1u;
+            const float* row_l = rows_lds + lane * ROWF;
+            float acc = 0.f;
+#pragma unroll
+            for (int c0 = 0; c0 < D; c0 += CH) {
+                f32x4 ld[64 / RPI];
+#pragma unroll
+                for (int it = 0; it < 64 / RPI; ++it) {
+                    const int sel = it * RPI + lane / LPR;
+                    ld[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (base + sel < n) ld[it] = *reinterpret_cast<const f32x4*>(p.items + (int64_t)(unsigned)keys[base + sel] * D + c0 + 4 * (lane % LPR));
+                }
+                if (c0) __syncthreads();                   // (the previous chunk has been consumed by every lane)
+#pragma unroll
+                for (int it = 0; it < 64 / RPI; ++it)
+                    *reinterpret_cast<f32x4*>(rows_lds + (it * RPI + lane / LPR) * ROWF + 4 * (lane % LPR)) = ld[it];
+                __syncthreads();
+#pragma unroll 4
+                for (int g = 0; g < CH; g += 8) {            // k order of mf_dot_chain
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(row_l + g), b = *reinterpret_cast<const f32x4*>(row_l + g + 4);
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(xq + c0 + g), xb = *reinterpret_cast<const f32x4*>(xq + c0 + g + 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc = __builtin_fmaf(xa[t], a[t], acc);
+                        acc = __builtin_fmaf(xb[t], b[t], acc);
+                    }
+                }
+            }
+            __syncthreads();
+            if (have) keys[base + lane] = ex ? 0ull : mf_key_retrieval(acc, row);
         }
         __syncthreads();
-        if (n <= 64) m = mf_row_topk<1>(keys, n, p.k, win, sorted);
+        if (p.abl & 16) m = 0;
+        else if (n <= 64) m = mf_row_topk<1>(keys, n, p.k, win, sorted);
         else if (n <= 256) m = mf_row_topk<4>(keys, n, p.k, win, sorted);
         else m = mf_row_topk<BF3_CAND / 64>(keys, n, p.k, win, sorted);
     } else {
         // the whole catalog by the exact chain, 64 rows a round; the winners so far ride along in win[]
-        const unsigned long long below = (1ull << lane) - 1ull;
         int carry = 0;
         for (int64_t base = 0; base < p.N; base += 64) {
             const int64_t row = base + lane;
             unsigned long long v0 = 0ull;
             if (row < p.N) {
-                const bool ex = p.exclW && ((p.exclW[r * p.NT + (row >> 5)] >> (row & 31)) & 1u);
+                const bool ex = p.exclW && ((p.exclW[r * p.NTp + (row >> 5)] >> (row & 31)) & 1u);
                 if (!ex) v0 = mf_key_retrieval(bf3_exact_dot<D>(xq, p.items + row * D), (unsigned)row);
             }
             const unsigned long long v1 = lane < carry ? win[lane] : 0ull;
@@ -613,24 +709,32 @@ __global__ __launch_bounds__(64) void bf3_final_kernel(Bf3Final p) {
     }
 }
 
-// one workgroup per query: its exclusion list -> its row of bit words, through an LDS window (no memset, no global atomics)
+// Prep, one workgroup per (padded) query: its bf16 fragments in MFMA operand order (zeros for padding queries), its
+// candidate counters, and -- with exclusion lists -- its row of bit words, through an LDS window (no memset, no global atomics)
 static constexpr int BF3_EXCL_WIN = 8192;       // words per window (262,144 catalog rows)
-__global__ __launch_bounds__(256) void bf3_excl_rows_kernel(const int64_t* __restrict__ excl_off, const int64_t* __restrict__ excl_idx,
-                                                            int64_t idx_base, int64_t N, int NT, uint32_t* __restrict__ exclW,
-                                                            const float* __restrict__ q, int d, bf16x8* __restrict__ xfrag) {
+__global__ __launch_bounds__(256) void bf3_prep_kernel(const int64_t* __restrict__ excl_off, const int64_t* __restrict__ excl_idx,
+                                                       int64_t idx_base, int64_t Q, int64_t N, int NT, int NTp,
+                                                       uint32_t* __restrict__ exclW, const float* __restrict__ q, int d,
+                                                       bf16x8* __restrict__ xfrag, int32_t* __restrict__ ovf_cnt, int32_t* __restrict__ ovf) {
     __shared__ uint32_t win[BF3_EXCL_WIN];
     const int64_t r = blockIdx.x;
-    // this query's bf16 fragments in MFMA operand order (lane (c, h) of tile r / 32, step s: k = 16 s + 8 h .. + 7)
+    const bool real = r < Q;
+    // lane (c, h) of query tile r / 32, step s: k = 16 s + 8 h .. + 7
     if ((int)threadIdx.x < d / 8) {
         const int s = threadIdx.x >> 1, h = threadIdx.x & 1;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(q + r * d + 16 * s + 8 * h);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(q + r * d + 16 * s + 8 * h + 4);
-        xfrag[((r >> 5) * (d / 16) + s) * 64 + h * 32 + (r & 31)] =
-            bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+        bf16x8 f = {};
+        if (real) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(q + r * d + 16 * s + 8 * h);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(q + r * d + 16 * s + 8 * h + 4);
+            f = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+        }
+        xfrag[((r >> 5) * (d / 16) + s) * 64 + h * 32 + (r & 31)] = f;
     }
-    const int64_t e0 = excl_off[r], e1 = excl_off[r + 1];
-    for (int w0 = 0; w0 < NT; w0 += BF3_EXCL_WIN) {
-        const int nw = min(BF3_EXCL_WIN, NT - w0);
+    if (threadIdx.x == 0) { ovf_cnt[r] = 0; ovf[r] = 0; }
+    if (!exclW) return;
+    const int64_t e0 = real && excl_off ? excl_off[r] : 0, e1 = real && excl_off ? excl_off[r + 1] : 0;
+    for (int w0 = 0; w0 < NTp; w0 += BF3_EXCL_WIN) {
+        const int nw = min(BF3_EXCL_WIN, NTp - w0);
         for (int i = threadIdx.x; i < nw; i += 256) win[i] = 0u;
         __syncthreads();
         for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
@@ -639,47 +743,52 @@ __global__ __launch_bounds__(256) void bf3_excl_rows_kernel(const int64_t* __res
             if (y >= 0 && y < N && wd >= 0 && wd < nw) atomicOr(&win[wd], 1u << (y & 31));
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < nw; i += 256) exclW[r * NT + w0 + i] = win[i];
+        for (int i = threadIdx.x; i < nw; i += 256) exclW[r * NTp + w0 + i] = win[i];
         __syncthreads();
     }
+    (void)NT;
 }
 
-template <int D, int ST, int XT, bool EXCL, int PASS>
-static void bf3_launch_scan(const Bf3Plan& pl, const Bf3Scan& sp, hipStream_t s) {
-    auto fn = bf3_scan_kernel<D, ST, XT, EXCL, PASS>;
-    const int bytes = Bf3Lds<D, ST, XT, EXCL>::BYTES;
+template <int D, int XT, bool EXCL, int PASS>
+static void bf3_launch_scan(int nwg, int gy, const Bf3Scan& sp, hipStream_t s) {
+    auto fn = bf3_scan_kernel<D, XT, EXCL, PASS>;
+    const int bytes = Bf3Lds<D, XT>::BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;
     }
-    fn<<<dim3((unsigned)pl.nchunk, (unsigned)pl.gy), 256, bytes, s>>>(sp);
+    fn<<<dim3((unsigned)nwg, (unsigned)gy), 64 * BF3_WAVES, bytes, s>>>(sp);
 }
-template <int D, int ST, int XT>
-static void bf3_run_xt(const Bf3Ws& w, const Bf3Scan& sp, bool excl, int k, const float* q, const float* ymax2, hipStream_t s) {
-    if (excl) bf3_launch_scan<D, ST, XT, true, 0>(w.plan, sp, s); else bf3_launch_scan<D, ST, XT, false, 0>(w.plan, sp, s);
-    bf3_bound_kernel<<<dim3((unsigned)sp.Q), 64, 0, s>>>(w.gmax, w.plan.nvals, k, q, D, ymax2, w.thr);
-    if (excl) bf3_launch_scan<D, ST, XT, true, 1>(w.plan, sp, s); else bf3_launch_scan<D, ST, XT, false, 1>(w.plan, sp, s);
+template <int D, int XT>
+static void bf3_run_xt(const Bf3Ws& w, Bf3Scan sp, bool excl, int k, const float* q, const float* ymax2, hipStream_t s) {
+    const Bf3Plan& pl = w.plan;
+    sp.bs = pl.bs; sp.bpc = pl.bpc_seed; sp.nvb = pl.nvb_seed;
+    if (excl) bf3_launch_scan<D, XT, true, 0>(pl.nwg_seed, pl.gy, sp, s); else bf3_launch_scan<D, XT, false, 0>(pl.nwg_seed, pl.gy, sp, s);
+    bf3_bound_kernel<<<dim3((unsigned)sp.Q), 64, 0, s>>>(w.gmax, pl.nvals, k, q, D, ymax2, w.thr);
+    sp.bs = 1; sp.bpc = pl.bpc; sp.nvb = pl.nblk;
+    bf3_launch_scan<D, XT, false, 1>(pl.nwg, pl.gy, sp, s);      // (exclusions are applied to the candidates, by the final kernel)
 }
-template <int D, int ST>
+template <int D>
 static void bf3_run(const Bf3Ws& w, const Bf3Scan& sp, bool excl, int k, const float* q, const float* ymax2, hipStream_t s) {
-    if (w.plan.XT == 2) {
-        if constexpr (D <= 128) bf3_run_xt<D, ST, 2>(w, sp, excl, k, q, ymax2, s);
-    } else {
-        bf3_run_xt<D, ST, 1>(w, sp, excl, k, q, ymax2, s);
-    }
+    if (w.plan.XT == 1) bf3_run_xt<D, 1>(w, sp, excl, k, q, ymax2, s);
+    else bf3_run_xt<D, (D >= 256 ? 2 : 4)>(w, sp, excl, k, q, ymax2, s);
 }
 
-#ifdef BF3_PROBE
-extern "C" void mf_probe_bf3(unsigned long long* out16, int reset) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(bf3_dbg), 16 * 8);
-    if (reset) {
-        unsigned long long z[16] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(bf3_dbg), z, 16 * 8);
+// lab: device counters of the final kernel (candidates gathered, queries); tools/lab/bf3_probe.py
+static unsigned long long* g_bf3_dbg = nullptr;
+extern "C" int mf_probe_bf3_candidates(unsigned long long* out2, int enable) {
+    static unsigned long long* buf = nullptr;
+    if (!buf) {
+        if (hipMalloc(reinterpret_cast<void**>(&buf), 16) != hipSuccess) return -1;
+        (void)hipMemset(buf, 0, 16);
     }
+    (void)hipDeviceSynchronize();
+    if (out2) (void)hipMemcpy(out2, buf, 16, hipMemcpyDeviceToHost);
+    (void)hipMemset(buf, 0, 16);
+    g_bf3_dbg = enable ? buf : nullptr;          // counting costs two contended atomics per query: off while timing
+    return 0;
 }
-#endif
 
 extern "C" int mf_topk_bf3(const float* q, int64_t Q, const float* items, const void* index, int64_t N, int d, int k,
                            const int64_t* excl_off, const int64_t* excl_idx, int64_t idx_base, void* ws, size_t ws_bytes,
@@ -688,29 +797,32 @@ extern "C" int mf_topk_bf3(const float* q, int64_t Q, const float* items, const 
         return mf_set_error(MF_EINVAL, "mf_topk_bf3: bad argument");
     if (k <= 0 || k > 64) return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: k = %d outside 1..64", k);
     if (d != 64 && d != 128 && d != 256) return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: embedding width %d not in {64,128,256}", d);
-    if (N >= (1ll << 31) || idx_base < 0 || idx_base + N > (1ll << 32))
-        return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: item indices must fit 32 bits");
+    if (N >= (1ll << 28) || idx_base < 0 || idx_base + N > (1ll << 32))
+        return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: item indices must fit 32 bits (and a shard 2^28 rows)");
     if ((excl_off == nullptr) != (excl_idx == nullptr)) return mf_set_error(MF_EINVAL, "mf_topk_bf3: excl_off/excl_idx mismatch");
     // geometry limits first (host arithmetic only: nothing below this point may run for an unsupported shape)
     const Bf3Plan plan = bf3_plan(Q, N, d);
-    if ((uint64_t)plan.upc * plan.ST * 32 * d * 2 > MF_SRD_MAX_BYTES) return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: chunk beyond 4 GiB");
-    // exclusion words are staged through a 32-bit buffer descriptor based at a workgroup's first query: its 128 XT query
-    // rows of NT words must fit (NT < ~4 M tiles: 134 M catalog rows per shard)
-    if (excl_off && ((uint64_t)plan.NT * (uint64_t)(128 * plan.XT) + 64u) * 4u > MF_SRD_MAX_BYTES)
+    const uint64_t span_tiles = (uint64_t)plan.bpc * BF3_BLOCK, span_seed = (uint64_t)plan.bpc_seed * plan.bs * BF3_BLOCK;
+    if ((span_tiles > span_seed ? span_tiles : span_seed) * 32 * d * 2 > MF_SRD_MAX_BYTES) return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: chunk beyond 4 GiB");
+    // exclusion words are staged through a 32-bit buffer descriptor based at a workgroup's first query: its 32 XT xw query
+    // rows of NTp words must fit (NT < ~4 M tiles at 256 queries per workgroup: 134 M catalog rows per shard)
+    if (excl_off && ((uint64_t)plan.NTp * (uint64_t)(32 * plan.XT * plan.xw) + 64u) * 4u > MF_SRD_MAX_BYTES)
         return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: exclusion words of one query block beyond 4 GiB (use mf_topk)");
     if (ws_bytes < mf_topk_bf3_ws_bytes(Q, N, d, k)) return mf_set_error(MF_ENOSPC, "mf_topk_bf3: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Bf3Ws w = bf3_ws(ws, Q, N, d);
     Bf3Index ix = bf3_index(const_cast<void*>(index), N, d);
     const bool excl = excl_off != nullptr;
-    if (excl) bf3_excl_rows_kernel<<<dim3((unsigned)Q), 256, 0, s>>>(excl_off, excl_idx, idx_base, N, w.plan.NT, w.exclW, q, d, w.xfrag);
-    Bf3Scan sp{q, Q, w.plan.Qp, ix.plane, N, w.plan.NT, w.plan.upc, w.plan.gpc, w.plan.nvals, w.exclW, w.gmax, w.thr, w.xfrag, w.lists,
-               getenv("MF_BF3_ABL") ? atoi(getenv("MF_BF3_ABL")) : 0};
     MF_TIMED("topk_bf3", s, {
-        if (d == 64) bf3_run<64, 2>(w, sp, excl, k, q, ix.ymax2, s);
-        else if (d == 128) bf3_run<128, 2>(w, sp, excl, k, q, ix.ymax2, s);
-        else bf3_run<256, 1>(w, sp, excl, k, q, ix.ymax2, s);
-        Bf3Final fp{q, items, N, d, k, w.plan.nchunk, w.plan.NT, w.plan.Qp, w.lists, excl ? w.exclW : nullptr, idx_base, out_scores, out_idx};
+        bf3_prep_kernel<<<dim3((unsigned)w.plan.Qp), 256, 0, s>>>(excl_off, excl_idx, idx_base, Q, N, w.plan.NT, w.plan.NTp,
+                                                                  excl ? w.exclW : nullptr, q, d, w.xfrag, w.ovf_cnt, w.ovf);
+        Bf3Scan sp{Q, w.plan.Qp, ix.plane, N, w.plan.NT, w.plan.NTp, w.plan.nblk, 1, 1, 1, w.plan.xw, w.plan.nvals, w.exclW, w.gmax,
+                   w.thr, w.xfrag, w.cand, w.ovf_list, w.ovf_cnt, w.ovf, getenv("MF_BF3_ABL") ? atoi(getenv("MF_BF3_ABL")) : 0};
+        if (d == 64) bf3_run<64>(w, sp, excl, k, q, ix.ymax2, s);
+        else if (d == 128) bf3_run<128>(w, sp, excl, k, q, ix.ymax2, s);
+        else bf3_run<256>(w, sp, excl, k, q, ix.ymax2, s);
+        Bf3Final fp{q, items, N, d, k, w.plan.NT, w.plan.NTp, w.plan.Qp, w.plan.nwg * (BF3_WAVES / w.plan.xw), w.cand, w.ovf_list, w.ovf_cnt, w.ovf,
+                    excl ? w.exclW : nullptr, idx_base, out_scores, out_idx, sp.abl, g_bf3_dbg};
         if (d == 64) bf3_final_kernel<64><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
         else if (d == 128) bf3_final_kernel<128><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
         else bf3_final_kernel<256><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
