@@ -482,6 +482,30 @@ def topk_small_leg(mf, lib, index, device, dim: int, rank: int) -> dict:
     return out
 
 
+def small_step_leg(mf, device, bsz: int, kw: dict) -> dict:
+    batches, _ = make_batches(8, bsz, seed=1000, device=device)
+    cfg = mf.models.ModelConfig(num_users=NUM_USERS, num_items=NUM_ITEMS, hidden_size=DIM)
+    torch.manual_seed(0)
+    towers = mf.models.init_towers(cfg, device=device)
+    opt = mf.optim.RowAdam(list(towers.parameters()), lr=1e-4)
+    fn = getattr(mf.losses, kw["loss"])(num_negatives=kw["num_negatives"], sigma=1.0)
+    step = mf.fused.FusedSmallStep(towers, opt, fn)
+    for i in range(20):
+        step(batches[i % 8])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(200):
+        step(batches[i % 8])
+    e1.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 200
+    assert step.fallback_steps == 0
+    return {"one_launch_ms_per_step": round(wall * 1e3, 4), "one_launch_device_ms_per_step": round(e0.elapsed_time(e1) / 200, 4),
+            "one_launch_pairs_per_s": round(bsz / wall, 1), "one_launch_kernel": "step_small_kernel (mf_step_small)"}
+
+
 def spawn_ranks(args) -> int:
     """``--gpus N`` without a launcher: start the N ranks as fresh children of this (GPU-untouched) process."""
     import socket
@@ -780,6 +804,10 @@ def main() -> None:
                             "eager_ms_per_step": round(eager["ms_per_step"], 4), "graph_ms_per_step": round(graphed["ms_per_step"], 4),
                             "eager_pairs_per_s": round(eager["pairs_per_s"], 1), "graph_pairs_per_s": round(graphed["pairs_per_s"], 1)}
             del eager, graphed
+            if kw.get("num_negatives"):
+                # the same step in ONE launch (mf_step_small: bit-identical tables): device time per step from events around 200
+                # launches, wall time of the eager loop, and one hipGraph replay per step
+                extras[name].update(small_step_leg(mf, device, bsz, kw))
         torch.cuda.empty_cache()
 
     # --------------------------------------------------------------------- CPU leg ----

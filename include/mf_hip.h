@@ -199,6 +199,24 @@ int mf_update_adam(float* table, float* exp_avg, float* exp_avg_sq, int64_t n_ro
                    const int64_t* step_dev, float lr, float beta1, float beta2, float eps,
                    float weight_decay, void* ws, size_t ws_bytes, mf_stream_t stream);
 
+/* -------------------------------------------------- the default step in one launch ---
+ * The reference trains with BATCH_SIZE = 32 pairs (xfmr_rec/params.py:18), PairwiseHingeLoss and 4 mined negatives
+ * (xfmr_rec/lightning.py:38-39): a step of ~0.5 MFLOP that the multi-kernel path spends in launch latency.  mf_step_small
+ * runs the WHOLE training step -- mf_gather_rows of both towers, mf_loss_fwd (all kinds of kind_mask into out_losses[7]),
+ * mf_loss_bwd of `kind` with upstream gradient 1, mf_update_sgd / mf_update_adam of both tables -- in ONE workgroup and one
+ * launch, for B <= 128 pairs, N <= 256 columns and a mined loss (0 < num_negatives <= 64 < N).  Results (losses, both
+ * tables, Adam moments) are bit-identical to that sequence of calls.  Positives: padded pos_idx[B, P], or -- pos_off != NULL --
+ * CSR lists indexed by user_ids (see mf_loss_fwd_csr).  adam = 0: SGD (lr, weight_decay); else lazy row-wise AdamW with the
+ * global step by value or from step_dev.  MF_ENOTSUP for shapes / losses outside that range (callers fall back). */
+size_t mf_step_small_ws_bytes(int d);
+int mf_step_small(float* user_table, float* user_m, float* user_v, int64_t num_users, float* item_table, float* item_m,
+                  float* item_v, int64_t num_items, int d, int normalize, const int64_t* user_ids, const int64_t* item_ids,
+                  const void* target, int target_i64, const int64_t* pos_idx, int P, const int64_t* pos_off,
+                  const int64_t* pos_items, int64_t pos_users, int64_t B, int64_t N, int kind, int kind_mask, int num_negatives,
+                  float sigma, float margin, const float* logq, int64_t logq_rows, int adam, int64_t step, const int64_t* step_dev,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, void* ws, size_t ws_bytes, float* out_losses,
+                  mf_stream_t stream);
+
 /* --------------------------------------------------------------- retrieval ---
  * Replaces `ItemProcessor.search` (xfmr_rec/data/lightning.py:237-259; LanceDB
  * cosine ANN with prefilter) by EXACT brute-force top-k over the indexed item

@@ -9,7 +9,7 @@ The directory name has a hyphen (fixed by the project layout), so import it with
 ``importlib.import_module("matrix-factorization-torch_amd")`` or through the
 ``mf_torch_amd`` alias module at the repository root.
 """
-from . import _lib, data, distributed, graph, lightning, losses, models, optim, params, retrieval  # noqa: F401
+from . import _lib, data, distributed, fused, graph, lightning, losses, models, optim, params, retrieval  # noqa: F401
 from ._lib import MfHipError, build  # noqa: F401
 
-__all__ = ["data", "distributed", "graph", "lightning", "losses", "models", "optim", "params", "retrieval", "MfHipError", "build"]
+__all__ = ["data", "distributed", "fused", "graph", "lightning", "losses", "models", "optim", "params", "retrieval", "MfHipError", "build"]

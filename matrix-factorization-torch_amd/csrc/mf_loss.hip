@@ -18,15 +18,9 @@
 #include <type_traits>
 
 #include "mf_common.h"
+#include "mf_loss_math.h"
 #include "mf_select.h"
 #include "mf_stream.h"
-
-static constexpr int NSTAT = 8;  // cnt, A(contrastive), mx, se, H, Hc, Lg, Ls
-enum { ST_CNT = 0, ST_A = 1, ST_MX = 2, ST_SE = 3, ST_H = 4, ST_HC = 5, ST_LG = 6, ST_LS = 7 };
-enum { NEED_CONTR = 1, NEED_LSE = 2, NEED_HINGE = 4, NEED_LOGI = 8 };
-enum { G_EXP = 0, G_STEP = 1, G_SIGM = 2 };
-static constexpr int KSEL_MAX = 64;
-static constexpr int HITS_PLANES = 2;      // planes of the users' hit bit-vectors (= HITS_MAX_SPLIT, mask build)
 
 static int need_flags(int kind_mask) {
     int f = 0;
@@ -527,45 +521,6 @@ struct FwdParams {
     uint32_t aux_mask, aux_nv, aux_lq, aux_bytes;
 };
 
-struct RowStats {
-    float cnt, A, mx, se, H, Hc, Lg, Ls;
-};
-
-__device__ __forceinline__ void stats_init(RowStats& s) {
-    s.cnt = s.A = s.se = s.H = s.Hc = s.Lg = s.Ls = 0.f;
-    s.mx = -FLT_MAX;
-}
-__device__ __forceinline__ void lse_merge(float& mx, float& se, float mx2, float se2) {
-    const float m = fmaxf(mx, mx2);
-    se = se * __expf(mx - m) + se2 * __expf(mx2 - m);
-    mx = m;
-}
-// softplus(x) and sigmoid(x) from one exp:  e = exp(-|x|)
-__device__ __forceinline__ void softplus_sigmoid(float x, float& sp, float& sg) {
-    const float e = __expf(-fabsf(x));
-    const float r = 1.f / (1.f + e);
-    sp = fmaxf(x, 0.f) + __logf(1.f + e);
-    sg = x >= 0.f ? r : e * r;
-}
-// accumulate one valid logit into the per-row statistics (mx handled by caller)
-__device__ __forceinline__ void stats_add(RowStats& s, int need, float L, float sm, float lii, float margin) {
-    s.cnt += 1.f;
-    if (need & NEED_CONTR) s.A += fmaxf(L + sm, 0.f);
-    if (need & (NEED_HINGE | NEED_LOGI)) {
-        const float x = (L - lii) + margin;
-        if (need & NEED_HINGE) {
-            s.H += fmaxf(x, 0.f);
-            s.Hc += x > 0.f ? 1.f : 0.f;
-        }
-        if (need & NEED_LOGI) {
-            float sp, sg;
-            softplus_sigmoid(x, sp, sg);
-            s.Lg += sp;
-            s.Ls += sg;
-        }
-    }
-}
-
 // Workgroup = 4 waves x 32 users; item tiles arrive through a 2-slot LDS ring filled by LDS-DMA, together with
 // their mask words, norms and -logQ (a separate 4-deep ring of side-input slots).  The loop is software-pipelined
 // inside each wave: the 64 MFMAs of tile t+1 are issued in the same basic block as the (branch-free) statistics of
@@ -779,30 +734,6 @@ static void launch_fwd(int need, dim3 grid, const FwdParams& fp, hipStream_t s) 
     }
 }
 
-// Per-row coefficients of dloss/dL for loss `kind`, WITHOUT the upstream gradient (the backward kernels scale
-// by grad_out[0]):  rowc[0] = a, rowc[1] = b, rowc[2] = coefG, rowc[3] = gdiag  with, for element (i, j),
-//   G'_ij = coefG_i * g((L_ij - a_i) + b_i)   (valid negatives),  G'_ii = gdiag_i,
-//   du_i = sum_j G'_ij (v_j - u_i),  dv_j = sum_i G'_ij (u_i - v_j).
-__device__ __forceinline__ void rowc_row(int kind, float t, float s, float l, float cnt, float mx, float se, float hc,
-                                         float ls, float sigma, float margin, float& a, float& b, float& cg, float& gd) {
-    a = b = cg = gd = 0.f;
-    const float base = sigma * s * fabsf(t);
-    const float den = cnt + 1e-10f;
-    switch (kind) {
-        case MF_ALIGNMENT: gd = -base; break;
-        case MF_CONTRASTIVE: b = s * margin; cg = base / den; break;
-        case MF_ALIGNMENT_CONTRASTIVE: b = s * margin; cg = base / den; gd = -base; break;
-        case MF_INFONCE: {
-            const float m2 = fmaxf(mx, l);
-            const float lse = m2 + __logf(se * __expf(mx - m2) + __expf(l - m2));
-            a = lse; cg = base; gd = base * (__expf(l - lse) - 1.f);
-        } break;
-        case MF_MINE: a = cnt > 0.f ? mx + __logf(se) : 0.f; cg = cnt > 0.f ? base : 0.f; gd = -base; break;
-        case MF_PAIRWISE_HINGE: a = l; b = margin; cg = base / den; gd = -cg * hc; break;
-        case MF_PAIRWISE_LOGISTIC: a = l; b = margin; cg = base / den; gd = -cg * ls; break;
-    }
-}
-
 // The tail of the forward in ONE launch: merge the item-range splits of the row statistics in split
 // order (nsplit = 0: `stats` is already final), evaluate the seven per-row losses, and sum them over
 // the batch in a fixed order: in-block tree, then the last workgroup to finish (ticket) adds the
@@ -840,24 +771,7 @@ __global__ __launch_bounds__(64) void finish_kernel(const float* __restrict__ pa
         }
     }
     float o[MF_NUM_KINDS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (i < B) {
-        const float t = target[i], w = fabsf(t), l = lii[i];
-        const float cnt = acc[ST_CNT], mx = acc[ST_MX], se = acc[ST_SE];
-        const float den = cnt + 1e-10f;
-        const float align = dii[i] * t * sigma;                       // losses.py:164-170
-        const float contr = (acc[ST_A] / den) * w;                    // losses.py:172-193
-        const float m2 = fmaxf(mx, l);
-        const float se2 = se * __expf(mx - m2) + __expf(l - m2);
-        const float lse_all = m2 + __logf(se2);                       // diagonal forced in, :213-215
-        const float lse_neg = cnt > 0.f ? mx + __logf(se) : -INFINITY;  // :242 (no valid negative: -inf)
-        o[MF_ALIGNMENT] = align;
-        o[MF_CONTRASTIVE] = contr;
-        o[MF_ALIGNMENT_CONTRASTIVE] = align + contr;
-        o[MF_INFONCE] = (lse_all - l) * w;
-        o[MF_MINE] = (-l + lse_neg) * w;
-        o[MF_PAIRWISE_HINGE] = (acc[ST_H] / den) * w;
-        o[MF_PAIRWISE_LOGISTIC] = (acc[ST_LG] / den) * w;
-    }
+    if (i < B) row_losses(acc, target[i], lii[i], dii[i], sigma, o);
     if (rowc_kind >= 0 && i < Bp) {       // the backward's row coefficients of the one trained loss (MF_LOSS_ROWC)
         float a = 0.f, b = 0.f, cg = 0.f, gd = 0.f;
         if (i < B) rowc_row(rowc_kind, target[i], sgn[i], lii[i], acc[ST_CNT], acc[ST_MX], acc[ST_SE], acc[ST_HC], acc[ST_LS],
@@ -1057,22 +971,6 @@ __global__ __launch_bounds__(256) void rowc_kernel(const float* __restrict__ sta
         rowc_row(kind, target[i], sgn[i], lii[i], stats[ST_CNT * Bp + i], stats[ST_MX * Bp + i], stats[ST_SE * Bp + i],
                  stats[ST_HC * Bp + i], stats[ST_LS * Bp + i], sigma, margin, a, b, cg, gd);
     rowc[0 * Bp + i] = a; rowc[1 * Bp + i] = b; rowc[2 * Bp + i] = cg; rowc[3 * Bp + i] = gd;
-}
-
-static int gmode_of(int kind) {
-    switch (kind) {
-        case MF_INFONCE: case MF_MINE: return G_EXP;
-        case MF_PAIRWISE_LOGISTIC: return G_SIGM;
-        default: return G_STEP;
-    }
-}
-
-__device__ __forceinline__ float g_of(int gmode, float x) {
-    if (gmode == G_EXP) return __expf(x);
-    if (gmode == G_STEP) return x > 0.f ? 1.f : 0.f;
-    const float e = __expf(-fabsf(x));
-    const float r = 1.f / (1.f + e);
-    return x >= 0.f ? r : e * r;
 }
 
 // The forward stashes the MASKED logits (-inf where the column is not a valid negative) of every
@@ -1324,8 +1222,6 @@ __global__ __launch_bounds__(256) void diag_bwd_kernel(const float* __restrict__
 // the fp32 atomics this replaces), and it is rounded to fp32 once, by dv_fix_to_f32_kernel.  A contribution is
 // exact on the 2^-40 grid down to |x| = 2^-17 and off by <= 2^-41 below; |sum| < 2^23.  Lane c of a 32-lane row
 // group owns the features c, c + 32, ..: one atomic instruction covers 256 contiguous bytes of a row.
-static constexpr float DV_FIX_SCALE = 1099511627776.0f;      // 2^40
-
 template <int D>
 __global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                         const float* __restrict__ rowc, const int32_t* __restrict__ sel,

@@ -1,0 +1,431 @@
+// mf_step_small.hip -- the reference's DEFAULT training step in ONE launch (gfx950).
+//
+// The reference trains with 32 pairs per step (BATCH_SIZE, xfmr_rec/params.py:18), PairwiseHingeLoss and 4 mined negatives
+// (xfmr_rec/lightning.py:38-39).  At that size the multi-kernel path -- 11+ launches of a few microseconds each -- is bound
+// by launch latency, not by work: ~0.5 MFLOP per step.  Here ONE workgroup of 1024 threads runs the whole step on
+// B <= 128 pairs: tower gathers (L2-normalised rows) -> chain norms, diagonal -> hit masks -> all B x N logits and the
+// mined negatives -> the row statistics, the seven losses and their batch sums -> dU / dV of the trained loss -> the
+// sparse SGD / row-Adam update of both tables.  Phases are separated by workgroup barriers; the intermediate rows live in
+// the caller's workspace (L1 / L2 resident).
+//
+// Bit-identical to the multi-kernel path (tests/test_gpu_module.py: torch.equal on both tables after several steps): every
+// floating-point expression is the one the batch kernels evaluate, in the same order -- the gather's shuffle tree, the
+// k-ordered fmaf chains (== the fp32 MFMA element), mined_rows_kernel's wave-reduced logits, finish_kernel's block sums,
+// mined_bwd_kernel's per-feature sums and fixed-point dV, and for the update the very same workgroup body
+// (fused_update_body, mf_update.h) bucket after bucket.  Integer work (masks, the exact top-k of unique 64-bit keys) is
+// free to take the short way.
+//
+// Scope: mining on (0 < num_negatives <= 64 < N); the in-batch dense path (num_negatives = 0) stays with the MFMA sweeps.
+#include "mf_common.h"
+#include "mf_loss_math.h"
+#include "mf_update.h"
+
+static constexpr int SS_MAXB = 128, SS_MAXN = 256, SS_THREADS = FUSED_THREADS, SS_HT = 512;
+static_assert(SS_THREADS == 1024, "the update body runs with FUSED_THREADS threads");
+
+struct StepSmallWs {
+    float *u, *v, *nu, *nv, *lii, *dii, *sgn, *tgt, *nlogq, *stats, *rowc, *sel_L, *du, *dv, *partial, *blockpart;
+    int32_t *sel, *sel_cnt;
+    long long* dvfix;
+    unsigned long long *gk0, *gk1;
+    size_t total;
+};
+static StepSmallWs step_small_ws(void* base, int d) {
+    MfArena a(base);
+    StepSmallWs w;
+    const size_t Bp = SS_MAXB, Np = SS_MAXN;
+    w.u = a.take<float>(Bp * d); w.v = a.take<float>(Np * d);
+    w.nu = a.take<float>(Bp); w.nv = a.take<float>(Np);
+    w.lii = a.take<float>(Bp); w.dii = a.take<float>(Bp); w.sgn = a.take<float>(Bp); w.tgt = a.take<float>(Bp);
+    w.nlogq = a.take<float>(Np);
+    w.stats = a.take<float>((size_t)NSTAT * Bp); w.rowc = a.take<float>(4 * Bp);
+    w.sel_L = a.take<float>(Bp * KSEL_MAX); w.sel = a.take<int32_t>(Bp * KSEL_MAX); w.sel_cnt = a.take<int32_t>(Bp);
+    w.du = a.take<float>(Bp * d); w.dv = a.take<float>(Np * d);
+    w.dvfix = a.take<long long>(Np * d);
+    w.partial = a.take<float>(Np * d);
+    w.blockpart = a.take<float>((size_t)MF_NUM_KINDS * 4);
+    w.gk0 = a.take<unsigned long long>(Np); w.gk1 = a.take<unsigned long long>(Np);
+    w.total = a.used();
+    return w;
+}
+extern "C" size_t mf_step_small_ws_bytes(int d) { return mf_width_ok(d) ? step_small_ws(nullptr, d).total : 0; }
+
+struct StepSmallParams {
+    float *ut, *um, *uv; long long n_users;
+    float *it, *im, *iv; long long n_items;
+    const int64_t *user_ids, *item_ids;
+    const void* target; int target_i64;
+    const int64_t* pos_idx; int P;
+    const int64_t *pos_off, *pos_items; long long pos_users;
+    int B, N, kind, kind_mask, k, normalize;
+    float sigma, margin;
+    const float* logq; long long logq_rows;
+    AdamHyper hp;
+    StepSmallWs w;
+    float* out;
+};
+
+__device__ __forceinline__ unsigned long long ss_shfl_or_u64(unsigned long long x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x |= mf_shfl_xor_u64(x, m);
+    return x;
+}
+
+template <int D, bool ADAM>
+__global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];                 // FUSED_CAP * 8 bytes (the update body's key list)
+    const int tid = threadIdx.x, lane = mf_lane(), wave = tid >> 6;
+    const int B = p.B, N = p.N;
+    constexpr int Bp = SS_MAXB;
+    const StepSmallWs& w = p.w;
+    // LDS before the updates: the batch's item ids -> column sets (a 512-slot table), and the users' hit masks
+    long long* hkey = reinterpret_cast<long long*>(smem);                       // [SS_HT]
+    unsigned long long* hset = reinterpret_cast<unsigned long long*>(smem + SS_HT * 8);          // [SS_HT][4]: columns carrying the id
+    unsigned long long* hitm = hset + SS_HT * 4;                                                 // [SS_MAXB][4]: bit j = column j is NOT a valid negative
+
+    // ---- 1. tower forward: gathered rows, L2-normalised (gather_rows_kernel: D/4 lanes per row, the same shuffle tree)
+    {
+        constexpr int LPR = D / 4, RPW = 64 / LPR;
+        for (int r0 = 0; r0 < B + N; r0 += (SS_THREADS / 64) * RPW) {
+            const int r = r0 + wave * RPW + lane / LPR;
+            const int c = lane % LPR;
+            const bool valid = r < B + N;
+            const bool is_u = r < B;
+            const float* table = is_u ? p.ut : p.it;
+            const long long n_rows = is_u ? p.n_users : p.n_items;
+            long long row = valid ? (is_u ? p.user_ids[r] : p.item_ids[r - B]) : 0;
+            const bool in_range = row >= 0 && row < n_rows;
+            row = in_range ? row : 0;
+            f32x4 x = reinterpret_cast<const f32x4*>(table + row * D)[c];
+            if (!in_range) x = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.normalize) {
+                float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+                ss = mf_group_sum(ss, LPR);
+                const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+                x = x * inv;
+            }
+            if (valid) reinterpret_cast<f32x4*>((is_u ? w.u + (size_t)r * D : w.v + (size_t)(r - B) * D))[c] = x;
+        }
+        // the id table while the rows land
+        for (int e = tid; e < SS_HT; e += SS_THREADS) {
+            hkey[e] = (long long)0x8080808080808080ull;
+            hset[4 * e] = hset[4 * e + 1] = hset[4 * e + 2] = hset[4 * e + 3] = 0ull;
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. chain norms of both operands, the diagonal, -logq (prep_kernel); the batch's ids into the table
+    if (tid < SS_MAXN) {
+        const int i = tid;
+        const bool hv = i < N, hu = i < B;
+        float nvv = 0.f, nuu = 0.f, dot = 0.f;
+        if (hv) {
+            const f32x4* pv = reinterpret_cast<const f32x4*>(w.v + (size_t)i * D);
+            const f32x4* pu = reinterpret_cast<const f32x4*>(w.u + (size_t)(hu ? i : 0) * D);
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int g = 0; g < D / 8; ++g) {                    // k order of mf_dot_chain
+                const f32x4 a = pv[2 * g], b = pv[2 * g + 1];
+                const f32x4 xa = hu ? pu[2 * g] : zero4, xb = hu ? pu[2 * g + 1] : zero4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    nvv = __builtin_fmaf(a[t], a[t], nvv);  nvv = __builtin_fmaf(b[t], b[t], nvv);
+                    nuu = __builtin_fmaf(xa[t], xa[t], nuu); nuu = __builtin_fmaf(xb[t], xb[t], nuu);
+                    dot = __builtin_fmaf(xa[t], a[t], dot);  dot = __builtin_fmaf(xb[t], b[t], dot);
+                }
+            }
+        }
+        w.nv[i] = nvv;
+        float lq = 0.f;
+        if (p.logq && hv) {
+            if (p.logq_rows > 0) {
+                const long long id = p.item_ids[i];
+                lq = (id >= 0 && id < p.logq_rows) ? p.logq[id] : 0.f;
+            } else {
+                lq = p.logq[i];
+            }
+        }
+        w.nlogq[i] = -lq;
+        if (i < Bp) {
+            float l = 0.f, dd = 0.f, sg = 0.f, tg = 0.f;
+            if (hu) {
+                tg = p.target_i64 ? (float)static_cast<const int64_t*>(p.target)[i] : static_cast<const float*>(p.target)[i];
+                sg = mf_sign(tg);
+                dd = mf_half_sqdist(nuu, nvv, dot);
+                l = mf_logit(nuu, nvv, dot, sg, p.sigma, lq);
+            }
+            w.nu[i] = nuu; w.lii[i] = l; w.dii[i] = dd; w.sgn[i] = sg; w.tgt[i] = tg;
+        }
+        if (hv) {                                                // column i joins the set of its item id
+            const long long key = p.item_ids[i];
+            unsigned h = ((((unsigned)key * 2654435761u) ^ ((unsigned)((unsigned long long)key >> 32) * 40503u)) >> 5) & (SS_HT - 1);
+            for (;;) {
+                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&hkey[h]), 0x8080808080808080ull, (unsigned long long)key);
+                if (old == 0x8080808080808080ull || old == (unsigned long long)key) break;
+                h = (h + 1) & (SS_HT - 1);
+            }
+            atomicOr(&hset[4 * h + (i >> 6)], 1ull << (i & 63));
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. hit masks (negative_masks, losses.py:92-110): one wave per user ORs the column sets of its positives and of its own item
+    for (int i = wave; i < B; i += SS_THREADS / 64) {
+        const int64_t* list = nullptr;
+        int len = 0;
+        if (p.pos_off) {
+            const long long uidx = p.user_ids[i];
+            if (uidx >= 0 && uidx < p.pos_users) {
+                const long long o = p.pos_off[uidx];
+                list = p.pos_items + o;
+                const long long ln = p.pos_off[uidx + 1] - o;
+                len = (int)(ln < 0 ? 0 : (ln > 0x7FFFFFF ? 0x7FFFFFF : ln));
+            }
+        } else if (p.P > 0) {
+            list = p.pos_idx + (size_t)i * p.P;
+            len = p.P;
+        }
+        unsigned long long m4[4] = {0ull, 0ull, 0ull, 0ull};
+        for (int t = lane; t < len + 1; t += 64) {
+            const long long key = t < len ? list[t] : p.item_ids[i];
+            unsigned h = ((((unsigned)key * 2654435761u) ^ ((unsigned)((unsigned long long)key >> 32) * 40503u)) >> 5) & (SS_HT - 1);
+            for (;;) {
+                const long long sv = hkey[h];
+                if (sv == key) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) m4[q] |= hset[4 * h + q];
+                    break;
+                }
+                if (sv == (long long)0x8080808080808080ull) break;
+                h = (h + 1) & (SS_HT - 1);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned long long m = ss_shfl_or_u64(m4[q]);
+            // padding columns (>= N) are never negatives
+            const int lo = 64 * q;
+            if (N < lo + 64) m |= N <= lo ? ~0ull : (~0ull << (N - lo));
+            if (lane == 0) hitm[4 * i + q] = m;
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. logits of every (user, column) -> mining keys -> the k best, in order; then (mined_rows_kernel) the selected
+    //         negatives' logits by the wave-reduced dot and the row statistics in selection order.  One wave per user.
+    const int need = ((p.kind_mask & ((1 << MF_CONTRASTIVE) | (1 << MF_ALIGNMENT_CONTRASTIVE))) ? NEED_CONTR : 0) |
+                     ((p.kind_mask & ((1 << MF_INFONCE) | (1 << MF_MINE))) ? NEED_LSE : 0) |
+                     ((p.kind_mask & (1 << MF_PAIRWISE_HINGE)) ? NEED_HINGE : 0) | ((p.kind_mask & (1 << MF_PAIRWISE_LOGISTIC)) ? NEED_LOGI : 0);
+    for (int i = wave; i < Bp; i += SS_THREADS / 64) {
+        RowStats st;
+        stats_init(st);
+        if (i < B) {
+            const float nu_i = w.nu[i], s_i = w.sgn[i], l = w.lii[i];
+            // the chains of this lane's (up to four) columns side by side: the user's row is wave-uniform (broadcast loads)
+            unsigned long long keyv[SS_MAXN / 64];
+            float dotv[SS_MAXN / 64];
+            bool live[SS_MAXN / 64];
+#pragma unroll
+            for (int q = 0; q < SS_MAXN / 64; ++q) {
+                const int j = lane + 64 * q;
+                live[q] = j < N && !((hitm[4 * i + q] >> lane) & 1ull);
+                dotv[q] = 0.f;
+            }
+            const f32x4* pu = reinterpret_cast<const f32x4*>(w.u + (size_t)i * D);
+#pragma unroll 1
+            for (int g = 0; g < D / 8; ++g) {                    // k order of mf_dot_chain
+                const f32x4 xa = pu[2 * g], xb = pu[2 * g + 1];
+#pragma unroll
+                for (int q = 0; q < SS_MAXN / 64; ++q) {
+                    if (64 * q >= N) continue;                   // (wave-uniform)
+                    const f32x4* pv = reinterpret_cast<const f32x4*>(w.v + (size_t)(live[q] ? lane + 64 * q : 0) * D);
+                    const f32x4 a = pv[2 * g], b = pv[2 * g + 1];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        dotv[q] = __builtin_fmaf(xa[t], a[t], dotv[q]);
+                        dotv[q] = __builtin_fmaf(xb[t], b[t], dotv[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SS_MAXN / 64; ++q) {
+                const int j = lane + 64 * q;
+                keyv[q] = 0ull;
+                if (live[q]) {
+                    const float L = mf_logit(nu_i, w.nv[j], dotv[q], s_i, p.sigma, -w.nlogq[j]);
+                    keyv[q] = mf_key_mining(L - l, (unsigned)j);
+                }
+            }
+            int m = 0, mysel = 0;
+            for (int t = 0; t < p.k; ++t) {                      // unique keys: k rounds of "largest remaining"
+                unsigned long long loc = 0ull;
+#pragma unroll
+                for (int q = 0; q < SS_MAXN / 64; ++q) loc = keyv[q] > loc ? keyv[q] : loc;
+                const unsigned long long best = mf_wave_max_u64(loc);
+                if (best == 0ull) break;
+#pragma unroll
+                for (int q = 0; q < SS_MAXN / 64; ++q)
+                    if (keyv[q] == best) keyv[q] = 0ull;
+                if (lane == t) mysel = (int)mf_key_mining_col(best);        // (k <= 64: lane t keeps the t-th selected column)
+                ++m;
+            }
+            if (lane < m) w.sel[i * KSEL_MAX + lane] = mysel;
+            if (lane == 0) w.sel_cnt[i] = m;
+            const float sm = s_i * p.margin;
+            const int d4 = D / 4;
+            f32x4 ur = {0.f, 0.f, 0.f, 0.f};
+            if (lane < d4) ur = reinterpret_cast<const f32x4*>(w.u + (size_t)i * D)[lane];
+            for (int t = 0; t < m; ++t) {
+                const int j = __shfl(mysel, t, 64);
+                float part = 0.f;
+                if (lane < d4) {
+                    const f32x4 vr = reinterpret_cast<const f32x4*>(w.v + (size_t)j * D)[lane];
+                    part = ur[0] * vr[0] + ur[1] * vr[1] + ur[2] * vr[2] + ur[3] * vr[3];
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                const float L = mf_logit(nu_i, w.nv[j], part, s_i, p.sigma, -w.nlogq[j]);
+                if (lane == 0) w.sel_L[i * KSEL_MAX + t] = L;
+                stats_add(st, need, L, sm, l, p.margin);
+                if (need & NEED_LSE) lse_merge(st.mx, st.se, L, 1.f);
+            }
+        }
+        if (lane == 0) {
+            float* o = w.stats + i;
+            o[ST_CNT * Bp] = st.cnt; o[ST_A * Bp] = st.A; o[ST_MX * Bp] = st.mx; o[ST_SE * Bp] = st.se;
+            o[ST_H * Bp] = st.H; o[ST_HC * Bp] = st.Hc; o[ST_LG * Bp] = st.Lg; o[ST_LS * Bp] = st.Ls;
+        }
+    }
+    __syncthreads();
+
+    // ---- 5. the seven row losses, the trained loss's backward coefficients, the batch sums (finish_kernel: 64-row blocks, xor trees)
+    if (wave < Bp / 64) {
+        const int i = wave * 64 + lane;
+        float acc[NSTAT];
+        for (int s = 0; s < NSTAT; ++s) acc[s] = w.stats[s * Bp + i];
+        float o[MF_NUM_KINDS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (i < B) row_losses(acc, w.tgt[i], w.lii[i], w.dii[i], p.sigma, o);
+        {
+            float a = 0.f, b = 0.f, cg = 0.f, gd = 0.f;
+            if (i < B) rowc_row(p.kind, w.tgt[i], w.sgn[i], w.lii[i], acc[ST_CNT], acc[ST_MX], acc[ST_SE], acc[ST_HC], acc[ST_LS],
+                                p.sigma, p.margin, a, b, cg, gd);
+            w.rowc[i] = a; w.rowc[Bp + i] = b; w.rowc[2 * Bp + i] = cg; w.rowc[3 * Bp + i] = gd;
+        }
+        for (int k = 0; k < MF_NUM_KINDS; ++k) {
+            float v = o[k];
+            for (int ww = 32; ww > 0; ww >>= 1) v += __shfl_xor(v, ww, 64);
+            if (lane == 0) w.blockpart[k * (Bp / 64) + wave] = v;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int k = 0; k < MF_NUM_KINDS; ++k) {
+            float t = lane < Bp / 64 ? w.blockpart[k * (Bp / 64) + lane] : 0.f;
+            for (int ww = 32; ww > 0; ww >>= 1) t += __shfl_xor(t, ww, 64);
+            if (lane == 0) p.out[k] = ((p.kind_mask >> k) & 1) ? t : 0.f;
+        }
+    }
+
+    // ---- 6. backward of the trained loss (mined_bwd_kernel): du in registers in selection order, dv as fixed-point integer sums
+    for (int e = tid; e < N * D; e += SS_THREADS) w.dvfix[e] = 0ll;
+    __syncthreads();
+    {
+        constexpr int LPR = 32, NE = D / LPR;
+        const int gmode = gmode_of(p.kind);
+        for (int t0 = 0; t0 < B * LPR; t0 += SS_THREADS) {
+            const int t = t0 + tid;
+            const int i = t / LPR, c = t % LPR;
+            if (i >= B) continue;
+            const float go = 1.0f;                               // the upstream gradient of loss.backward(): one
+            const float a = w.rowc[i], b = w.rowc[Bp + i], cg = go * w.rowc[2 * Bp + i], gd = go * w.rowc[3 * Bp + i];
+            float ui[NE], acc[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { ui[e] = w.u[(size_t)i * D + c + LPR * e]; acc[e] = 0.f; }
+            const int n = w.sel_cnt[i];
+            for (int s = -1; s < n; ++s) {
+                int j;
+                float g;
+                if (s < 0) { j = i; g = gd; }
+                else { j = w.sel[i * KSEL_MAX + s]; g = cg * g_of(gmode, (w.sel_L[i * KSEL_MAX + s] - a) + b); }
+                unsigned long long* o = reinterpret_cast<unsigned long long*>(w.dvfix) + (size_t)j * D + c;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const float vj = w.v[(size_t)j * D + c + LPR * e];
+                    acc[e] += g * (vj - ui[e]);
+                    const float dvj = g * (ui[e] - vj);
+                    const long long q = (long long)__builtin_rintf(fminf(fmaxf(dvj, -8388607.f), 8388607.f) * DV_FIX_SCALE);
+                    atomicAdd(o + LPR * e, (unsigned long long)q);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) w.du[(size_t)i * D + c + LPR * e] = acc[e];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < N * D; e += SS_THREADS) w.dv[e] = (float)((double)w.dvfix[e] * (1.0 / 1099511627776.0));
+    __syncthreads();
+
+    // ---- 7. the sparse updates: the one-launch update's own workgroup body, bucket after bucket (item table first, like the
+    //         optimisers' parameter order does not matter: the two tables are disjoint)
+    unsigned long long* lk = reinterpret_cast<unsigned long long*>(smem);
+    {
+        const int bits = fused_bucket_bits(N);
+        FusedUpdateParams fp{p.it, p.im, p.iv, p.n_items, reinterpret_cast<const long long*>(p.item_ids), N, bits, w.dv, w.partial, w.gk0, w.gk1,
+                             p.normalize, p.hp};
+        for (unsigned b = 0; b < (1u << bits); ++b) fused_update_body<D, ADAM, 4>(fp, b, lk);
+    }
+    {
+        const int bits = fused_bucket_bits(B);
+        FusedUpdateParams fp{p.ut, p.um, p.uv, p.n_users, reinterpret_cast<const long long*>(p.user_ids), B, bits, w.du, w.partial, w.gk0, w.gk1,
+                             p.normalize, p.hp};
+        for (unsigned b = 0; b < (1u << bits); ++b) fused_update_body<D, ADAM, 4>(fp, b, lk);
+    }
+}
+
+extern "C" int mf_step_small(float* user_table, float* user_m, float* user_v, int64_t num_users, float* item_table, float* item_m,
+                             float* item_v, int64_t num_items, int d, int normalize, const int64_t* user_ids, const int64_t* item_ids,
+                             const void* target, int target_i64, const int64_t* pos_idx, int P, const int64_t* pos_off,
+                             const int64_t* pos_items, int64_t pos_users, int64_t B, int64_t N, int kind, int kind_mask,
+                             int num_negatives, float sigma, float margin, const float* logq, int64_t logq_rows, int adam, int64_t step,
+                             const int64_t* step_dev, float lr, float beta1, float beta2, float eps, float weight_decay, void* ws,
+                             size_t ws_bytes, float* out_losses, mf_stream_t stream) {
+    if (!user_table || !item_table || !user_ids || !item_ids || !target || !ws || !out_losses || num_users <= 0 || num_items <= 0)
+        return mf_set_error(MF_EINVAL, "mf_step_small: bad argument");
+    if (!mf_width_ok(d)) return mf_set_error(MF_EINVAL, "mf_step_small: embedding width %d not in {32,64,128,256}", d);
+    if (B <= 0 || N < B || B > SS_MAXB || N > SS_MAXN)
+        return mf_set_error(MF_ENOTSUP, "mf_step_small: needs 0 < B <= %d and B <= N <= %d (B=%lld N=%lld)", SS_MAXB, SS_MAXN, (long long)B, (long long)N);
+    if (!(num_negatives > 0 && num_negatives < N && num_negatives <= KSEL_MAX))
+        return mf_set_error(MF_ENOTSUP, "mf_step_small: the one-launch step covers mined losses (0 < num_negatives <= %d < N)", KSEL_MAX);
+    if (kind < 0 || kind >= MF_NUM_KINDS || !((kind_mask >> kind) & 1)) return mf_set_error(MF_EINVAL, "mf_step_small: kind / kind_mask");
+    if (adam && (!user_m || !user_v || !item_m || !item_v || (!step_dev && step < 1))) return mf_set_error(MF_EINVAL, "mf_step_small: Adam state / step");
+    if (pos_off ? (!pos_items || pos_users <= 0) : (P < 0 || (P > 0 && !pos_idx))) return mf_set_error(MF_EINVAL, "mf_step_small: bad positives");
+    if (logq && logq_rows <= 0 && false) return MF_EINVAL;
+    if (ws_bytes < mf_step_small_ws_bytes(d)) return mf_set_error(MF_ENOSPC, "mf_step_small: workspace too small");
+    StepSmallParams sp{};
+    sp.ut = user_table; sp.um = user_m; sp.uv = user_v; sp.n_users = num_users;
+    sp.it = item_table; sp.im = item_m; sp.iv = item_v; sp.n_items = num_items;
+    sp.user_ids = user_ids; sp.item_ids = item_ids; sp.target = target; sp.target_i64 = target_i64;
+    sp.pos_idx = pos_idx; sp.P = P; sp.pos_off = pos_off; sp.pos_items = pos_items; sp.pos_users = pos_users;
+    sp.B = (int)B; sp.N = (int)N; sp.kind = kind; sp.kind_mask = kind_mask; sp.k = num_negatives; sp.normalize = normalize;
+    sp.sigma = sigma; sp.margin = margin; sp.logq = logq; sp.logq_rows = logq_rows;
+    sp.hp = adam ? AdamHyper{lr, beta1, beta2, eps, weight_decay, (long long)step, reinterpret_cast<const long long*>(step_dev),
+                             log((double)beta1), log((double)beta2)}
+                 : AdamHyper{lr, 0.f, 0.f, 0.f, weight_decay, 1, nullptr, 0.0, 0.0};
+    sp.w = step_small_ws(ws, d);
+    sp.out = out_losses;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MF_DISPATCH_D(d, {
+        if (adam) {
+            auto fn = step_small_kernel<D, true>;
+            static bool set = false;
+            if (!set) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_CAP * 8); set = true; }
+            fn<<<dim3(1), SS_THREADS, FUSED_CAP * 8, s>>>(sp);
+        } else {
+            auto fn = step_small_kernel<D, false>;
+            static bool set = false;
+            if (!set) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_CAP * 8); set = true; }
+            fn<<<dim3(1), SS_THREADS, FUSED_CAP * 8, s>>>(sp);
+        }
+    });
+    return mf_check_launch("mf_step_small");
+}

@@ -320,3 +320,72 @@ def test_captured_step_replays_bit_identically(mf, cfg):
             assert opt_e.state[pe]["step"] == opt_g.state[pg]["step"] == 6
     with pytest.raises(ValueError, match="ONE shape"):
         captured({**batches[1], "user": batches[1]["user"][:-1]})
+
+
+@pytest.mark.parametrize("cfg", [("adam", "PairwiseHingeLoss", 4, 32, 32, False, False), ("adam", "PairwiseHingeLoss", 4, 32, 128, True, False),
+                                 ("sgd", "InfomationNoiseContrastiveEstimationLoss", 8, 128, 64, False, True),
+                                 ("adam", "MutualInformationNeuralEstimationLoss", 64, 100, 256, True, True),
+                                 ("sgd", "ContrastiveLoss", 1, 5, 32, False, False)],
+                         ids=lambda c: "-".join(map(str, c)))
+def test_fused_small_step_is_bit_identical_to_the_multi_kernel_step(mf, cfg):
+    """The reference's default step (B = 32, PairwiseHinge, 4 mined negatives, AdamW; xfmr_rec/params.py:18, lightning.py:38-39)
+    in ONE launch (mf_step_small) against the ordinary sequence gather -> loss -> backward -> update: the same loss value and --
+    torch.equal -- the same tables and Adam moments after three steps, with duplicate users / items inside a batch, zero and
+    negative targets, padded and CSR positives, a logQ table, k = 1 and k = 64, B up to 128."""
+    opt_name, kind, k, b, d, use_csr, use_logq = cfg
+    n_users, n_items = 60, 90
+    g = torch.Generator().manual_seed(b * 7 + d)
+
+    def make():
+        towers = mf.models.init_towers(mf.models.ModelConfig(num_users=n_users, num_items=n_items, hidden_size=d), device=DEV)
+        opt = mf.optim.RowAdam(towers.parameters(), lr=0.05) if opt_name == "adam" else mf.optim.SparseSGD(towers.parameters(), lr=0.1, weight_decay=0.01)
+        return towers, opt
+
+    ta, oa = make()
+    tb, ob = make()
+    with torch.no_grad():
+        for name in ("user", "item"):
+            tb[name].weight.copy_(ta[name].weight)
+    fn = getattr(mf.losses, kind)(num_negatives=k, sigma=1.3, margin=0.7)
+    logq = (torch.rand(n_items, generator=g) - 0.5).to(DEV) if use_logq else None
+    lists = [torch.randperm(n_items - 1, generator=g)[: int(ln)] + 1 for ln in torch.randint(0, 12, (n_users,), generator=g)]
+    off = torch.tensor([0] + list(np.cumsum([x.numel() for x in lists])), dtype=torch.int64).to(DEV)
+    flat = torch.cat(lists).to(DEV)
+    fused = mf.fused.FusedSmallStep(tb, ob, fn, logq_table=logq)
+    one = torch.ones((), device=DEV)
+    for step in range(3):
+        user = torch.randint(1, n_users, (b,), generator=g)
+        item = torch.randint(1, n_items, (2 * b,), generator=g)
+        if b >= 4:
+            user[1] = user[0]
+            item[b] = item[0]                     # a sampled negative that is row 0's positive
+            item[2] = item[3]
+        target = torch.randint(-1, 6, (b,), generator=g)
+        batch = {"user": user.to(DEV), "item": item.to(DEV), "target": target.to(DEV)}
+        if use_csr:
+            batch["pos_csr"] = (batch["user"], off, flat)
+        else:
+            pos = torch.randint(0, n_items, (b, 6), generator=g)
+            pos[:, 0] = item[:b]
+            batch["pos"] = pos.to(DEV)
+        # the ordinary path
+        u = ta["user"](batch["user"])
+        v = ta["item"](batch["item"])
+        want = fn(u, v, batch["target"], item_idx=batch["item"], pos_idx=batch.get("pos"), logq_table=logq, pos_csr=batch.get("pos_csr"))
+        want.backward(one)
+        oa.step()
+        got = fused(batch)
+        assert fused.fused_steps == step + 1 and fused.fallback_steps == 0
+        assert torch.equal(got, want.detach()) or (torch.isinf(got) and torch.isinf(want)), (step, float(got), float(want))
+        for name in ("user", "item"):
+            assert torch.equal(ta[name].weight, tb[name].weight), (step, name, float((ta[name].weight - tb[name].weight).abs().max()))
+            if opt_name == "adam":
+                sa, sb = oa.state[ta[name].weight], ob.state[tb[name].weight]
+                assert sa["step"] == sb["step"]
+                assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+    # shapes outside the one-launch range fall back to the ordinary path, with the same results
+    big = {"user": torch.randint(1, n_users, (200,), generator=g).to(DEV), "item": torch.randint(1, n_items, (400,), generator=g).to(DEV),
+           "target": torch.ones(200, device=DEV), "pos": torch.zeros(200, 1, dtype=torch.int64, device=DEV)}
+    assert not fused.supported(big)
+    fused(big)
+    assert fused.fallback_steps == 1
