@@ -106,25 +106,114 @@ __device__ __forceinline__ f32x16 mf_tile_scores(const RowFrag<D>& y, const RowF
 // accumulator register e of lane half h  ->  tile row
 __device__ __forceinline__ constexpr int mf_acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
-__device__ __forceinline__ float mf_shfl_xor32(float x) { return __shfl_xor(x, 32, 64); }
-__device__ __forceinline__ unsigned mf_shfl_xor32u(unsigned x) { return (unsigned)__shfl_xor((int)x, 32, 64); }
+// ---- lane exchanges without the LDS crossbar ---------------------------------------------------------------------
+// `__shfl_xor` is a ds_bpermute_b32: an LDS-pipe round trip (~100+ cycles, and contended by every other wave's LDS work)
+// per step of a reduction.  The value of lane (l ^ M) comes as well from the VALU's own cross-lane paths: DPP within a
+// row of 16 (quad_perm for M = 1 and 2, two bank-masked row shifts for M = 4, row_ror:8 for M = 8) and gfx950's
+// v_permlane16_swap / v_permlane32_swap between rows.  The same value moves, so a butterfly built on these has the
+// result of the `__shfl_xor` one bit for bit.  Like every cross-lane operation: call it with the whole wave active.
+template <int CTRL, int BANKS = 0xF>
+__device__ __forceinline__ unsigned mf_dpp_u32(unsigned old, unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)x, CTRL, 0xF, BANKS, false);
+}
+// {rows of the lower half twice, rows of the upper half twice} (M = 32; M = 16: of each half's lower / upper row).  The second
+// operand goes through an empty asm: given the SAME value twice, this compiler (ROCm 7.2 clang) folds the two results into
+// one register (`v_add_f32 v1, v7, v7` for r[0] + r[1]) -- they are different lanes' values
+template <int M>
+__device__ __forceinline__ auto mf_swap_halves(unsigned x) {
+    unsigned y = x;
+    asm volatile("" : "+v"(y));
+    if constexpr (M == 16) return __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    else return __builtin_amdgcn_permlane32_swap(x, y, false, false);
+}
+template <int M>
+__device__ __forceinline__ unsigned mf_xor_lane_u32(unsigned x) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "a single lane bit");
+    if constexpr (M == 1) return mf_dpp_u32<0xB1>(x, x);                                   // quad_perm:[1,0,3,2]
+    else if constexpr (M == 2) return mf_dpp_u32<0x4E>(x, x);                              // quad_perm:[2,3,0,1]
+    else if constexpr (M == 4) return mf_dpp_u32<0x114, 0xA>(mf_dpp_u32<0x104, 0x5>(x, x), x);   // row_shl:4 into lanes with bit 2 clear, row_shr:4 into the others
+    else if constexpr (M == 8) return mf_dpp_u32<0x128>(x, x);                             // row_ror:8
+    else {
+        const auto r = mf_swap_halves<M>(x);                 // the partner's value is the one that is not mine
+        return (threadIdx.x & M) ? r[0] : r[1];
+    }
+}
+template <int M>
+__device__ __forceinline__ float mf_xor_lane(float x) { return __builtin_bit_cast(float, mf_xor_lane_u32<M>(__builtin_bit_cast(unsigned, x))); }
+template <int M>
+__device__ __forceinline__ unsigned long long mf_xor_lane_u64(unsigned long long x) {
+    return ((unsigned long long)mf_xor_lane_u32<M>((unsigned)(x >> 32)) << 32) | mf_xor_lane_u32<M>((unsigned)x);
+}
+// x + (lane ^ M's x): for the two swaps the sum of the two halves is symmetric, no select needed
+template <int M>
+__device__ __forceinline__ float mf_xor_add(float x) {
+    if constexpr (M >= 16) {
+        const auto r = mf_swap_halves<M>(__builtin_bit_cast(unsigned, x));
+        unsigned a = r[0], b = r[1];
+        asm volatile("" : "+v"(a), "+v"(b));       // (see mf_swap_halves: without it the sum comes out as r[0] + r[0])
+        return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    } else {
+        return x + mf_xor_lane<M>(x);
+    }
+}
+// the butterfly 32, 16, .. 1 of `for (m = 32; m; m >>= 1) x += __shfl_xor(x, m)`, from step WIDTH / 2 down
+template <int WIDTH>
+__device__ __forceinline__ float mf_butterfly_sum(float x) {
+    if constexpr (WIDTH >= 64) x = mf_xor_add<32>(x);
+    if constexpr (WIDTH >= 32) x = mf_xor_add<16>(x);
+    if constexpr (WIDTH >= 16) x = mf_xor_add<8>(x);
+    if constexpr (WIDTH >= 8) x = mf_xor_add<4>(x);
+    if constexpr (WIDTH >= 4) x = mf_xor_add<2>(x);
+    if constexpr (WIDTH >= 2) x = mf_xor_add<1>(x);
+    return x;
+}
+__device__ __forceinline__ float mf_wave_sum(float x) { return mf_butterfly_sum<64>(x); }
+__device__ __forceinline__ int mf_wave_sum_int(int x) {
+    x += (int)mf_xor_lane_u32<32>((unsigned)x); x += (int)mf_xor_lane_u32<16>((unsigned)x); x += (int)mf_xor_lane_u32<8>((unsigned)x);
+    x += (int)mf_xor_lane_u32<4>((unsigned)x); x += (int)mf_xor_lane_u32<2>((unsigned)x); x += (int)mf_xor_lane_u32<1>((unsigned)x);
+    return x;
+}
+
+__device__ __forceinline__ float mf_shfl_xor32(float x) { return mf_xor_lane<32>(x); }
+__device__ __forceinline__ unsigned mf_shfl_xor32u(unsigned x) { return mf_xor_lane_u32<32>(x); }
 
 __device__ __forceinline__ unsigned long long mf_shfl_xor_u64(unsigned long long x, int m) {
-    unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(x & 0xFFFFFFFFull), m, 64);
-    unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(x >> 32), m, 64);
-    return ((unsigned long long)hi << 32) | lo;
+    switch (m) {                                   // (a constant at every call site)
+        case 1: return mf_xor_lane_u64<1>(x);
+        case 2: return mf_xor_lane_u64<2>(x);
+        case 4: return mf_xor_lane_u64<4>(x);
+        case 8: return mf_xor_lane_u64<8>(x);
+        case 16: return mf_xor_lane_u64<16>(x);
+        default: return mf_xor_lane_u64<32>(x);
+    }
+}
+template <int M>
+__device__ __forceinline__ unsigned long long mf_xor_max_u64(unsigned long long x) {
+    if constexpr (M >= 16) {
+        const unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+        const auto rl = mf_swap_halves<M>(lo), rh = mf_swap_halves<M>(hi);
+        const unsigned long long a = ((unsigned long long)rh[0] << 32) | rl[0], b = ((unsigned long long)rh[1] << 32) | rl[1];
+        return a > b ? a : b;
+    } else {
+        const unsigned long long o = mf_xor_lane_u64<M>(x);
+        return o > x ? o : x;
+    }
 }
 __device__ __forceinline__ unsigned long long mf_wave_max_u64(unsigned long long x) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        unsigned long long o = mf_shfl_xor_u64(x, m);
-        x = o > x ? o : x;
-    }
+    x = mf_xor_max_u64<32>(x); x = mf_xor_max_u64<16>(x); x = mf_xor_max_u64<8>(x);
+    x = mf_xor_max_u64<4>(x); x = mf_xor_max_u64<2>(x); x = mf_xor_max_u64<1>(x);
     return x;
 }
-__device__ __forceinline__ float mf_group_sum(float x, int width) {  // width: power of two <= 64
-    for (int m = width >> 1; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-    return x;
+__device__ __forceinline__ float mf_group_sum(float x, int width) {  // width: power of two <= 64 (a constant at every call site)
+    switch (width) {
+        case 64: return mf_butterfly_sum<64>(x);
+        case 32: return mf_butterfly_sum<32>(x);
+        case 16: return mf_butterfly_sum<16>(x);
+        case 8: return mf_butterfly_sum<8>(x);
+        case 4: return mf_butterfly_sum<4>(x);
+        case 2: return mf_butterfly_sum<2>(x);
+        default: return x;
+    }
 }
 
 // A zero fill as a KERNEL (16-byte aligned pointer, bytes a multiple of 4): inside a captured hipGraph a memset node

@@ -469,3 +469,48 @@ extern "C" int mf_update_adam(float* table, float* exp_avg, float* exp_avg_sq, i
     return update_common<true>(table, exp_avg, exp_avg_sq, n_rows, d, idx, n, grad, normalized, hp, ws,
                                ws_bytes, stream, "mf_update_adam");
 }
+
+// ---- lab: the DPP / permlane lane exchanges of mf_common.h against the `__shfl_xor` they replace ----------------------
+// (tests/test_gpu_parity.py: every butterfly sum, the 64-bit wave maximum and every single exchange, bit for bit)
+__global__ __launch_bounds__(64) void lane_ops_probe_kernel(const uint32_t* __restrict__ in, unsigned* __restrict__ bad) {
+    const int lane = threadIdx.x;
+    const uint32_t a = in[(size_t)blockIdx.x * 128 + lane], b = in[(size_t)blockIdx.x * 128 + 64 + lane];
+    const float x = __builtin_bit_cast(float, a);
+    auto ref_sum = [&](int width) {
+        float r = x;
+        for (int m = width >> 1; m >= 1; m >>= 1) r += __shfl_xor(r, m, 64);
+        return __builtin_bit_cast(uint32_t, r);
+    };
+    auto note = [&](int op, bool wrong) { if (wrong) atomicAdd(bad + op, 1u); };      // bad[16]: mismatching lanes per operation
+    note(0, ref_sum(64) != __builtin_bit_cast(uint32_t, mf_butterfly_sum<64>(x)));
+    note(1, ref_sum(32) != __builtin_bit_cast(uint32_t, mf_butterfly_sum<32>(x)));
+    note(2, ref_sum(16) != __builtin_bit_cast(uint32_t, mf_butterfly_sum<16>(x)));
+    note(3, ref_sum(8) != __builtin_bit_cast(uint32_t, mf_butterfly_sum<8>(x)));
+    note(4, ref_sum(4) != __builtin_bit_cast(uint32_t, mf_butterfly_sum<4>(x)));
+    note(5, ref_sum(2) != __builtin_bit_cast(uint32_t, mf_butterfly_sum<2>(x)));
+    note(6, (uint32_t)__shfl_xor((int)a, 1, 64) != mf_xor_lane_u32<1>(a));
+    note(7, (uint32_t)__shfl_xor((int)a, 2, 64) != mf_xor_lane_u32<2>(a));
+    note(8, (uint32_t)__shfl_xor((int)a, 4, 64) != mf_xor_lane_u32<4>(a));
+    note(9, (uint32_t)__shfl_xor((int)a, 8, 64) != mf_xor_lane_u32<8>(a));
+    note(10, (uint32_t)__shfl_xor((int)a, 16, 64) != mf_xor_lane_u32<16>(a));
+    note(11, (uint32_t)__shfl_xor((int)a, 32, 64) != mf_xor_lane_u32<32>(a));
+    {
+        const unsigned long long k = ((unsigned long long)a << 32) | b;
+        unsigned long long r = k;
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(r >> 32), m, 64) << 32) |
+                                         (uint32_t)__shfl_xor((int)(uint32_t)r, m, 64);
+            r = o > r ? o : r;
+        }
+        note(12, r != mf_wave_max_u64(k));
+        int s = (int)b;
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        note(13, s != mf_wave_sum_int((int)b));
+    }
+}
+
+extern "C" int mf_probe_lane_ops(const uint32_t* in, int64_t waves, unsigned* mismatches, mf_stream_t stream) {
+    if (!in || !mismatches || waves <= 0 || waves > (1 << 20)) return mf_set_error(MF_EINVAL, "mf_probe_lane_ops: bad argument");
+    lane_ops_probe_kernel<<<dim3((unsigned)waves), 64, 0, static_cast<hipStream_t>(stream)>>>(in, mismatches);
+    return mf_check_launch("mf_probe_lane_ops");
+}

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(HITS_THREADS) void hits_kernel(const int64_t* __res
 // 32 x 32 bit transpose across the 32 lanes of a half-wave: lane i holds row i; five block-swap steps
 template <int J, uint32_t M0>
 __device__ __forceinline__ uint32_t bit_transpose_step(uint32_t w, int lane) {
-    const uint32_t p = (uint32_t)__shfl_xor((int)w, J, 64);
+    const uint32_t p = mf_xor_lane_u32<J>(w);
     return (lane & J) ? ((w & ~M0) | ((p & ~M0) >> J)) : ((w & M0) | ((p & M0) << J));
 }
 __device__ __forceinline__ uint32_t bit_transpose32(uint32_t w, int lane) {
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(64) void finish_kernel(const float* __restrict__ pa
     for (int k = 0; k < MF_NUM_KINDS; ++k) {
         if (i < Bp) rowloss[(int64_t)k * Bp + i] = o[k];
         float v = o[k];
-        for (int w = 32; w > 0; w >>= 1) v += __shfl_xor(v, w, 64);
+        v = mf_wave_sum(v);
         if (lane == 0) blockpart[(int64_t)k * gridDim.x + blockIdx.x] = v;
     }
     // release only (the block sums are in L2 before the ticket moves): a full fence also invalidates the L1, ~1.7 us each;
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(64) void finish_kernel(const float* __restrict__ pa
 #pragma unroll
         for (int k = 0; k < MF_NUM_KINDS; ++k) {
             float t = tot[k];
-            for (int w = 32; w > 0; w >>= 1) t += __shfl_xor(t, w, 64);
+            t = mf_wave_sum(t);
             if (lane == 0) out[k] = ((kind_mask >> k) & 1) ? t : 0.f;   // every entry is written
         }
     }
@@ -932,8 +932,7 @@ __global__ __launch_bounds__(64) void mined_rows_kernel(MinedRowParams p) {
                 const f32x4 vr = reinterpret_cast<const f32x4*>(p.v + j * p.d)[lane];
                 part = ur[0] * vr[0] + ur[1] * vr[1] + ur[2] * vr[2] + ur[3] * vr[3];
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            part = mf_wave_sum(part);
             const float L = mf_logit(nu_i, p.nv[j], part, s_i, p.sigma, -p.nlogq[j]);
             if (lane == 0) p.sel_L[i * KSEL_MAX + t] = L;
             stats_add(st, p.need, L, sm, l, p.margin);

@@ -21,19 +21,25 @@
 #include "mf_update.h"
 
 static constexpr int SS_MAXB = 128, SS_MAXN = 256, SS_THREADS = FUSED_THREADS, SS_HT = 512;
+// dynamic LDS: [0, FUSED_CAP * 8) the update body's key list (before the updates: the id table and the hit masks), then the
+// normalised rows of the batch when they fit (rows padded by 16 bytes: lanes reading the same 16 bytes of 16 different rows
+// hit 64 different banks) -- chains that read them from L2 instead cost a memory round trip per 8 features
+static constexpr int SS_ROWS0 = FUSED_CAP * 8, SS_ROWS_BYTES = 88 * 1024;
 static_assert(SS_THREADS == 1024, "the update body runs with FUSED_THREADS threads");
 
 struct StepSmallWs {
     float *u, *v, *nu, *nv, *lii, *dii, *sgn, *tgt, *nlogq, *stats, *rowc, *sel_L, *du, *dv, *partial, *blockpart;
     int32_t *sel, *sel_cnt;
-    long long* dvfix;
+    float* dots;                     // [SS_MAXB][SS_MAXN + 8] chain products of a batch too large for LDS
     unsigned long long *gk0, *gk1;
+    unsigned long long* stamps;      // [16] at offset 0: s_memrealtime (100 MHz) at the phase boundaries of the last step (tools/lab/small_step_probe.py)
     size_t total;
 };
 static StepSmallWs step_small_ws(void* base, int d) {
     MfArena a(base);
     StepSmallWs w;
     const size_t Bp = SS_MAXB, Np = SS_MAXN;
+    w.stamps = a.take<unsigned long long>(16);
     w.u = a.take<float>(Bp * d); w.v = a.take<float>(Np * d);
     w.nu = a.take<float>(Bp); w.nv = a.take<float>(Np);
     w.lii = a.take<float>(Bp); w.dii = a.take<float>(Bp); w.sgn = a.take<float>(Bp); w.tgt = a.take<float>(Bp);
@@ -41,7 +47,7 @@ static StepSmallWs step_small_ws(void* base, int d) {
     w.stats = a.take<float>((size_t)NSTAT * Bp); w.rowc = a.take<float>(4 * Bp);
     w.sel_L = a.take<float>(Bp * KSEL_MAX); w.sel = a.take<int32_t>(Bp * KSEL_MAX); w.sel_cnt = a.take<int32_t>(Bp);
     w.du = a.take<float>(Bp * d); w.dv = a.take<float>(Np * d);
-    w.dvfix = a.take<long long>(Np * d);
+    w.dots = a.take<float>(Bp * (Np + 8));
     w.partial = a.take<float>(Np * d);
     w.blockpart = a.take<float>((size_t)MF_NUM_KINDS * 4);
     w.gk0 = a.take<unsigned long long>(Np); w.gk1 = a.take<unsigned long long>(Np);
@@ -78,10 +84,38 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
     const int B = p.B, N = p.N;
     constexpr int Bp = SS_MAXB;
     const StepSmallWs& w = p.w;
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (tid == 0) w.stamps[stamp_i] = __builtin_amdgcn_s_memrealtime();
+        ++stamp_i;
+    };
+    stamp();
     // LDS before the updates: the batch's item ids -> column sets (a 512-slot table), and the users' hit masks
     long long* hkey = reinterpret_cast<long long*>(smem);                       // [SS_HT]
     unsigned long long* hset = reinterpret_cast<unsigned long long*>(smem + SS_HT * 8);          // [SS_HT][4]: columns carrying the id
     unsigned long long* hitm = hset + SS_HT * 4;                                                 // [SS_MAXB][4]: bit j = column j is NOT a valid negative
+    // ... and the per-row scalars of the step (norms, diagonal, targets, statistics, backward coefficients), so that no phase
+    // waits on a round trip to L2 for a value another wave of this workgroup has just produced
+    float* fl = reinterpret_cast<float*>(hitm + SS_MAXB * 4);
+    float *nu_l = fl, *lii_l = fl + 128, *dii_l = fl + 256, *sgn_l = fl + 384, *tgt_l = fl + 512, *nv_l = fl + 640, *nlq_l = fl + 896,
+          *stats_l = fl + 1152, *rowc_l = fl + 2176, *bpart_l = fl + 2688;
+    int32_t* cnt_l = reinterpret_cast<int32_t*>(fl + 2720);                     // [SS_MAXB] selected columns per user
+    int32_t* sel_l = cnt_l + SS_MAXB;                                           // [B][k] selected columns, then [B][k] their logits
+    const bool sel_in_lds = (size_t)B * p.k * 8 <= (size_t)(SS_ROWS0 - ((char*)sel_l - smem));
+    int32_t* selp = sel_in_lds ? sel_l : w.sel;
+    float* sel_Lp = sel_in_lds ? reinterpret_cast<float*>(sel_l + (size_t)B * p.k) : w.sel_L;
+    const int sels = sel_in_lds ? p.k : KSEL_MAX;                               // entries per user
+    constexpr int ROWF = D + 4;
+    const bool in_lds = (size_t)(B + N) * ROWF * 4 <= (size_t)SS_ROWS_BYTES;
+    float* rows_lds = reinterpret_cast<float*>(smem + SS_ROWS0);
+    // row r of the batch (users 0 .. B-1, then the N columns): from LDS when the batch fits, else from the workspace copy
+    const float* ubase = in_lds ? rows_lds : w.u;
+    const float* vbase = in_lds ? rows_lds + (size_t)B * ROWF : w.v;
+    const int rstride = in_lds ? ROWF : D;
+    // the chain products of every (user, column): behind the rows when that fits too
+    const int dstride = ((N + 31) & ~31) + 8;                 // (+8: the two half-waves of a tile store land in different banks)
+    const bool dots_in_lds = in_lds && (size_t)(B + N) * ROWF * 4 + (size_t)B * dstride * 4 <= (size_t)SS_ROWS_BYTES;
+    float* dots = dots_in_lds ? rows_lds + (size_t)(B + N) * ROWF : w.dots;
 
     // ---- 1. tower forward: gathered rows, L2-normalised (gather_rows_kernel: D/4 lanes per row, the same shuffle tree)
     {
@@ -104,7 +138,10 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                 const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
                 x = x * inv;
             }
-            if (valid) reinterpret_cast<f32x4*>((is_u ? w.u + (size_t)r * D : w.v + (size_t)(r - B) * D))[c] = x;
+            if (valid) {
+                reinterpret_cast<f32x4*>((is_u ? w.u + (size_t)r * D : w.v + (size_t)(r - B) * D))[c] = x;
+                if (in_lds) reinterpret_cast<f32x4*>(rows_lds + (size_t)r * ROWF)[c] = x;
+            }
         }
         // the id table while the rows land
         for (int e = tid; e < SS_HT; e += SS_THREADS) {
@@ -113,6 +150,7 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
         }
     }
     __syncthreads();
+    stamp();
 
     // ---- 2. chain norms of both operands, the diagonal, -logq (prep_kernel); the batch's ids into the table
     if (tid < SS_MAXN) {
@@ -120,8 +158,8 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
         const bool hv = i < N, hu = i < B;
         float nvv = 0.f, nuu = 0.f, dot = 0.f;
         if (hv) {
-            const f32x4* pv = reinterpret_cast<const f32x4*>(w.v + (size_t)i * D);
-            const f32x4* pu = reinterpret_cast<const f32x4*>(w.u + (size_t)(hu ? i : 0) * D);
+            const f32x4* pv = reinterpret_cast<const f32x4*>(vbase + (size_t)i * rstride);
+            const f32x4* pu = reinterpret_cast<const f32x4*>(ubase + (size_t)(hu ? i : 0) * rstride);
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
             for (int g = 0; g < D / 8; ++g) {                    // k order of mf_dot_chain
@@ -135,7 +173,7 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                 }
             }
         }
-        w.nv[i] = nvv;
+        nv_l[i] = nvv;
         float lq = 0.f;
         if (p.logq && hv) {
             if (p.logq_rows > 0) {
@@ -145,7 +183,7 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                 lq = p.logq[i];
             }
         }
-        w.nlogq[i] = -lq;
+        nlq_l[i] = -lq;
         if (i < Bp) {
             float l = 0.f, dd = 0.f, sg = 0.f, tg = 0.f;
             if (hu) {
@@ -154,7 +192,7 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                 dd = mf_half_sqdist(nuu, nvv, dot);
                 l = mf_logit(nuu, nvv, dot, sg, p.sigma, lq);
             }
-            w.nu[i] = nuu; w.lii[i] = l; w.dii[i] = dd; w.sgn[i] = sg; w.tgt[i] = tg;
+            nu_l[i] = nuu; lii_l[i] = l; dii_l[i] = dd; sgn_l[i] = sg; tgt_l[i] = tg;
         }
         if (hv) {                                                // column i joins the set of its item id
             const long long key = p.item_ids[i];
@@ -168,25 +206,30 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
         }
     }
     __syncthreads();
+    stamp();
 
     // ---- 3. hit masks (negative_masks, losses.py:92-110): one wave per user ORs the column sets of its positives and of its own item
-    for (int i = wave; i < B; i += SS_THREADS / 64) {
+    for (int i0 = 0; i0 < B; i0 += 2 * (SS_THREADS / 64)) {           // a half-wave per user
+        const int i = i0 + 2 * wave + (lane >> 5), l32 = lane & 31;
         const int64_t* list = nullptr;
-        int len = 0;
-        if (p.pos_off) {
-            const long long uidx = p.user_ids[i];
-            if (uidx >= 0 && uidx < p.pos_users) {
-                const long long o = p.pos_off[uidx];
-                list = p.pos_items + o;
-                const long long ln = p.pos_off[uidx + 1] - o;
-                len = (int)(ln < 0 ? 0 : (ln > 0x7FFFFFF ? 0x7FFFFFF : ln));
+        int len = -1;                                                // (no user: nothing to look up, not even an own item)
+        if (i < B) {
+            len = 0;
+            if (p.pos_off) {
+                const long long uidx = p.user_ids[i];
+                if (uidx >= 0 && uidx < p.pos_users) {
+                    const long long o = p.pos_off[uidx];
+                    list = p.pos_items + o;
+                    const long long ln = p.pos_off[uidx + 1] - o;
+                    len = (int)(ln < 0 ? 0 : (ln > 0x7FFFFFF ? 0x7FFFFFF : ln));
+                }
+            } else if (p.P > 0) {
+                list = p.pos_idx + (size_t)i * p.P;
+                len = p.P;
             }
-        } else if (p.P > 0) {
-            list = p.pos_idx + (size_t)i * p.P;
-            len = p.P;
         }
         unsigned long long m4[4] = {0ull, 0ull, 0ull, 0ull};
-        for (int t = lane; t < len + 1; t += 64) {
+        for (int t = l32; t < len + 1; t += 32) {
             const long long key = t < len ? list[t] : p.item_ids[i];
             unsigned h = ((((unsigned)key * 2654435761u) ^ ((unsigned)((unsigned long long)key >> 32) * 40503u)) >> 5) & (SS_HT - 1);
             for (;;) {
@@ -202,60 +245,68 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            unsigned long long m = ss_shfl_or_u64(m4[q]);
+            unsigned long long m = m4[q];
+#pragma unroll
+            for (int sh = 16; sh >= 1; sh >>= 1) m |= mf_shfl_xor_u64(m, sh);      // (within the half-wave)
             // padding columns (>= N) are never negatives
             const int lo = 64 * q;
             if (N < lo + 64) m |= N <= lo ? ~0ull : (~0ull << (N - lo));
-            if (lane == 0) hitm[4 * i + q] = m;
+            if (l32 == 0 && i < B) hitm[4 * i + q] = m;
         }
     }
     __syncthreads();
+    stamp();
 
     // ---- 4. logits of every (user, column) -> mining keys -> the k best, in order; then (mined_rows_kernel) the selected
     //         negatives' logits by the wave-reduced dot and the row statistics in selection order.  One wave per user.
     const int need = ((p.kind_mask & ((1 << MF_CONTRASTIVE) | (1 << MF_ALIGNMENT_CONTRASTIVE))) ? NEED_CONTR : 0) |
                      ((p.kind_mask & ((1 << MF_INFONCE) | (1 << MF_MINE))) ? NEED_LSE : 0) |
                      ((p.kind_mask & (1 << MF_PAIRWISE_HINGE)) ? NEED_HINGE : 0) | ((p.kind_mask & (1 << MF_PAIRWISE_LOGISTIC)) ? NEED_LOGI : 0);
+    {
+        // 32 x 32 tiles of u . v on the matrix core: v_mfma_f32_32x32x2_f32 with a lane pair holding elements 8g + 4h .. + 3
+        // of a row IS the k order of mf_dot_chain (mf_common.h: mf_tile_scores), and one CU's LDS feeds it 32 x less data
+        // than it would feed one FMA chain per lane
+        const int TU = (B + 31) / 32, TN = (N + 31) / 32;
+        const int r = lane & 31, h = lane >> 5;
+        for (int tt = wave; tt < TU * TN; tt += SS_THREADS / 64) {
+            const int tu = tt / TN, tn = tt % TN;
+            const int iu = 32 * tu + r, jv = 32 * tn + r;
+            const f32x4* pa = reinterpret_cast<const f32x4*>(ubase + (size_t)(iu < B ? iu : 0) * rstride + 4 * h);
+            const f32x4* pb = reinterpret_cast<const f32x4*>(vbase + (size_t)(jv < N ? jv : 0) * rstride + 4 * h);
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll 4
+            for (int g = 0; g < D / 8; ++g) {
+                const f32x4 a = pa[2 * g], b = pb[2 * g];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * tu + mf_acc_row(e, h);
+                if (row < B) dots[(size_t)row * dstride + 32 * tn + r] = acc[e];      // (columns >= N: inside the row's padding, never read)
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) w.stamps[9] = __builtin_amdgcn_s_memrealtime();
     for (int i = wave; i < Bp; i += SS_THREADS / 64) {
         RowStats st;
         stats_init(st);
         if (i < B) {
-            const float nu_i = w.nu[i], s_i = w.sgn[i], l = w.lii[i];
-            // the chains of this lane's (up to four) columns side by side: the user's row is wave-uniform (broadcast loads)
+            const float nu_i = nu_l[i], s_i = sgn_l[i], l = lii_l[i];
             unsigned long long keyv[SS_MAXN / 64];
-            float dotv[SS_MAXN / 64];
-            bool live[SS_MAXN / 64];
-#pragma unroll
-            for (int q = 0; q < SS_MAXN / 64; ++q) {
-                const int j = lane + 64 * q;
-                live[q] = j < N && !((hitm[4 * i + q] >> lane) & 1ull);
-                dotv[q] = 0.f;
-            }
-            const f32x4* pu = reinterpret_cast<const f32x4*>(w.u + (size_t)i * D);
-#pragma unroll 1
-            for (int g = 0; g < D / 8; ++g) {                    // k order of mf_dot_chain
-                const f32x4 xa = pu[2 * g], xb = pu[2 * g + 1];
-#pragma unroll
-                for (int q = 0; q < SS_MAXN / 64; ++q) {
-                    if (64 * q >= N) continue;                   // (wave-uniform)
-                    const f32x4* pv = reinterpret_cast<const f32x4*>(w.v + (size_t)(live[q] ? lane + 64 * q : 0) * D);
-                    const f32x4 a = pv[2 * g], b = pv[2 * g + 1];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        dotv[q] = __builtin_fmaf(xa[t], a[t], dotv[q]);
-                        dotv[q] = __builtin_fmaf(xb[t], b[t], dotv[q]);
-                    }
-                }
-            }
 #pragma unroll
             for (int q = 0; q < SS_MAXN / 64; ++q) {
                 const int j = lane + 64 * q;
                 keyv[q] = 0ull;
-                if (live[q]) {
-                    const float L = mf_logit(nu_i, w.nv[j], dotv[q], s_i, p.sigma, -w.nlogq[j]);
+                if (j < N && !((hitm[4 * i + q] >> lane) & 1ull)) {
+                    const float L = mf_logit(nu_i, nv_l[j], dots[(size_t)i * dstride + j], s_i, p.sigma, -nlq_l[j]);
                     keyv[q] = mf_key_mining(L - l, (unsigned)j);
                 }
             }
+            if (tid == 0) w.stamps[10] = __builtin_amdgcn_s_memrealtime();
             int m = 0, mysel = 0;
             for (int t = 0; t < p.k; ++t) {                      // unique keys: k rounds of "largest remaining"
                 unsigned long long loc = 0ull;
@@ -269,101 +320,135 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                 if (lane == t) mysel = (int)mf_key_mining_col(best);        // (k <= 64: lane t keeps the t-th selected column)
                 ++m;
             }
-            if (lane < m) w.sel[i * KSEL_MAX + lane] = mysel;
-            if (lane == 0) w.sel_cnt[i] = m;
+            if (tid == 0) w.stamps[11] = __builtin_amdgcn_s_memrealtime();
+            if (lane < m) selp[i * sels + lane] = mysel;
+            if (lane == 0) cnt_l[i] = m;
             const float sm = s_i * p.margin;
             const int d4 = D / 4;
             f32x4 ur = {0.f, 0.f, 0.f, 0.f};
-            if (lane < d4) ur = reinterpret_cast<const f32x4*>(w.u + (size_t)i * D)[lane];
+            if (lane < d4) ur = reinterpret_cast<const f32x4*>(ubase + (size_t)i * rstride)[lane];
             for (int t = 0; t < m; ++t) {
                 const int j = __shfl(mysel, t, 64);
                 float part = 0.f;
                 if (lane < d4) {
-                    const f32x4 vr = reinterpret_cast<const f32x4*>(w.v + (size_t)j * D)[lane];
+                    const f32x4 vr = reinterpret_cast<const f32x4*>(vbase + (size_t)j * rstride)[lane];
                     part = ur[0] * vr[0] + ur[1] * vr[1] + ur[2] * vr[2] + ur[3] * vr[3];
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-                const float L = mf_logit(nu_i, w.nv[j], part, s_i, p.sigma, -w.nlogq[j]);
-                if (lane == 0) w.sel_L[i * KSEL_MAX + t] = L;
+                part = mf_wave_sum(part);
+                const float L = mf_logit(nu_i, nv_l[j], part, s_i, p.sigma, -nlq_l[j]);
+                if (lane == 0) sel_Lp[i * sels + t] = L;
                 stats_add(st, need, L, sm, l, p.margin);
                 if (need & NEED_LSE) lse_merge(st.mx, st.se, L, 1.f);
             }
         }
+        if (tid == 0) w.stamps[12] = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
-            float* o = w.stats + i;
+            float* o = stats_l + i;
             o[ST_CNT * Bp] = st.cnt; o[ST_A * Bp] = st.A; o[ST_MX * Bp] = st.mx; o[ST_SE * Bp] = st.se;
             o[ST_H * Bp] = st.H; o[ST_HC * Bp] = st.Hc; o[ST_LG * Bp] = st.Lg; o[ST_LS * Bp] = st.Ls;
         }
     }
     __syncthreads();
+    stamp();
 
     // ---- 5. the seven row losses, the trained loss's backward coefficients, the batch sums (finish_kernel: 64-row blocks, xor trees)
     if (wave < Bp / 64) {
         const int i = wave * 64 + lane;
         float acc[NSTAT];
-        for (int s = 0; s < NSTAT; ++s) acc[s] = w.stats[s * Bp + i];
+        for (int s = 0; s < NSTAT; ++s) acc[s] = stats_l[s * Bp + i];
         float o[MF_NUM_KINDS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (i < B) row_losses(acc, w.tgt[i], w.lii[i], w.dii[i], p.sigma, o);
+        if (i < B) row_losses(acc, tgt_l[i], lii_l[i], dii_l[i], p.sigma, o);
         {
             float a = 0.f, b = 0.f, cg = 0.f, gd = 0.f;
-            if (i < B) rowc_row(p.kind, w.tgt[i], w.sgn[i], w.lii[i], acc[ST_CNT], acc[ST_MX], acc[ST_SE], acc[ST_HC], acc[ST_LS],
+            if (i < B) rowc_row(p.kind, tgt_l[i], sgn_l[i], lii_l[i], acc[ST_CNT], acc[ST_MX], acc[ST_SE], acc[ST_HC], acc[ST_LS],
                                 p.sigma, p.margin, a, b, cg, gd);
-            w.rowc[i] = a; w.rowc[Bp + i] = b; w.rowc[2 * Bp + i] = cg; w.rowc[3 * Bp + i] = gd;
+            rowc_l[i] = a; rowc_l[Bp + i] = b; rowc_l[2 * Bp + i] = cg; rowc_l[3 * Bp + i] = gd;
         }
         for (int k = 0; k < MF_NUM_KINDS; ++k) {
             float v = o[k];
-            for (int ww = 32; ww > 0; ww >>= 1) v += __shfl_xor(v, ww, 64);
-            if (lane == 0) w.blockpart[k * (Bp / 64) + wave] = v;
+            v = mf_wave_sum(v);
+            if (lane == 0) bpart_l[k * (Bp / 64) + wave] = v;
         }
     }
     __syncthreads();
     if (wave == 0) {
         for (int k = 0; k < MF_NUM_KINDS; ++k) {
-            float t = lane < Bp / 64 ? w.blockpart[k * (Bp / 64) + lane] : 0.f;
-            for (int ww = 32; ww > 0; ww >>= 1) t += __shfl_xor(t, ww, 64);
+            float t = lane < Bp / 64 ? bpart_l[k * (Bp / 64) + lane] : 0.f;
+            t = mf_wave_sum(t);
             if (lane == 0) p.out[k] = ((p.kind_mask >> k) & 1) ? t : 0.f;
         }
     }
+    stamp();
 
-    // ---- 6. backward of the trained loss (mined_bwd_kernel): du in registers in selection order, dv as fixed-point integer sums
-    for (int e = tid; e < N * D; e += SS_THREADS) w.dvfix[e] = 0ll;
-    __syncthreads();
+    // ---- 6. backward of the trained loss (mined_bwd_kernel's arithmetic).  du: a lane group per user walks its selected columns in
+    //         selection order.  dv: the batch kernel adds fixed-point terms with integer atomics, a sum that does not depend on
+    //         the order -- here a lane group per COLUMN walks the users that mined it (a bit set per column) and adds the same
+    //         integers in registers: no atomics, no zeroing, no second pass
     {
-        constexpr int LPR = 32, NE = D / LPR;
+        unsigned long long* colm = reinterpret_cast<unsigned long long*>(smem);      // [N][2] (the id table is dead)
+        for (int e = tid; e < 2 * N; e += SS_THREADS) colm[e] = 0ull;
+        __syncthreads();
         const int gmode = gmode_of(p.kind);
-        for (int t0 = 0; t0 < B * LPR; t0 += SS_THREADS) {
-            const int t = t0 + tid;
-            const int i = t / LPR, c = t % LPR;
-            if (i >= B) continue;
-            const float go = 1.0f;                               // the upstream gradient of loss.backward(): one
-            const float a = w.rowc[i], b = w.rowc[Bp + i], cg = go * w.rowc[2 * Bp + i], gd = go * w.rowc[3 * Bp + i];
-            float ui[NE], acc[NE];
-#pragma unroll
-            for (int e = 0; e < NE; ++e) { ui[e] = w.u[(size_t)i * D + c + LPR * e]; acc[e] = 0.f; }
-            const int n = w.sel_cnt[i];
-            for (int s = -1; s < n; ++s) {
-                int j;
-                float g;
-                if (s < 0) { j = i; g = gd; }
-                else { j = w.sel[i * KSEL_MAX + s]; g = cg * g_of(gmode, (w.sel_L[i * KSEL_MAX + s] - a) + b); }
-                unsigned long long* o = reinterpret_cast<unsigned long long*>(w.dvfix) + (size_t)j * D + c;
-#pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    const float vj = w.v[(size_t)j * D + c + LPR * e];
-                    acc[e] += g * (vj - ui[e]);
-                    const float dvj = g * (ui[e] - vj);
-                    const long long q = (long long)__builtin_rintf(fminf(fmaxf(dvj, -8388607.f), 8388607.f) * DV_FIX_SCALE);
-                    atomicAdd(o + LPR * e, (unsigned long long)q);
-                }
+        for (int e = tid; e < B * p.k; e += SS_THREADS) {
+            const int i = e / p.k, sl = e % p.k;
+            if (sl < cnt_l[i]) {
+                const float a = rowc_l[i], b = rowc_l[Bp + i], cg = rowc_l[2 * Bp + i];      // (upstream gradient of loss.backward(): one)
+                const float g = cg * g_of(gmode, (sel_Lp[i * sels + sl] - a) + b);
+                sel_Lp[i * sels + sl] = g;                                                   // the logit is not needed again
+                atomicOr(&colm[2 * selp[i * sels + sl] + (i >> 6)], 1ull << (i & 63));
             }
+        }
+        __syncthreads();
+        constexpr int LPR = 32, NE = D / LPR;
+        for (int t0 = 0; t0 < (B + N) * LPR; t0 += SS_THREADS) {
+            const int t = t0 + tid;
+            const int r = t / LPR, c = t % LPR;
+            if (r < B) {
+                const int i = r;
+                float ui[NE], acc[NE];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) w.du[(size_t)i * D + c + LPR * e] = acc[e];
+                for (int e = 0; e < NE; ++e) { ui[e] = ubase[(size_t)i * rstride + c + LPR * e]; acc[e] = 0.f; }
+                const int n = cnt_l[i];
+                for (int sl = -1; sl < n; ++sl) {
+                    const int j = sl < 0 ? i : selp[i * sels + sl];
+                    const float g = sl < 0 ? rowc_l[3 * Bp + i] : sel_Lp[i * sels + sl];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) acc[e] += g * (vbase[(size_t)j * rstride + c + LPR * e] - ui[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) w.du[(size_t)i * D + c + LPR * e] = acc[e];
+            } else if (r < B + N) {
+                const int j = r - B;
+                float vj[NE];
+                long long sum[NE];
+#pragma unroll
+                for (int e = 0; e < NE; ++e) { vj[e] = vbase[(size_t)j * rstride + c + LPR * e]; sum[e] = 0ll; }
+                auto add = [&](int i, float g) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const float dvj = g * (ubase[(size_t)i * rstride + c + LPR * e] - vj[e]);
+                        sum[e] += (long long)__builtin_rintf(fminf(fmaxf(dvj, -8388607.f), 8388607.f) * DV_FIX_SCALE);
+                    }
+                };
+                if (j < B) add(j, rowc_l[3 * Bp + j]);
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    unsigned long long m = colm[2 * j + h];
+                    while (m) {
+                        const int i = 64 * h + __builtin_ctzll(m);
+                        m &= m - 1;
+                        int sl = 0;
+                        while (selp[i * sels + sl] != j) ++sl;                                // (there: the bit says so)
+                        add(i, sel_Lp[i * sels + sl]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) w.dv[(size_t)j * D + c + LPR * e] = (float)((double)sum[e] * (1.0 / 1099511627776.0));
+            }
         }
     }
     __syncthreads();
-    for (int e = tid; e < N * D; e += SS_THREADS) w.dv[e] = (float)((double)w.dvfix[e] * (1.0 / 1099511627776.0));
-    __syncthreads();
+    stamp();
 
     // ---- 7. the sparse updates: the one-launch update's own workgroup body, bucket after bucket (item table first, like the
     //         optimisers' parameter order does not matter: the two tables are disjoint)
@@ -372,14 +457,16 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
         const int bits = fused_bucket_bits(N);
         FusedUpdateParams fp{p.it, p.im, p.iv, p.n_items, reinterpret_cast<const long long*>(p.item_ids), N, bits, w.dv, w.partial, w.gk0, w.gk1,
                              p.normalize, p.hp};
-        for (unsigned b = 0; b < (1u << bits); ++b) fused_update_body<D, ADAM, 4>(fp, b, lk);
+        fused_update_small<D, ADAM, 4>(fp, lk);
     }
+    stamp();
     {
         const int bits = fused_bucket_bits(B);
         FusedUpdateParams fp{p.ut, p.um, p.uv, p.n_users, reinterpret_cast<const long long*>(p.user_ids), B, bits, w.du, w.partial, w.gk0, w.gk1,
                              p.normalize, p.hp};
-        for (unsigned b = 0; b < (1u << bits); ++b) fused_update_body<D, ADAM, 4>(fp, b, lk);
+        fused_update_small<D, ADAM, 4>(fp, lk);
     }
+    stamp();
 }
 
 extern "C" int mf_step_small(float* user_table, float* user_m, float* user_v, int64_t num_users, float* item_table, float* item_m,
@@ -400,6 +487,8 @@ extern "C" int mf_step_small(float* user_table, float* user_m, float* user_v, in
     if (adam && (!user_m || !user_v || !item_m || !item_v || (!step_dev && step < 1))) return mf_set_error(MF_EINVAL, "mf_step_small: Adam state / step");
     if (pos_off ? (!pos_items || pos_users <= 0) : (P < 0 || (P > 0 && !pos_idx))) return mf_set_error(MF_EINVAL, "mf_step_small: bad positives");
     if (logq && logq_rows <= 0 && false) return MF_EINVAL;
+    if (num_users >= (1ll << 37) || num_items >= (1ll << 37)) return mf_set_error(MF_ENOTSUP, "mf_step_small: tables of < 2^37 rows");
+    static_assert(SS_MAXN <= FUSED_SMALL_N && SS_MAXB <= FUSED_SMALL_N, "fused_update_small's list");
     if (ws_bytes < mf_step_small_ws_bytes(d)) return mf_set_error(MF_ENOSPC, "mf_step_small: workspace too small");
     StepSmallParams sp{};
     sp.ut = user_table; sp.um = user_m; sp.uv = user_v; sp.n_users = num_users;
@@ -418,13 +507,13 @@ extern "C" int mf_step_small(float* user_table, float* user_m, float* user_v, in
         if (adam) {
             auto fn = step_small_kernel<D, true>;
             static bool set = false;
-            if (!set) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_CAP * 8); set = true; }
-            fn<<<dim3(1), SS_THREADS, FUSED_CAP * 8, s>>>(sp);
+            if (!set) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, SS_ROWS0 + SS_ROWS_BYTES); set = true; }
+            fn<<<dim3(1), SS_THREADS, SS_ROWS0 + SS_ROWS_BYTES, s>>>(sp);
         } else {
             auto fn = step_small_kernel<D, false>;
             static bool set = false;
-            if (!set) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_CAP * 8); set = true; }
-            fn<<<dim3(1), SS_THREADS, FUSED_CAP * 8, s>>>(sp);
+            if (!set) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, SS_ROWS0 + SS_ROWS_BYTES); set = true; }
+            fn<<<dim3(1), SS_THREADS, SS_ROWS0 + SS_ROWS_BYTES, s>>>(sp);
         }
     });
     return mf_check_launch("mf_step_small");

@@ -291,16 +291,14 @@ __global__ __launch_bounds__(64) void retrieval_metrics_kernel(const int64_t* __
         if (rank < k) idcg += r / log2f((float)rank + 2.f);
     }
     float dcg = rel / log2f((float)lane + 2.f);
-    for (int o = 32; o > 0; o >>= 1) {
-        dcg += __shfl_xor(dcg, o, 64);
-        idcg += __shfl_xor(idcg, o, 64);
-        npos += __shfl_xor(npos, o, 64);
-    }
+    dcg = mf_wave_sum(dcg);
+    idcg = mf_wave_sum(idcg);
+    npos = mf_wave_sum_int(npos);
     const unsigned long long hit = __ballot(rel > 0.f);
     const int hits = __popcll(hit);
     float ap = 0.f;                                    // precision at every relevant rank
     if (rel > 0.f) ap = (float)__popcll(hit & ((2ull << lane) - 1ull)) / (float)(lane + 1);
-    for (int o = 32; o > 0; o >>= 1) ap += __shfl_xor(ap, o, 64);
+    ap = mf_wave_sum(ap);
     if (lane == 0) {
         float* o = out + q * 6;
         const bool any = npos > 0;

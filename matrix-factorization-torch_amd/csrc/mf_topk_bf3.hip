@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void bf3_build_kernel(const float* __restrict_
         reinterpret_cast<ushort4*>(plane + r * D)[c] = o;
         ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
-    for (int w = LPR / 2; w >= 1; w >>= 1) ss += __shfl_xor(ss, w, 64);
+    ss = mf_butterfly_sum<LPR>(ss);
     // (non-negative floats order like their bit patterns)
     if (r < N && c == 0) atomicMax(reinterpret_cast<unsigned*>(ymax2), __builtin_bit_cast(unsigned, ss));
 }
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64) void bf3_bound_kernel(const float* __restrict__
     }
     float ss = 0.f;
     for (int i = lane; i < d; i += 64) ss = __builtin_fmaf(q[r * d + i], q[r * d + i], ss);
-    for (int w = 32; w >= 1; w >>= 1) ss += __shfl_xor(ss, w, 64);
+    ss = mf_wave_sum(ss);
     if (lane == 0) {
         const float c = 1.01f * (0x1p-7f + 0x1p-16f + (float)d * 0x1p-22f);
         const float eps = c * sqrtf(ss) * sqrtf(ymax2[0]);

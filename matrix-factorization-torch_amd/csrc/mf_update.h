@@ -154,7 +154,7 @@ __device__ __forceinline__ void fused_runs(Keys K, int m, const FusedUpdateParam
             static_assert(NWAVE == 16 && RUN_CHUNK == 32, "position <-> (wave, lane) map");
             const int k = pos_of(lane);
             bool todo = false;
-            if (k < m) {
+            if (k < m && K[k] != FUSED_PAD) {                           // (padding: fused_update_small's bucket boundaries)
                 const unsigned long long row = K[k] >> 24;
                 const bool head = k == 0 || (K[k - 1] >> 24) != row;
                 const int chunk_end = (k / RUN_CHUNK + 1) * RUN_CHUNK;
@@ -323,7 +323,7 @@ __device__ __forceinline__ void fused_update_body(const FusedUpdateParams& p, co
             const long long id = p.idx[q];
             low += (id >= 0 && id < p.n_rows && fused_bucket(id, p.bucket_bits) < myb) ? 1 : 0;
         }
-        for (int w = 32; w >= 1; w >>= 1) low += __shfl_xor(low, w);
+        low = mf_wave_sum_int(low);
         if (lane == 0 && low) atomicAdd(&s_lower, low);
         if (tid == 0) s_count = 0;
         __syncthreads();
@@ -345,6 +345,58 @@ __device__ __forceinline__ void fused_update_body(const FusedUpdateParams& p, co
         __syncthreads();
         fused_runs<D, ADAM, NFLIGHT>(static_cast<const unsigned long long*>(g1), m, p, bc1, bc2);
     }
+}
+
+// EVERY bucket of a short list (n <= FUSED_SMALL_N, bucket_bits <= 3, ids < 2^37) by one workgroup in ONE pass -- the
+// one-launch step (mf_step_small.hip), where a bucket after a bucket would pay the table's memory latency once per bucket.
+// The result is the one update_fused_kernel's workgroups produce: the sorted lists of the buckets are laid end to end,
+// each starting at a multiple of RUN_CHUNK (the gap filled with FUSED_PAD), so that every run is cut into the same
+// chunks, summed in the same order, as in its own bucket's list.
+static constexpr int FUSED_SMALL_N = 256;
+template <int D, bool ADAM, int NFLIGHT>
+__device__ __forceinline__ void fused_update_small(const FusedUpdateParams& p, unsigned long long* lk) {
+    __shared__ int s_n, s_cnt[8], s_pad[8];
+    __shared__ float s_b[2];
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid < 8) s_cnt[tid] = 0;
+    if (tid == 8) s_n = 0;
+    __syncthreads();
+    {
+        const long long id = tid < p.n ? p.idx[tid] : -1;
+        if (ADAM && tid == FUSED_THREADS - 64) {
+            float b1, b2;
+            adam_bias(p.hp, b1, b2);
+            s_b[0] = b1; s_b[1] = b2;
+        }
+        const bool mine = id >= 0 && id < p.n_rows;
+        const unsigned b = mine ? fused_bucket(id, p.bucket_bits) : 0u;
+        fused_append(mine, ((unsigned long long)b << 61) | ((unsigned long long)id << 24) | (unsigned)tid, &s_n, lk, FUSED_SMALL_N);
+        if (mine) atomicAdd(&s_cnt[b], 1);
+    }
+    __syncthreads();
+    const int m = s_n;
+    if (tid == 0) {
+        int pad = 0;
+        for (int b = 0; b < 8; ++b) {
+            s_pad[b] = pad;                                           // padding keys in front of bucket b's segment
+            pad += (RUN_CHUNK - s_cnt[b] % RUN_CHUNK) % RUN_CHUNK;
+        }
+    }
+    const float bc1 = ADAM ? s_b[0] : 1.f, bc2 = ADAM ? s_b[1] : 1.f;
+    unsigned long long* sorted = lk + FUSED_CAP / 2;
+    for (int t = tid; t < FUSED_SMALL_N + 8 * RUN_CHUNK; t += FUSED_THREADS) sorted[t] = FUSED_PAD;
+    __syncthreads();
+    if (m == 0) return;
+    if (tid < m) {
+        const unsigned long long mine = lk[tid];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += lk[j] < mine ? 1 : 0;
+        sorted[rank + s_pad[mine >> 61]] = mine & ((1ull << 61) - 1ull);
+    }
+    __syncthreads();
+    int total = m + s_pad[7];                                         // (the last bucket's tail needs no padding)
+    fused_runs<D, ADAM, NFLIGHT>(sorted, total, p, bc1, bc2);
 }
 
 template <int D, bool ADAM>

@@ -32,6 +32,24 @@ def test_mfma_scores_equal_fmaf_chain_bitwise(mf, d):
     assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+def test_dpp_lane_exchanges_equal_the_shuffles_they_replace(mf):
+    """mf_common.h's DPP / v_permlane swaps against `__shfl_xor`: butterfly sums of every width, the 64-bit wave maximum,
+    every single exchange -- on random bit patterns (floats of every magnitude and sign; no NaN INPUTS: which payload the sum
+    of two NaNs keeps depends on the operand order, which the swaps do not preserve in the upper half-wave)."""
+    import ctypes
+    fn = mf._lib.lib().mf_probe_lane_ops
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    g = torch.Generator().manual_seed(5)
+    waves = 4096
+    bits = torch.randint(-2**31, 2**31, (waves, 128), generator=g, dtype=torch.int64).to(torch.int32)
+    finite = torch.randn(waves // 2, 128, generator=g).mul(torch.logspace(-20, 20, 128)[None, :]).view(torch.int32)
+    bits &= ~(1 << 23)                           # (exponent never all ones: overflow to inf / inf - inf still happen in the sums)
+    bits[: waves // 2] = finite                  # half the waves: ordinary floats over forty decades
+    bad = torch.zeros(16, dtype=torch.int32, device=DEV)
+    mf._lib.check(fn(bits.to(DEV).data_ptr(), waves, bad.data_ptr(), None))
+    assert bad.cpu().tolist() == [0] * 16          # (mismatching lanes per operation, in the kernel's order)
+
+
 def test_sqnorm_bitwise(mf):
     x = torch.randn(300, 128)
     out = torch.empty(300, device=DEV)
