@@ -482,9 +482,9 @@ def topk_small_leg(mf, lib, index, device, dim: int, rank: int) -> dict:
     return out
 
 
-def small_step_leg(mf, device, bsz: int, kw: dict) -> dict:
+def small_step_leg(mf, device, bsz: int, kw: dict, dim: int = DIM) -> dict:
     batches, _ = make_batches(8, bsz, seed=1000, device=device)
-    cfg = mf.models.ModelConfig(num_users=NUM_USERS, num_items=NUM_ITEMS, hidden_size=DIM)
+    cfg = mf.models.ModelConfig(num_users=NUM_USERS, num_items=NUM_ITEMS, hidden_size=dim)
     torch.manual_seed(0)
     towers = mf.models.init_towers(cfg, device=device)
     opt = mf.optim.RowAdam(list(towers.parameters()), lr=1e-4)
@@ -496,14 +496,17 @@ def small_step_leg(mf, device, bsz: int, kw: dict) -> dict:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for i in range(200):
+    for i in range(2000):
         step(batches[i % 8])
     e1.record()
     torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / 200
+    wall = (time.perf_counter() - t0) / 2000
     assert step.fallback_steps == 0
-    return {"one_launch_ms_per_step": round(wall * 1e3, 4), "one_launch_device_ms_per_step": round(e0.elapsed_time(e1) / 200, 4),
-            "one_launch_pairs_per_s": round(bsz / wall, 1), "one_launch_kernel": "step_small_kernel (mf_step_small)"}
+    st = step._ws[:128].view(torch.int64).cpu().tolist()         # s_memrealtime (100 MHz) at the phase boundaries of the last step
+    names = ("ids_and_id_table", "masks", "rows_normalised", "norms", "logits_mining_rows", "losses", "backward", "both_updates")
+    return {"one_launch_ms_per_step": round(wall * 1e3, 4), "one_launch_device_ms_per_step": round(e0.elapsed_time(e1) / 2000, 4),
+            "one_launch_pairs_per_s": round(bsz / wall, 1), "one_launch_kernel": "step_small_kernel (mf_step_small)",
+            "one_launch_phases_us": {n: round((st[i + 1] - st[i]) / 100, 1) for i, n in enumerate(names)}}
 
 
 def spawn_ranks(args) -> int:
@@ -808,6 +811,8 @@ def main() -> None:
                 # the same step in ONE launch (mf_step_small: bit-identical tables): device time per step from events around 200
                 # launches, wall time of the eager loop, and one hipGraph replay per step
                 extras[name].update(small_step_leg(mf, device, bsz, kw))
+                # ... and at the reference's own width (hidden_size = 32, xfmr_rec/lightning.py:33)
+                extras[name]["d32"] = small_step_leg(mf, device, bsz, kw, dim=32)
         torch.cuda.empty_cache()
 
     # --------------------------------------------------------------------- CPU leg ----

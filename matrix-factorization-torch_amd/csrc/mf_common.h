@@ -187,22 +187,31 @@ __device__ __forceinline__ unsigned long long mf_shfl_xor_u64(unsigned long long
         default: return mf_xor_lane_u64<32>(x);
     }
 }
-template <int M>
-__device__ __forceinline__ unsigned long long mf_xor_max_u64(unsigned long long x) {
-    if constexpr (M >= 16) {
-        const unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
-        const auto rl = mf_swap_halves<M>(lo), rh = mf_swap_halves<M>(hi);
-        const unsigned long long a = ((unsigned long long)rh[0] << 32) | rl[0], b = ((unsigned long long)rh[1] << 32) | rl[1];
-        return a > b ? a : b;
-    } else {
-        const unsigned long long o = mf_xor_lane_u64<M>(x);
-        return o > x ? o : x;
+// the wave's maximum, in every lane: max is exact and order-free, so the butterfly's partner may as well be any lane that
+// makes the classes merge -- here the cheapest ones
+__device__ __forceinline__ unsigned mf_wave_max_u32(unsigned x) {
+    {
+        const auto r = mf_swap_halves<32>(x);
+        x = r[0] > r[1] ? r[0] : r[1];
     }
-}
-__device__ __forceinline__ unsigned long long mf_wave_max_u64(unsigned long long x) {
-    x = mf_xor_max_u64<32>(x); x = mf_xor_max_u64<16>(x); x = mf_xor_max_u64<8>(x);
-    x = mf_xor_max_u64<4>(x); x = mf_xor_max_u64<2>(x); x = mf_xor_max_u64<1>(x);
+    {
+        const auto r = mf_swap_halves<16>(x);
+        x = r[0] > r[1] ? r[0] : r[1];
+    }
+    unsigned o;
+    o = mf_xor_lane_u32<8>(x); x = o > x ? o : x;
+    o = mf_dpp_u32<0x124>(x, x); x = o > x ? o : x;            // row_ror:4 (classes are closed under ^8 by now: the same merge as ^4)
+    o = mf_xor_lane_u32<2>(x); x = o > x ? o : x;
+    o = mf_xor_lane_u32<1>(x); x = o > x ? o : x;
     return x;
+}
+// 64-bit keys: the largest high word, then the largest low word among the lanes that hold it -- two 32-bit reductions
+// instead of one of 64-bit compare-and-selects over two exchanged words
+__device__ __forceinline__ unsigned long long mf_wave_max_u64(unsigned long long x) {
+    const unsigned hi = (unsigned)(x >> 32), lo = (unsigned)x;
+    const unsigned mh = mf_wave_max_u32(hi);
+    const unsigned ml = mf_wave_max_u32(hi == mh ? lo : 0u);
+    return ((unsigned long long)mh << 32) | ml;
 }
 __device__ __forceinline__ float mf_group_sum(float x, int width) {  // width: power of two <= 64 (a constant at every call site)
     switch (width) {

@@ -1,21 +1,26 @@
 // mf_step_small.hip -- the reference's DEFAULT training step in ONE launch (gfx950).
 //
 // The reference trains with 32 pairs per step (BATCH_SIZE, xfmr_rec/params.py:18), PairwiseHingeLoss and 4 mined negatives
-// (xfmr_rec/lightning.py:38-39).  At that size the multi-kernel path -- 11+ launches of a few microseconds each -- is bound
-// by launch latency, not by work: ~0.5 MFLOP per step.  Here ONE workgroup of 1024 threads runs the whole step on
-// B <= 128 pairs: tower gathers (L2-normalised rows) -> chain norms, diagonal -> hit masks -> all B x N logits and the
-// mined negatives -> the row statistics, the seven losses and their batch sums -> dU / dV of the trained loss -> the
-// sparse SGD / row-Adam update of both tables.  Phases are separated by workgroup barriers; the intermediate rows live in
-// the caller's workspace (L1 / L2 resident).
+// (xfmr_rec/lightning.py:38-39), 32 features.  At that size the multi-kernel path -- 11+ launches of a few microseconds
+// each -- is bound by launch latency, not by work: ~0.5 MFLOP per step.  Here ONE workgroup of 1024 threads runs the whole
+// step on B <= 128 pairs, and what bounds it is one CU's instruction issue and the chain of dependent memory round trips:
+//   ids -> [table rows + logq + a word of every Adam-moment line (L2 warming) in flight; meanwhile: id table in LDS, hit
+//   masks from the padded positives asked for at the very top] -> rows normalised into LDS -> chain norms, one chain per
+//   thread -> u.v on the matrix core (32 x 32 x 2 fp32 MFMA == the k-ordered fmaf chain) -> mining keys, k rounds of a
+//   DPP wave maximum, the mined logits 64/(D/4) at a time -> row statistics, the seven losses, batch sums -> dU (a lane
+//   group per user) and dV (a lane group per COLUMN walking the users that mined it: the batch kernel's fixed-point sums
+//   without atomics) in LDS -> both tables' sparse SGD / row-Adam updates in one pass (fused_update_small, mf_update.h).
+// Per-row scalars, selections, chain products and gradients stay in LDS when the batch fits (the default shapes do);
+// larger ones fall back to the caller's workspace (L2).
 //
 // Bit-identical to the multi-kernel path (tests/test_gpu_module.py: torch.equal on both tables after several steps): every
-// floating-point expression is the one the batch kernels evaluate, in the same order -- the gather's shuffle tree, the
-// k-ordered fmaf chains (== the fp32 MFMA element), mined_rows_kernel's wave-reduced logits, finish_kernel's block sums,
-// mined_bwd_kernel's per-feature sums and fixed-point dV, and for the update the very same workgroup body
-// (fused_update_body, mf_update.h) bucket after bucket.  Integer work (masks, the exact top-k of unique 64-bit keys) is
-// free to take the short way.
+// floating-point expression is the one the batch kernels evaluate, in the same order -- the gather's butterfly, the
+// k-ordered fmaf chains, mined_rows_kernel's wave-reduced logits, finish_kernel's block sums, mined_bwd_kernel's
+// per-feature sums and fixed-point dV, and for the update the very same run logic (fused_runs_of) over the same chunks.
+// Integer work (masks, the exact top-k of unique 64-bit keys) is free to take the short way.
 //
-// Scope: mining on (0 < num_negatives <= 64 < N); the in-batch dense path (num_negatives = 0) stays with the MFMA sweeps.
+// Scope: mining on (0 < num_negatives <= 64, num_negatives < N); the in-batch dense path (num_negatives = 0) stays with the
+// MFMA sweeps.  s_memrealtime stamps at the phase boundaries go to the workspace's first 128 bytes (tools/lab/small_step_probe.py).
 #include "mf_common.h"
 #include "mf_loss_math.h"
 #include "mf_update.h"
@@ -48,7 +53,7 @@ static StepSmallWs step_small_ws(void* base, int d) {
     w.sel_L = a.take<float>(Bp * KSEL_MAX); w.sel = a.take<int32_t>(Bp * KSEL_MAX); w.sel_cnt = a.take<int32_t>(Bp);
     w.du = a.take<float>(Bp * d); w.dv = a.take<float>(Np * d);
     w.dots = a.take<float>(Bp * (Np + 8));
-    w.partial = a.take<float>(Np * d);
+    w.partial = a.take<float>((Np + Bp) * d);
     w.blockpart = a.take<float>((size_t)MF_NUM_KINDS * 4);
     w.gk0 = a.take<unsigned long long>(Np); w.gk1 = a.take<unsigned long long>(Np);
     w.total = a.used();
@@ -77,6 +82,13 @@ __device__ __forceinline__ unsigned long long ss_shfl_or_u64(unsigned long long 
     return x;
 }
 
+// a workgroup barrier for LDS traffic only: global loads stay in flight across it (__syncthreads waits for them)
+__device__ __forceinline__ void ss_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int D, bool ADAM>
 __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];                 // FUSED_CAP * 8 bytes (the update body's key list)
@@ -99,8 +111,10 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
     float* fl = reinterpret_cast<float*>(hitm + SS_MAXB * 4);
     float *nu_l = fl, *lii_l = fl + 128, *dii_l = fl + 256, *sgn_l = fl + 384, *tgt_l = fl + 512, *nv_l = fl + 640, *nlq_l = fl + 896,
           *stats_l = fl + 1152, *rowc_l = fl + 2176, *bpart_l = fl + 2688;
+    float* bias_l = fl + 2704;                                                  // [2] Adam's bias corrections
     int32_t* cnt_l = reinterpret_cast<int32_t*>(fl + 2720);                     // [SS_MAXB] selected columns per user
-    int32_t* sel_l = cnt_l + SS_MAXB;                                           // [B][k] selected columns, then [B][k] their logits
+    long long* itemid_l = reinterpret_cast<long long*>(cnt_l + SS_MAXB);        // [SS_MAXN] the columns' item ids
+    int32_t* sel_l = reinterpret_cast<int32_t*>(itemid_l + SS_MAXN);            // [B][k] selected columns, then [B][k] their logits
     const bool sel_in_lds = (size_t)B * p.k * 8 <= (size_t)(SS_ROWS0 - ((char*)sel_l - smem));
     int32_t* selp = sel_in_lds ? sel_l : w.sel;
     float* sel_Lp = sel_in_lds ? reinterpret_cast<float*>(sel_l + (size_t)B * p.k) : w.sel_L;
@@ -116,100 +130,109 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
     const int dstride = ((N + 31) & ~31) + 8;                 // (+8: the two half-waves of a tile store land in different banks)
     const bool dots_in_lds = in_lds && (size_t)(B + N) * ROWF * 4 + (size_t)B * dstride * 4 <= (size_t)SS_ROWS_BYTES;
     float* dots = dots_in_lds ? rows_lds + (size_t)(B + N) * ROWF : w.dots;
+    // the gradients of the gathered rows (du, dv): over the chain products, which are dead by then
+    const bool grads_in_lds = in_lds && (size_t)(B + N) * ROWF * 4 + (size_t)(B + N) * D * 4 <= (size_t)SS_ROWS_BYTES;
+    float* dup = grads_in_lds ? rows_lds + (size_t)(B + N) * ROWF : w.du;
+    float* dvp = grads_in_lds ? dup + (size_t)B * D : w.dv;
 
-    // ---- 1. tower forward: gathered rows, L2-normalised (gather_rows_kernel: D/4 lanes per row, the same shuffle tree)
-    {
-        constexpr int LPR = D / 4, RPW = 64 / LPR;
-        for (int r0 = 0; r0 < B + N; r0 += (SS_THREADS / 64) * RPW) {
-            const int r = r0 + wave * RPW + lane / LPR;
-            const int c = lane % LPR;
-            const bool valid = r < B + N;
-            const bool is_u = r < B;
-            const float* table = is_u ? p.ut : p.it;
-            const long long n_rows = is_u ? p.n_users : p.n_items;
-            long long row = valid ? (is_u ? p.user_ids[r] : p.item_ids[r - B]) : 0;
-            const bool in_range = row >= 0 && row < n_rows;
-            row = in_range ? row : 0;
-            f32x4 x = reinterpret_cast<const f32x4*>(table + row * D)[c];
-            if (!in_range) x = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.normalize) {
-                float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
-                ss = mf_group_sum(ss, LPR);
-                const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
-                x = x * inv;
-            }
-            if (valid) {
-                reinterpret_cast<f32x4*>((is_u ? w.u + (size_t)r * D : w.v + (size_t)(r - B) * D))[c] = x;
-                if (in_lds) reinterpret_cast<f32x4*>(rows_lds + (size_t)r * ROWF)[c] = x;
-            }
-        }
-        // the id table while the rows land
-        for (int e = tid; e < SS_HT; e += SS_THREADS) {
-            hkey[e] = (long long)0x8080808080808080ull;
-            hset[4 * e] = hset[4 * e + 1] = hset[4 * e + 2] = hset[4 * e + 3] = 0ull;
-        }
-    }
-    __syncthreads();
-    stamp();
-
-    // ---- 2. chain norms of both operands, the diagonal, -logq (prep_kernel); the batch's ids into the table
-    if (tid < SS_MAXN) {
-        const int i = tid;
-        const bool hv = i < N, hu = i < B;
-        float nvv = 0.f, nuu = 0.f, dot = 0.f;
-        if (hv) {
-            const f32x4* pv = reinterpret_cast<const f32x4*>(vbase + (size_t)i * rstride);
-            const f32x4* pu = reinterpret_cast<const f32x4*>(ubase + (size_t)(hu ? i : 0) * rstride);
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-            for (int g = 0; g < D / 8; ++g) {                    // k order of mf_dot_chain
-                const f32x4 a = pv[2 * g], b = pv[2 * g + 1];
-                const f32x4 xa = hu ? pu[2 * g] : zero4, xb = hu ? pu[2 * g + 1] : zero4;
+    // ---- 1-3. the front of the step is a chain of dependent memory round trips (ids -> table rows; ids -> logq; positives ->
+    //           masks), each ~1-2 us for one workgroup: they are issued as early as their addresses are known and the work
+    //           that needs only LDS (the id table, the masks) runs under the table rows' latency.  Barriers in between are
+    //           LDS-only (ss_lds_barrier: no vmcnt wait), loads return in order.
+    constexpr int LPR = D / 4, RPW = 64 / LPR, RPI = (SS_THREADS / 64) * RPW, PF = 4;      // rows per pass; passes in flight
+    const int gc = lane % LPR, rsub = wave * RPW + lane / LPR;
+    long long rid[PF];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    nvv = __builtin_fmaf(a[t], a[t], nvv);  nvv = __builtin_fmaf(b[t], b[t], nvv);
-                    nuu = __builtin_fmaf(xa[t], xa[t], nuu); nuu = __builtin_fmaf(xb[t], xb[t], nuu);
-                    dot = __builtin_fmaf(xa[t], a[t], dot);  dot = __builtin_fmaf(xb[t], b[t], dot);
-                }
-            }
-        }
-        nv_l[i] = nvv;
-        float lq = 0.f;
-        if (p.logq && hv) {
-            if (p.logq_rows > 0) {
-                const long long id = p.item_ids[i];
-                lq = (id >= 0 && id < p.logq_rows) ? p.logq[id] : 0.f;
-            } else {
-                lq = p.logq[i];
-            }
-        }
-        nlq_l[i] = -lq;
-        if (i < Bp) {
-            float l = 0.f, dd = 0.f, sg = 0.f, tg = 0.f;
-            if (hu) {
-                tg = p.target_i64 ? (float)static_cast<const int64_t*>(p.target)[i] : static_cast<const float*>(p.target)[i];
-                sg = mf_sign(tg);
-                dd = mf_half_sqdist(nuu, nvv, dot);
-                l = mf_logit(nuu, nvv, dot, sg, p.sigma, lq);
-            }
-            nu_l[i] = nuu; lii_l[i] = l; dii_l[i] = dd; sgn_l[i] = sg; tgt_l[i] = tg;
-        }
-        if (hv) {                                                // column i joins the set of its item id
-            const long long key = p.item_ids[i];
-            unsigned h = ((((unsigned)key * 2654435761u) ^ ((unsigned)((unsigned long long)key >> 32) * 40503u)) >> 5) & (SS_HT - 1);
-            for (;;) {
-                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&hkey[h]), 0x8080808080808080ull, (unsigned long long)key);
-                if (old == 0x8080808080808080ull || old == (unsigned long long)key) break;
-                h = (h + 1) & (SS_HT - 1);
-            }
-            atomicOr(&hset[4 * h + (i >> 6)], 1ull << (i & 63));
+    for (int it = 0; it < PF; ++it) {
+        const int r = it * RPI + rsub;
+        rid[it] = r < B ? p.user_ids[r] : (r < B + N ? p.item_ids[r - B] : -1ll);
+    }
+    const long long my_item = tid < N ? p.item_ids[tid] : 0ll;                           // column tid's id
+    float tg_reg = 0.f;
+    if (tid < B) tg_reg = p.target_i64 ? (float)static_cast<const int64_t*>(p.target)[tid] : static_cast<const float*>(p.target)[tid];
+    // the first 64 padded positives of the first 32 users (a half-wave per user): their addresses need no id
+    constexpr long long NO_KEY = (long long)0x8080808080808080ull;                       // (never an id: the table's empty slot)
+    long long pre[2] = {NO_KEY, NO_KEY};
+    {
+        const int i = 2 * wave + (lane >> 5), l32 = lane & 31;
+        if (!p.pos_off && i < B) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+                if (l32 + 32 * sl < p.P) pre[sl] = p.pos_idx[(size_t)i * p.P + l32 + 32 * sl];
         }
     }
-    __syncthreads();
+    for (int e = tid; e < SS_HT; e += SS_THREADS) {
+        hkey[e] = NO_KEY;
+        hset[4 * e] = hset[4 * e + 1] = hset[4 * e + 2] = hset[4 * e + 3] = 0ull;
+    }
+    ss_lds_barrier();
+    auto slot_of = [](long long key) {
+        return ((((unsigned)key * 2654435761u) ^ ((unsigned)((unsigned long long)key >> 32) * 40503u)) >> 5) & (SS_HT - 1);
+    };
+    if (tid < N) {                                               // column tid joins the set of its item id
+        unsigned h = slot_of(my_item);
+        for (;;) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&hkey[h]), (unsigned long long)NO_KEY, (unsigned long long)my_item);
+            if (old == (unsigned long long)NO_KEY || old == (unsigned long long)my_item) break;
+            h = (h + 1) & (SS_HT - 1);
+        }
+        atomicOr(&hset[4 * h + (tid >> 6)], 1ull << (tid & 63));
+        itemid_l[tid] = my_item;
+    }
+    // the table rows (and logq) are asked for now ...
+    auto load_row = [&](int r, long long row) {
+        const bool is_u = r < B;
+        const bool in_range = row >= 0 && row < (is_u ? p.n_users : p.n_items);
+        f32x4 x = reinterpret_cast<const f32x4*>((is_u ? p.ut : p.it) + (in_range ? row : 0) * D)[gc];
+        if (!in_range) x = f32x4{0.f, 0.f, 0.f, 0.f};
+        return x;
+    };
+    auto keep_row = [&](int r, f32x4 x) {                        // gather_rows_kernel: D/4 lanes per row, the same butterfly
+        if (p.normalize) {
+            float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+            ss = mf_group_sum(ss, LPR);
+            const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+            x = x * inv;
+        }
+        if (r < B + N) {
+            if (in_lds) reinterpret_cast<f32x4*>(rows_lds + (size_t)r * ROWF)[gc] = x;
+            else reinterpret_cast<f32x4*>((r < B ? w.u + (size_t)r * D : w.v + (size_t)(r - B) * D))[gc] = x;
+        }
+    };
+    f32x4 xrow[PF];
+#pragma unroll
+    for (int it = 0; it < PF; ++it) xrow[it] = load_row(it * RPI + rsub, rid[it]);
+    // ... and one word of every 128-byte line of the rows' Adam moments, which the updates at the far end of the step would
+    // otherwise fetch cold (HBM + a TLB miss, on the critical path): this brings them into the XCD's L2
+    unsigned warm = 0u;
+    if (ADAM) {
+        constexpr int LINES = D * 4 / 128;                       // (2 * LINES <= D / 4 lanes of the row's group)
+#pragma unroll
+        for (int it = 0; it < PF; ++it) {
+            const int r = it * RPI + rsub;
+            const long long row = rid[it];
+            if (gc < 2 * LINES && r < B + N && row >= 0 && row < (r < B ? p.n_users : p.n_items)) {
+                const float* base = r < B ? ((gc & 1) ? p.uv : p.um) : ((gc & 1) ? p.iv : p.im);
+                warm ^= *(reinterpret_cast<const unsigned*>(base + row * D) + 32 * (gc >> 1));
+            }
+        }
+    }
+    if (ADAM && tid == SS_THREADS - 1) {                         // two double-precision expm1 by one lane: under the rows' latency, once
+        float b1, b2;
+        adam_bias(p.hp, b1, b2);
+        bias_l[0] = b1; bias_l[1] = b2;
+    }
+    float lq_reg = 0.f;
+    if (p.logq && tid < N) {
+        if (p.logq_rows > 0) lq_reg = (my_item >= 0 && my_item < p.logq_rows) ? p.logq[my_item] : 0.f;
+        else lq_reg = p.logq[tid];
+    }
+    ss_lds_barrier();                                          // the id table is complete
     stamp();
 
-    // ---- 3. hit masks (negative_masks, losses.py:92-110): one wave per user ORs the column sets of its positives and of its own item
-    for (int i0 = 0; i0 < B; i0 += 2 * (SS_THREADS / 64)) {           // a half-wave per user
+    // ... and the hit masks (negative_masks, losses.py:92-110) are made while they travel: a half-wave per user ORs the column
+    // sets of its positives and of its own item
+    for (int i0 = 0; i0 < B; i0 += 2 * (SS_THREADS / 64)) {
         const int i = i0 + 2 * wave + (lane >> 5), l32 = lane & 31;
         const int64_t* list = nullptr;
         int len = -1;                                                // (no user: nothing to look up, not even an own item)
@@ -229,9 +252,8 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
             }
         }
         unsigned long long m4[4] = {0ull, 0ull, 0ull, 0ull};
-        for (int t = l32; t < len + 1; t += 32) {
-            const long long key = t < len ? list[t] : p.item_ids[i];
-            unsigned h = ((((unsigned)key * 2654435761u) ^ ((unsigned)((unsigned long long)key >> 32) * 40503u)) >> 5) & (SS_HT - 1);
+        auto look_up = [&](long long key) {
+            unsigned h = slot_of(key);
             for (;;) {
                 const long long sv = hkey[h];
                 if (sv == key) {
@@ -239,10 +261,18 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                     for (int q = 0; q < 4; ++q) m4[q] |= hset[4 * h + q];
                     break;
                 }
-                if (sv == (long long)0x8080808080808080ull) break;
+                if (sv == NO_KEY) break;
                 h = (h + 1) & (SS_HT - 1);
             }
+        };
+        int t = l32;
+        if (i0 == 0 && !p.pos_off) {                                 // (wave-uniform) the entries asked for at the top
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+                if (t < len) { look_up(pre[sl]); t += 32; }
         }
+        for (; t < len; t += 32) look_up(list[t]);
+        if (l32 == 0 && len >= 0) look_up(itemid_l[i]);              // the user's own item
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             unsigned long long m = m4[q];
@@ -252,6 +282,56 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
             const int lo = 64 * q;
             if (N < lo + 64) m |= N <= lo ? ~0ull : (~0ull << (N - lo));
             if (l32 == 0 && i < B) hitm[4 * i + q] = m;
+        }
+    }
+    stamp();
+
+    // the rows have landed: tower forward (L2 normalisation), into LDS
+#pragma unroll
+    for (int it = 0; it < PF; ++it) keep_row(it * RPI + rsub, xrow[it]);
+    for (int r0 = PF * RPI; r0 < B + N; r0 += RPI) {
+        const int r = r0 + rsub;
+        const long long row = r < B ? p.user_ids[r] : (r < B + N ? p.item_ids[r - B] : -1ll);
+        keep_row(r, load_row(r, row));
+    }
+    __syncthreads();
+    stamp();
+
+    // ---- chain norms of both operands, the diagonal, -logq (prep_kernel).  One chain per thread -- N of v.v, B of u.u, B of
+    //      u_i.v_i -- instead of three per column: a chain is a sequence of dependent LDS round trips, and the default batch
+    //      would leave them all to one wave
+    {
+        float* dot_l = stats_l;                                  // [SS_MAXB] (the statistics are written later)
+        const int which = tid < N ? 0 : (tid < N + B ? 1 : 2), i = tid < N ? tid : (tid < N + B ? tid - N : tid - N - B);
+        if (tid < N + 2 * B) {
+            const f32x4* pa = reinterpret_cast<const f32x4*>((which == 0 ? vbase : ubase) + (size_t)i * rstride);
+            const f32x4* pb = reinterpret_cast<const f32x4*>((which == 1 ? ubase : vbase) + (size_t)i * rstride);
+            float acc = 0.f;
+#pragma unroll 4
+            for (int g = 0; g < D / 8; ++g) {                    // k order of mf_dot_chain
+                const f32x4 a0 = pa[2 * g], a1 = pa[2 * g + 1], b0 = pb[2 * g], b1 = pb[2 * g + 1];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc = __builtin_fmaf(a0[t], b0[t], acc);
+                    acc = __builtin_fmaf(a1[t], b1[t], acc);
+                }
+            }
+            (which == 0 ? nv_l : (which == 1 ? nu_l : dot_l))[i] = acc;
+        }
+        if (tid >= N && tid < SS_MAXN) nv_l[tid] = 0.f;
+        if (tid < SS_MAXN) nlq_l[tid] = tid < N ? -lq_reg : 0.f;
+        ss_lds_barrier();
+        if (tid < Bp) {
+            float l = 0.f, dd = 0.f, sg = 0.f, tg = 0.f, nuu = 0.f;
+            if (tid < B) {
+                nuu = nu_l[tid];
+                const float nvv = nv_l[tid], dot = dot_l[tid];
+                tg = tg_reg;
+                sg = mf_sign(tg);
+                dd = mf_half_sqdist(nuu, nvv, dot);
+                l = mf_logit(nuu, nvv, dot, sg, p.sigma, lq_reg);
+            }
+            nu_l[tid] = nuu; lii_l[tid] = l; dii_l[tid] = dd; sgn_l[tid] = sg; tgt_l[tid] = tg;
         }
     }
     __syncthreads();
@@ -290,58 +370,64 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
         }
     }
     __syncthreads();
-    if (tid == 0) w.stamps[9] = __builtin_amdgcn_s_memrealtime();
-    for (int i = wave; i < Bp; i += SS_THREADS / 64) {
+    for (int i = wave; i < B; i += SS_THREADS / 64) {
         RowStats st;
         stats_init(st);
-        if (i < B) {
+        {
             const float nu_i = nu_l[i], s_i = sgn_l[i], l = lii_l[i];
             unsigned long long keyv[SS_MAXN / 64];
 #pragma unroll
             for (int q = 0; q < SS_MAXN / 64; ++q) {
                 const int j = lane + 64 * q;
                 keyv[q] = 0ull;
+                if (64 * q >= N) continue;                       // (wave-uniform)
                 if (j < N && !((hitm[4 * i + q] >> lane) & 1ull)) {
                     const float L = mf_logit(nu_i, nv_l[j], dots[(size_t)i * dstride + j], s_i, p.sigma, -nlq_l[j]);
                     keyv[q] = mf_key_mining(L - l, (unsigned)j);
                 }
             }
-            if (tid == 0) w.stamps[10] = __builtin_amdgcn_s_memrealtime();
             int m = 0, mysel = 0;
             for (int t = 0; t < p.k; ++t) {                      // unique keys: k rounds of "largest remaining"
                 unsigned long long loc = 0ull;
 #pragma unroll
-                for (int q = 0; q < SS_MAXN / 64; ++q) loc = keyv[q] > loc ? keyv[q] : loc;
+                for (int q = 0; q < SS_MAXN / 64; ++q)
+                    if (64 * q < N) loc = keyv[q] > loc ? keyv[q] : loc;
                 const unsigned long long best = mf_wave_max_u64(loc);
                 if (best == 0ull) break;
 #pragma unroll
                 for (int q = 0; q < SS_MAXN / 64; ++q)
-                    if (keyv[q] == best) keyv[q] = 0ull;
+                    if (64 * q < N && keyv[q] == best) keyv[q] = 0ull;
                 if (lane == t) mysel = (int)mf_key_mining_col(best);        // (k <= 64: lane t keeps the t-th selected column)
                 ++m;
             }
-            if (tid == 0) w.stamps[11] = __builtin_amdgcn_s_memrealtime();
             if (lane < m) selp[i * sels + lane] = mysel;
             if (lane == 0) cnt_l[i] = m;
             const float sm = s_i * p.margin;
-            const int d4 = D / 4;
-            f32x4 ur = {0.f, 0.f, 0.f, 0.f};
-            if (lane < d4) ur = reinterpret_cast<const f32x4*>(ubase + (size_t)i * rstride)[lane];
-            for (int t = 0; t < m; ++t) {
-                const int j = __shfl(mysel, t, 64);
-                float part = 0.f;
-                if (lane < d4) {
-                    const f32x4 vr = reinterpret_cast<const f32x4*>(vbase + (size_t)j * rstride)[lane];
-                    part = ur[0] * vr[0] + ur[1] * vr[1] + ur[2] * vr[2] + ur[3] * vr[3];
-                }
-                part = mf_wave_sum(part);
+            // the selected negatives' logits (mined_rows_kernel: D/4 lanes x 4 elements, then the wave's butterfly with the other
+            // lanes at zero): 64 / (D/4) of them at a time, a lane group each.  A group's butterfly is the wave's with the
+            // levels that only add those zeros (x + 0) made explicit -- the same bits.
+            constexpr int d4 = D / 4, G = 64 / d4;
+            const int grp = lane / d4, c = lane % d4;
+            const f32x4 ur = reinterpret_cast<const f32x4*>(ubase + (size_t)i * rstride)[c];
+            float myL = 0.f;                                     // lane t: the logit of selection t
+            for (int t0 = 0; t0 < m; t0 += G) {
+                const int t = t0 + grp;
+                const int j = __shfl(mysel, t < m ? t : 0, 64);
+                const f32x4 vr = reinterpret_cast<const f32x4*>(vbase + (size_t)j * rstride)[c];
+                float part = ur[0] * vr[0] + ur[1] * vr[1] + ur[2] * vr[2] + ur[3] * vr[3];
+                if (d4 < 64) part = part + 0.f;
+                part = mf_butterfly_sum<d4>(part);
                 const float L = mf_logit(nu_i, nv_l[j], part, s_i, p.sigma, -nlq_l[j]);
-                if (lane == 0) sel_Lp[i * sels + t] = L;
+                if (c == 0 && t < m) sel_Lp[i * sels + t] = L;
+                const float got = __shfl(L, ((lane - t0) & (G - 1)) * d4, 64);
+                if (lane >= t0 && lane < t0 + G) myL = got;
+            }
+            for (int t = 0; t < m; ++t) {                        // the statistics, in selection order
+                const float L = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myL), t));
                 stats_add(st, need, L, sm, l, p.margin);
                 if (need & NEED_LSE) lse_merge(st.mx, st.se, L, 1.f);
             }
         }
-        if (tid == 0) w.stamps[12] = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
             float* o = stats_l + i;
             o[ST_CNT * Bp] = st.cnt; o[ST_A * Bp] = st.A; o[ST_MX * Bp] = st.mx; o[ST_SE * Bp] = st.se;
@@ -416,7 +502,7 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                     for (int e = 0; e < NE; ++e) acc[e] += g * (vbase[(size_t)j * rstride + c + LPR * e] - ui[e]);
                 }
 #pragma unroll
-                for (int e = 0; e < NE; ++e) w.du[(size_t)i * D + c + LPR * e] = acc[e];
+                for (int e = 0; e < NE; ++e) dup[(size_t)i * D + c + LPR * e] = acc[e];
             } else if (r < B + N) {
                 const int j = r - B;
                 float vj[NE];
@@ -443,30 +529,24 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < NE; ++e) w.dv[(size_t)j * D + c + LPR * e] = (float)((double)sum[e] * (1.0 / 1099511627776.0));
+                for (int e = 0; e < NE; ++e) dvp[(size_t)j * D + c + LPR * e] = (float)((double)sum[e] * (1.0 / 1099511627776.0));
             }
         }
     }
     __syncthreads();
     stamp();
 
-    // ---- 7. the sparse updates: the one-launch update's own workgroup body, bucket after bucket (item table first, like the
-    //         optimisers' parameter order does not matter: the two tables are disjoint)
-    unsigned long long* lk = reinterpret_cast<unsigned long long*>(smem);
+    // ---- 7. the sparse updates: the one-launch update's own run logic (fused_runs_of), every bucket of both tables in one pass
     {
-        const int bits = fused_bucket_bits(N);
-        FusedUpdateParams fp{p.it, p.im, p.iv, p.n_items, reinterpret_cast<const long long*>(p.item_ids), N, bits, w.dv, w.partial, w.gk0, w.gk1,
-                             p.normalize, p.hp};
-        fused_update_small<D, ADAM, 4>(fp, lk);
+        unsigned long long* lk = reinterpret_cast<unsigned long long*>(smem);
+        FusedUpdateParams fi{p.it, p.im, p.iv, p.n_items, reinterpret_cast<const long long*>(p.item_ids), N, fused_bucket_bits(N), dvp,
+                             w.partial, w.gk0, w.gk1, p.normalize, p.hp};
+        FusedUpdateParams fu{p.ut, p.um, p.uv, p.n_users, reinterpret_cast<const long long*>(p.user_ids), B, fused_bucket_bits(B), dup,
+                             w.partial + (size_t)SS_MAXN * D, w.gk0, w.gk1, p.normalize, p.hp};
+        fused_update_small<D, ADAM, 4>(fi, fu, bias_l, lk);
     }
     stamp();
-    {
-        const int bits = fused_bucket_bits(B);
-        FusedUpdateParams fp{p.ut, p.um, p.uv, p.n_users, reinterpret_cast<const long long*>(p.user_ids), B, bits, w.du, w.partial, w.gk0, w.gk1,
-                             p.normalize, p.hp};
-        fused_update_small<D, ADAM, 4>(fp, lk);
-    }
-    stamp();
+    if (warm == 0x7FC5A5A5u) w.stamps[15] = warm;               // (keeps the warming loads; practically never true, harmless when it is)
 }
 
 extern "C" int mf_step_small(float* user_table, float* user_m, float* user_v, int64_t num_users, float* item_table, float* item_m,
@@ -487,7 +567,7 @@ extern "C" int mf_step_small(float* user_table, float* user_m, float* user_v, in
     if (adam && (!user_m || !user_v || !item_m || !item_v || (!step_dev && step < 1))) return mf_set_error(MF_EINVAL, "mf_step_small: Adam state / step");
     if (pos_off ? (!pos_items || pos_users <= 0) : (P < 0 || (P > 0 && !pos_idx))) return mf_set_error(MF_EINVAL, "mf_step_small: bad positives");
     if (logq && logq_rows <= 0 && false) return MF_EINVAL;
-    if (num_users >= (1ll << 37) || num_items >= (1ll << 37)) return mf_set_error(MF_ENOTSUP, "mf_step_small: tables of < 2^37 rows");
+    if (num_users >= (1ll << 36) || num_items >= (1ll << 36)) return mf_set_error(MF_ENOTSUP, "mf_step_small: tables of < 2^36 rows");
     static_assert(SS_MAXN <= FUSED_SMALL_N && SS_MAXB <= FUSED_SMALL_N, "fused_update_small's list");
     if (ws_bytes < mf_step_small_ws_bytes(d)) return mf_set_error(MF_ENOSPC, "mf_step_small: workspace too small");
     StepSmallParams sp{};

@@ -140,8 +140,11 @@ __device__ __forceinline__ void fused_append(bool mine, unsigned long long key, 
 // consecutive positions AND consecutive chunk starts (multiples of 32: the chunks of one popular row) land in
 // different waves -- GPW owners at a time per wave, one per D/4-lane group.
 // pass 0: chunk sums (a run that is one chunk is applied);  pass 1: runs of several chunks
-template <int D, bool ADAM, int NFLIGHT, class Keys>
-__device__ __forceinline__ void fused_runs(Keys K, int m, const FusedUpdateParams& p, float bc1, float bc2) {
+// `params(k)`: the table / gradient / hyper-parameter set of sorted position k, `params.row(key)`: the row a key addresses
+// (FusedOneTable for update_fused_kernel; the one-launch step lays the lists of its two tables end to end and updates
+// both in one pass: FusedTwoTables)
+template <int D, bool ADAM, int NFLIGHT, class Keys, class Params>
+__device__ __forceinline__ void fused_runs_of(Keys K, int m, Params params, float bc1, float bc2) {
     constexpr int LPR = D / 4, GPW = 64 / LPR, NWAVE = FUSED_THREADS / 64;
     // gradient rows in flight per lane group.  1024 threads leave 128 registers per lane; with Adam the row and its two
     // moments are in flight beside the gradients (12 registers): sixteen rows spilled 20 registers, twelve fit
@@ -174,18 +177,20 @@ __device__ __forceinline__ void fused_runs(Keys K, int m, const FusedUpdateParam
                 }
                 if (src < 0) continue;                                  // (a whole group: the row's lanes stay together)
                 const int kk = pos_of(src);
+                const FusedUpdateParams& p = params(kk);
                 const unsigned long long key = K[kk];
-                const unsigned long long row = key >> 24;
+                const unsigned long long row = key >> 24;              // what a run is a run of (fused_update_small: the table's bit on top)
+                const int64_t ri = params.row(key);                    // the row to address
                 const bool head = kk == 0 || (K[kk - 1] >> 24) != row;
                 const int chunk_end = min(m, (kk / RUN_CHUNK + 1) * RUN_CHUNK);
                 // the row and its moments are asked for before the gradient rows: one memory round trip, not two
                 const bool will_apply = pass == 1 || head;
                 f32x4 w = {0.f, 0.f, 0.f, 0.f}, mm = w, vv = w;
                 if (will_apply) {
-                    w = reinterpret_cast<const f32x4*>(p.table + (int64_t)row * D)[c];
+                    w = reinterpret_cast<const f32x4*>(p.table + ri * D)[c];
                     if (ADAM) {
-                        mm = reinterpret_cast<const f32x4*>(p.exp_avg + (int64_t)row * D)[c];
-                        vv = reinterpret_cast<const f32x4*>(p.exp_avg_sq + (int64_t)row * D)[c];
+                        mm = reinterpret_cast<const f32x4*>(p.exp_avg + ri * D)[c];
+                        vv = reinterpret_cast<const f32x4*>(p.exp_avg_sq + ri * D)[c];
                     }
                 }
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -238,15 +243,34 @@ __device__ __forceinline__ void fused_runs(Keys K, int m, const FusedUpdateParam
                 if (apply) {
                     row_update_math<D, ADAM>(w, mm, vv, acc, p.normalized, p.hp, bc1, bc2);
                     if (ADAM) {
-                        reinterpret_cast<f32x4*>(p.exp_avg + (int64_t)row * D)[c] = mm;
-                        reinterpret_cast<f32x4*>(p.exp_avg_sq + (int64_t)row * D)[c] = vv;
+                        reinterpret_cast<f32x4*>(p.exp_avg + ri * D)[c] = mm;
+                        reinterpret_cast<f32x4*>(p.exp_avg_sq + ri * D)[c] = vv;
                     }
-                    reinterpret_cast<f32x4*>(p.table + (int64_t)row * D)[c] = w;
+                    reinterpret_cast<f32x4*>(p.table + ri * D)[c] = w;
                 }
             }
         }
         __syncthreads();                // parked chunk sums are visible to the workgroup's other waves
     }
+}
+
+struct FusedOneTable {
+    const FusedUpdateParams& p;
+    __device__ __forceinline__ const FusedUpdateParams& operator()(int) const { return p; }
+    __device__ __forceinline__ int64_t row(unsigned long long key) const { return (int64_t)(key >> 24); }
+};
+// two lists end to end: positions below `split` are table A's; B's keys carry bit 60 (bit 36 of the row field), so that a run
+// never continues into an equal id of the other table
+static constexpr unsigned long long FUSED_ROW_MASK = (1ull << 36) - 1ull;
+struct FusedTwoTables {
+    const FusedUpdateParams &pa, &pb;
+    int split;
+    __device__ __forceinline__ const FusedUpdateParams& operator()(int k) const { return k < split ? pa : pb; }
+    __device__ __forceinline__ int64_t row(unsigned long long key) const { return (int64_t)((key >> 24) & FUSED_ROW_MASK); }
+};
+template <int D, bool ADAM, int NFLIGHT, class Keys>
+__device__ __forceinline__ void fused_runs(Keys K, int m, const FusedUpdateParams& p, float bc1, float bc2) {
+    fused_runs_of<D, ADAM, NFLIGHT>(K, m, FusedOneTable{p}, bc1, bc2);
 }
 
 // The work of ONE bucket `myb` by a workgroup of FUSED_THREADS threads; `lk`: FUSED_CAP keys of LDS.
@@ -347,56 +371,63 @@ __device__ __forceinline__ void fused_update_body(const FusedUpdateParams& p, co
     }
 }
 
-// EVERY bucket of a short list (n <= FUSED_SMALL_N, bucket_bits <= 3, ids < 2^37) by one workgroup in ONE pass -- the
-// one-launch step (mf_step_small.hip), where a bucket after a bucket would pay the table's memory latency once per bucket.
-// The result is the one update_fused_kernel's workgroups produce: the sorted lists of the buckets are laid end to end,
-// each starting at a multiple of RUN_CHUNK (the gap filled with FUSED_PAD), so that every run is cut into the same
-// chunks, summed in the same order, as in its own bucket's list.
+// EVERY bucket of TWO short lists (n <= FUSED_SMALL_N each, bucket_bits <= 3, ids < 2^36; threads [0, n) scan list A,
+// threads [512, 512 + n) list B) by one workgroup in ONE pass -- the one-launch step (mf_step_small.hip), where a bucket
+// after a bucket, a table after a table, would pay the memory latency of a row update once each.  The result is the one
+// update_fused_kernel's workgroups produce: the sorted lists of the buckets are laid end to end, each starting at a
+// multiple of RUN_CHUNK (the gap filled with FUSED_PAD), so that every run is cut into the same chunks, summed in the same
+// order, as in its own bucket's list.  `bias`: the two Adam bias corrections, evaluated by the caller.
 static constexpr int FUSED_SMALL_N = 256;
 template <int D, bool ADAM, int NFLIGHT>
-__device__ __forceinline__ void fused_update_small(const FusedUpdateParams& p, unsigned long long* lk) {
-    __shared__ int s_n, s_cnt[8], s_pad[8];
-    __shared__ float s_b[2];
+__device__ __forceinline__ void fused_update_small(const FusedUpdateParams& pa, const FusedUpdateParams& pb, const float* bias,
+                                                   unsigned long long* lk) {
+    __shared__ int s_n[2], s_cnt[16], s_pad[17];
     const int tid = threadIdx.x;
+    const float bc1 = ADAM ? bias[0] : 1.f, bc2 = ADAM ? bias[1] : 1.f;      // (read first: `bias` may lie inside `lk`)
     __syncthreads();
-    if (tid < 8) s_cnt[tid] = 0;
-    if (tid == 8) s_n = 0;
+    if (tid < 16) s_cnt[tid] = 0;
+    if (tid < 2) s_n[tid] = 0;
     __syncthreads();
+    unsigned long long* raw[2] = {lk, lk + FUSED_SMALL_N};
     {
-        const long long id = tid < p.n ? p.idx[tid] : -1;
-        if (ADAM && tid == FUSED_THREADS - 64) {
-            float b1, b2;
-            adam_bias(p.hp, b1, b2);
-            s_b[0] = b1; s_b[1] = b2;
-        }
+        const int which = tid >> 9, t = tid & 511;                   // (wave-uniform)
+        const FusedUpdateParams& p = which ? pb : pa;
+        const long long id = t < p.n ? p.idx[t] : -1;
         const bool mine = id >= 0 && id < p.n_rows;
         const unsigned b = mine ? fused_bucket(id, p.bucket_bits) : 0u;
-        fused_append(mine, ((unsigned long long)b << 61) | ((unsigned long long)id << 24) | (unsigned)tid, &s_n, lk, FUSED_SMALL_N);
-        if (mine) atomicAdd(&s_cnt[b], 1);
+        fused_append(mine, ((unsigned long long)b << 61) | ((unsigned long long)which << 60) | ((unsigned long long)id << 24) | (unsigned)t, &s_n[which], raw[which],
+                     FUSED_SMALL_N);
+        if (mine) atomicAdd(&s_cnt[8 * which + b], 1);
     }
     __syncthreads();
-    const int m = s_n;
+    const int ma = s_n[0], mb = s_n[1];
     if (tid == 0) {
-        int pad = 0;
-        for (int b = 0; b < 8; ++b) {
-            s_pad[b] = pad;                                           // padding keys in front of bucket b's segment
-            pad += (RUN_CHUNK - s_cnt[b] % RUN_CHUNK) % RUN_CHUNK;
+        int at = 0;                                                  // where bucket b's segment starts: a multiple of RUN_CHUNK
+        for (int b = 0; b < 16; ++b) {
+            s_pad[b] = at;
+            at += (s_cnt[b] + RUN_CHUNK - 1) / RUN_CHUNK * RUN_CHUNK;
+        }
+        s_pad[16] = at;
+    }
+    unsigned long long* sorted = lk + FUSED_CAP / 2;
+    for (int t = tid; t < 2 * FUSED_SMALL_N + 16 * RUN_CHUNK; t += FUSED_THREADS) sorted[t] = FUSED_PAD;
+    __syncthreads();
+    if (ma + mb == 0) return;
+    {
+        const int which = tid >> 9, t = tid & 511;
+        const int m = which ? mb : ma;
+        if (t < m) {
+            const unsigned long long* list = raw[which];
+            const unsigned long long mine = list[t];
+            const unsigned b = (unsigned)(mine >> 61);
+            int below = 0;                                           // keys of MY bucket below mine: the rank inside the segment
+            for (int j = 0; j < m; ++j) below += ((list[j] >> 61) == b && list[j] < mine) ? 1 : 0;
+            sorted[s_pad[8 * which + b] + below] = mine & ((1ull << 61) - 1ull);
         }
     }
-    const float bc1 = ADAM ? s_b[0] : 1.f, bc2 = ADAM ? s_b[1] : 1.f;
-    unsigned long long* sorted = lk + FUSED_CAP / 2;
-    for (int t = tid; t < FUSED_SMALL_N + 8 * RUN_CHUNK; t += FUSED_THREADS) sorted[t] = FUSED_PAD;
     __syncthreads();
-    if (m == 0) return;
-    if (tid < m) {
-        const unsigned long long mine = lk[tid];
-        int rank = 0;
-        for (int j = 0; j < m; ++j) rank += lk[j] < mine ? 1 : 0;
-        sorted[rank + s_pad[mine >> 61]] = mine & ((1ull << 61) - 1ull);
-    }
-    __syncthreads();
-    int total = m + s_pad[7];                                         // (the last bucket's tail needs no padding)
-    fused_runs<D, ADAM, NFLIGHT>(sorted, total, p, bc1, bc2);
+    const int split = s_pad[8], total = s_pad[16];
+    fused_runs_of<D, ADAM, NFLIGHT>(sorted, total, FusedTwoTables{pa, pb, split}, bc1, bc2);
 }
 
 template <int D, bool ADAM>

@@ -39,6 +39,5 @@ for reps in (200, 2000):
 
 torch.cuda.synchronize()
 st = step._ws[:128].view(torch.int64).cpu().tolist()
-names = ["gather", "norms + id table", "masks", "logits + mining + rows", "losses", "backward", "item update", "user update"]
-print("phases of the last step (us): " + ", ".join(f"{n} {(st[i + 1] - st[i]) / 100:.1f}" for i, n in enumerate(names)) + f"; total {(st[8] - st[0]) / 100:.1f}")
-print("inside phase 4, wave 0 (1/100 us since the phase began):", [st[i] - st[3] for i in (9, 10, 11, 12)], {k: (tuple(v.shape) if hasattr(v, "shape") else type(v).__name__) for k, v in batches[0].items()})
+names = ["ids + id table", "masks (under the rows' latency)", "rows + normalise", "norms", "logits + mining + rows", "losses", "backward", "both updates"]
+print("phases of the last step (us): " + ", ".join(f"{n} {(st[i + 1] - st[i]) / 100:.1f}" for i, n in enumerate(names)) + f"; total {(st[len(names)] - st[0]) / 100:.1f}")
