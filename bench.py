@@ -268,12 +268,12 @@ def timed(fn, n_steps: int, dist_on: bool) -> float:
 
 
 def measured_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r02_traffic.json: rocprofv3 --pmc
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rNN_traffic.json, the latest round: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).
     The file records the fingerprint of the kernel sources it was measured on: a figure of other sources is not
     quoted (None)."""
     try:
-        data = json.loads((ROOT / "profiles" / "r02_traffic.json").read_text())
+        data = json.loads(sorted((ROOT / "profiles").glob("r*_traffic.json"))[-1].read_text())     # the latest round's
         if data.get("csrc_sha") != csrc_sha():
             return None
         return data["kernels"][kernel]["hbm_bytes_per_launch"]
@@ -728,21 +728,22 @@ def main() -> None:
         def brief(leg, batch, dim, optimizer="adam"):
             roof = train_roofline(leg["spans"], batch, dim, 1, optimizer)
             return {"ms_per_step": round(leg["ms_per_step"], 4), "pairs_per_s": round(leg["pairs_per_s"], 1),
+                    **({"reps_ms_per_step": spread(leg["reps_ms"])} if len(leg.get("reps_ms", ())) > 1 else {}),
                     "roofline": None if roof is None else {k: roof[k] for k in ("kernel", "achieved", "frac", "avg_ms", "all_sweeps_frac", "hbm_kernels")}}
 
         extras["q_small"] = topk_small_leg(mf, lib, index, device, DIM, rank)
         del index
         # the reference's DEFAULT training configuration (xfmr_rec/lightning.py:38-39): PairwiseHingeLoss, num_negatives = 4
-        leg = run_train_leg(mf, lib, device, batch=B, steps=40, warmup=5, loss="PairwiseHingeLoss", num_negatives=4, use_logq=False)
+        leg = run_train_leg(mf, lib, device, batch=B, steps=40, warmup=5, loss="PairwiseHingeLoss", num_negatives=4, use_logq=False, reps=3)
         extras["mined"] = {"workload": "C3 shape, PairwiseHingeLoss, num_negatives=4 (reference default loss), row-adam",
                            **brief(leg, B, DIM)}
         del leg
         # config C2: MovieLens-1M shape, d = 64, in-batch sampled softmax
-        leg = run_train_leg(mf, lib, device, batch=B, steps=40, warmup=5, num_users=6041, num_items=3884, dim=64, use_logq=False)
+        leg = run_train_leg(mf, lib, device, batch=B, steps=40, warmup=5, num_users=6041, num_items=3884, dim=64, use_logq=False, reps=3)
         extras["c2_ml1m_d64"] = {"workload": "C2: MovieLens-1M shape (6,040 x 3,883), d=64, InfoNCE, row-adam", **brief(leg, B, 64)}
         del leg
         # positive lists of 1024 ids per user (SURVEY 8d stress)
-        leg = run_train_leg(mf, lib, device, batch=B, steps=20, warmup=3, pos_pad=1024)
+        leg = run_train_leg(mf, lib, device, batch=B, steps=20, warmup=3, pos_pad=1024, reps=3)
         extras["pos_pad_1024"] = {"workload": "C3 shape, InfoNCE + logQ, P = 1024 padded positives per user", **brief(leg, B, DIM)}
         del leg
         # ALL of a user's positives, as the reference passes them (data/lightning.py:274-280), at MovieLens-25M's list-length

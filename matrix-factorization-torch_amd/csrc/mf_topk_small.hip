@@ -277,6 +277,7 @@ __global__ __launch_bounds__(64 * SQ_SEL_WAVES) void topk_small_select_kernel(co
         const unsigned long long tau0 = m >= k ? mn : 1ull;          // fewer than k maxima: every key passes
         if (lane == 0) tau_s = tau0;
         // the winning blocks (about k of them), by the same wave: no second trip to memory for a catalog of <= 1024 blocks
+        int listed = 0;
         for (int64_t base = 0; base < nblocks; base += 64 * 16) {
             if (nblocks > 64 * 16) {
 #pragma unroll
@@ -286,32 +287,41 @@ __global__ __launch_bounds__(64 * SQ_SEL_WAVES) void topk_small_select_kernel(co
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < 16; ++j) {                  // (one wave: the list's fill count is a scalar, no atomics)
                 const bool hit = v[j] != 0ull && v[j] >= tau0;
                 const unsigned long long bal = __ballot(hit);
-                if (bal) {
-                    int at = 0;
-                    if (lane == 0) at = atomicAdd(&wl_n, __popcll(bal));
-                    at = __shfl(at, 0, 64) + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (hit && at < SQ_ROUND_BLOCKS) wlist[at] = (int)(base + lane + 64 * j);
-                }
+                const int at = listed + __popcll(bal & ((1ull << lane) - 1ull));
+                if (hit && at < SQ_ROUND_BLOCKS) wlist[at] = (int)(base + lane + 64 * j);
+                listed += __popcll(bal);
             }
         }
+        if (lane == 0) wl_n = listed;
     }
     __syncthreads();
     const unsigned long long tau = tau_s;
     // (b) + (c) for the W blocks in wlist: candidates into LDS, wave 0 merges them into the winners so far
     auto round = [&](int W) {
-        for (int t = wave; t < W; t += SQ_SEL_WAVES) {
-            const int64_t row = (int64_t)wlist[t] * 64 + lane;
-            const float sc = scores[(size_t)q * nblocks * 64 + row];
-            const unsigned long long key = __builtin_bit_cast(unsigned, sc) == SQ_NOKEY ? 0ull : mf_key_retrieval(sc, (unsigned)row);
-            const bool keep = key != 0ull && key >= tau;
-            const unsigned long long mk = __ballot(keep);
-            int base = 0;
-            if (lane == 0 && mk) base = atomicAdd(&cand_n, __popcll(mk));
-            base = __shfl(base, 0, 64);
-            if (keep) cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = key;
+        // a wave's blocks eight at a time: their scores are asked for together (one memory round trip, not one per block)
+        for (int t0 = wave; t0 < W; t0 += SQ_SEL_WAVES * 8) {
+            float sc[8];
+            int64_t rows[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = t0 + j * SQ_SEL_WAVES;
+                rows[j] = (int64_t)wlist[t < W ? t : t0] * 64 + lane;
+                sc[j] = scores[(size_t)q * nblocks * 64 + rows[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (t0 + j * SQ_SEL_WAVES >= W) break;                  // (wave-uniform)
+                const unsigned long long key = __builtin_bit_cast(unsigned, sc[j]) == SQ_NOKEY ? 0ull : mf_key_retrieval(sc[j], (unsigned)rows[j]);
+                const bool keep = key != 0ull && key >= tau;
+                const unsigned long long mk = __ballot(keep);
+                int base = 0;
+                if (lane == 0 && mk) base = atomicAdd(&cand_n, __popcll(mk));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (keep) cand[base + __popcll(mk & ((1ull << lane) - 1ull))] = key;
+            }
         }
         __syncthreads();
         if (wave == 0) {

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round profiles on the GPU box (run through gpurun from the repository root):
-#   bash tools/collect_profiles.sh r02
+#   bash tools/collect_profiles.sh r03
 # kernel trace + stats of the default bench.py run, then three PMC passes (SQ counters, FETCH_SIZE, WRITE_SIZE; counters in
 # their own runs, no trace domains beside them), summarised into gpurun_out/profiles_<round>/ -- copy into profiles/.
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1

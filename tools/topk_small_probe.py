@@ -26,14 +26,14 @@ for n, d in ((62423, 128), (1_000_000, 128), (62423, 64)):
         ids = torch.randint(0, n, (int(lens.sum()),), generator=g).to(dev)
         for csr in (None, (off, ids)):
             for _ in range(20):
-                index.search(queries, 20, exclude_csr=csr)
+                index.search(queries, 20, exclude_csr=csr, path="scan")
             torch.cuda.synchronize()
             lib.mf_timing_reset()
             lib.mf_timing_enable(1)
             reps = 200
             t0 = time.perf_counter()
             for _ in range(reps):
-                index.search(queries, 20, exclude_csr=csr)
+                index.search(queries, 20, exclude_csr=csr, path="scan")
             torch.cuda.synchronize()
             wall = (time.perf_counter() - t0) / reps
             lib.mf_timing_enable(0)
@@ -41,4 +41,4 @@ for n, d in ((62423, 128), (1_000_000, 128), (62423, 64)):
             cnt = lib.mf_timing_get(b"topk_small", ctypes.byref(tot))
             us = tot.value / max(cnt, 1) * 1e3
             print(f"N={n} d={d} Q={q:2d} excl={'yes' if csr else 'no ':3s}: device {us:7.2f} us/call  "
-                  f"({n * d * 4 / us / 1e3:7.1f} GB/s of catalog), wall {wall * 1e6:7.1f} us/call", flush=True)
+                  f"({n * d * 4 / max(us, 1e-9) / 1e3:7.1f} GB/s of catalog), wall {wall * 1e6:7.1f} us/call", flush=True)
