@@ -204,7 +204,7 @@ int mf_update_adam(float* table, float* exp_avg, float* exp_avg_sq, int64_t n_ro
  * (xfmr_rec/lightning.py:38-39): a step of ~0.5 MFLOP that the multi-kernel path spends in launch latency.  mf_step_small
  * runs the WHOLE training step -- mf_gather_rows of both towers, mf_loss_fwd (all kinds of kind_mask into out_losses[7]),
  * mf_loss_bwd of `kind` with upstream gradient 1, mf_update_sgd / mf_update_adam of both tables -- in ONE workgroup and one
- * launch, for B <= 128 pairs, N <= 256 columns and a mined loss (0 < num_negatives <= 64 < N).  Results (losses, both
+ * launch, for B <= 128 pairs, N <= 256 columns, tables of < 2^36 rows and a mined loss (0 < num_negatives <= 64, < N).  Results (losses, both
  * tables, Adam moments) are bit-identical to that sequence of calls.  Positives: padded pos_idx[B, P], or -- pos_off != NULL --
  * CSR lists indexed by user_ids (see mf_loss_fwd_csr).  adam = 0: SGD (lr, weight_decay); else lazy row-wise AdamW with the
  * global step by value or from step_dev.  MF_ENOTSUP for shapes / losses outside that range (callers fall back). */
