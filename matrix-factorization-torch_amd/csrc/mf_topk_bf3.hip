@@ -364,24 +364,47 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
                         gm[xt] = __builtin_amdgcn_fmed3f(gm[xt], x, __builtin_inff());
                     }
                 } else {
-                    // bit e: element e is above the bound.  Two instructions per element: the sign of thr - score is shifted in
-                    // (v_alignbit), last element first; "score > thr" instead of ">=" is why thr is nudged down by the bound kernel
+                    // bit e: element e reaches the bound.  The accumulators START at -thr (the matrix core does the subtraction: a
+                    // lane's 16 elements are one query's), so ONE instruction per element shifts the sign of score - thr in
+                    // (v_alignbit), last element first; sign clear = hit.  (The extra rounding of the accumulation from -thr is
+                    // inside eps' allowance for the accumulations, bf3_bound_kernel.)
                     uint32_t hm = 0u;
+                    // (the whole vector is bit-cast, THEN indexed: `bit_cast<uint32_t>(acc[e])` -- a bit-cast of an extracted element --
+                    // is folded to element 0 by this compiler, the same family as the permlane swap fold in mf_common.h)
+                    typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+                    const u32x16_t ab = __builtin_bit_cast(u32x16_t, acc);
 #pragma unroll
-                    for (int e = 15; e >= 0; --e) hm = __builtin_amdgcn_alignbit(hm, __builtin_bit_cast(uint32_t, thr[xt] - acc[e]), 31);
-                    hm &= 0xFFFFu & ~m;
+                    for (int e = 15; e >= 0; --e) hm = __builtin_amdgcn_alignbit(hm, ab[e], 31);
+                    hm = ~hm & 0xFFFFu & ~m;
                     hmw[xt >> 1] |= hm << (16 * (xt & 1));
                 }
             };
-            if constexpr (D <= 128) {
+            if constexpr (D <= 128 && PASS == 1 && XT > 1) {
+                // the full scan at XT = 4 sits at the 256-register line: ONE accumulator set (its 16-instruction epilogue is short,
+                // and the SIMD's other wave has matrix work for the gap)
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) {
+                    f32x16 acc;
+                    float nt = -thr[xt];
+                    asm volatile("" : "+v"(nt));       // (per tile: a loop-invariant 16-register splat per query tile would be hoisted and kept)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = nt;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], xb[xt][s], acc, 0, 0, 0);
+                    epi(xt, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (D <= 128) {
                 // two accumulator sets: the epilogue of query tile xt - 1 is threaded between the MFMAs of query tile xt
                 f32x16 accA, accB;
 #pragma unroll
                 for (int xt = 0; xt < XT; ++xt) {
                     f32x16& cur = (xt & 1) ? accB : accA;
                     const f32x16& prev = (xt & 1) ? accA : accB;
+                    float nt = PASS == 1 ? -thr[xt] : 0.f;
+                    if (PASS == 1) asm volatile("" : "+v"(nt));
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) cur[e] = 0.f;
+                    for (int e = 0; e < 16; ++e) cur[e] = nt;
 #pragma unroll
                     for (int s = 0; s < KS; ++s) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], xb[xt][s], cur, 0, 0, 0);
                     if (xt > 0) {
@@ -389,7 +412,7 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
 #pragma unroll
                         for (int s = 0; s < KS; ++s) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x006, 64 / KS, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x006, (PASS == 1 ? 32 : 64) / KS, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -401,8 +424,10 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
 #pragma unroll
                 for (int xt = 0; xt < XT; ++xt) {
                     f32x16 acc;
+                    float nt = PASS == 1 ? -thr[xt] : 0.f;
+                    if (PASS == 1) asm volatile("" : "+v"(nt));
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                    for (int e = 0; e < 16; ++e) acc[e] = nt;
 #pragma unroll
                     for (int s0 = 0; s0 < KS; s0 += KH) {
 #pragma unroll
@@ -552,25 +577,32 @@ __device__ __forceinline__ float bf3_exact_dot(const float* xq, const float* __r
     return acc;
 }
 
+// One wave per query.  (Two waves sharing the rescoring rounds measured SLOWER, 19.2 -> 22.6 us: 45 KB of LDS per workgroup
+// leave 3 workgroups per CU, and 1024 queries no longer run in one round of workgroups.)
+static constexpr int BF3_FWAVES = 1;
 template <int D>
-__global__ __launch_bounds__(64) void bf3_final_kernel(Bf3Final p) {
+__global__ __launch_bounds__(64 * BF3_FWAVES) void bf3_final_kernel(Bf3Final p) {
     constexpr int CH = 64;                                   // floats of a row staged at a time (the chain runs chunk after chunk)
     constexpr int ROWF = CH + 4;                             // LDS row stride in floats: + 16 bytes, so 16 lanes reading 16 bytes at the
                                                              // same offset of 16 different rows hit 64 different banks
-    __shared__ __attribute__((aligned(16))) float rows_lds[64 * ROWF];      // 17 KiB: six of these workgroups fit a CU
+    __shared__ __attribute__((aligned(16))) float rows_all[BF3_FWAVES * 64 * ROWF];      // 17 KiB per wave
+    __shared__ int s_n, s_overflow;
     __shared__ unsigned long long keys[BF3_CAND];
     __shared__ unsigned long long win[64], sorted[64];
     __shared__ __attribute__((aligned(16))) float xq[256];
     const int64_t r = blockIdx.x;
-    const int lane = mf_lane();
+    const int lane = mf_lane(), wave = mf_wave_id();
+    float* rows_lds = rows_all + wave * 64 * ROWF;
     const unsigned long long below = (1ull << lane) - 1ull;
+    int n = 0;
+    bool overflow = false;
+    if (wave == 0) {
     // everything the wave needs first, in ONE round trip: the query, the overflow counters, its 16 bytes (two lane halves x
     // BF3_SLOTS rows) of every scan workgroup's candidate block
     static_assert(BF3_SLOTS == 2, "one 16-byte load = the two lane halves of a block");
     for (int i = lane; i < p.d; i += 64) xq[i] = p.q[r * p.d + i];
     const int novf = p.ovf_cnt[r];
-    bool overflow = p.ovf[r] != 0 || novf > BF3_OVF;
-    int n = 0;
+    overflow = p.ovf[r] != 0 || novf > BF3_OVF;
     for (int j0 = 0; j0 < p.nlists; j0 += 64 * 4) {          // four 16-byte loads in flight per lane (256 blocks: one trip)
         uint4 v4[4];
 #pragma unroll
@@ -603,8 +635,12 @@ __global__ __launch_bounds__(64) void bf3_final_kernel(Bf3Final p) {
     }
     overflow = overflow || n > BF3_CAND;
     if (p.dbg && lane == 0) { atomicAdd(p.dbg, (unsigned long long)n); atomicAdd(p.dbg + 1, 1ull); }
+    if (lane == 0) { s_n = n; s_overflow = overflow ? 1 : 0; }
+    }
     __syncthreads();
-    int m;
+    n = s_n;
+    overflow = s_overflow != 0;
+    int m = 0;
     if (!overflow) {
         // Exact rescoring, 64 candidates a round.  The rows are fetched by the WAVE -- D/4 lanes per row, whole 512-byte rows
         // per half-wave instruction -- into LDS, then every lane runs the canonical chain over ITS candidate's row from there
@@ -612,40 +648,59 @@ __global__ __launch_bounds__(64) void bf3_final_kernel(Bf3Final p) {
         // 6.7 us per round).  A candidate on the query's exclusion list gets no key (the scan does not look at exclusions).
         constexpr int LPR = CH / 4, RPI = 64 / LPR;          // lanes per row chunk (256 bytes), rows per load instruction
         const uint32_t* xrow = p.exclW ? p.exclW + r * p.NTp : nullptr;
-        for (int base = 0; base < n && !(p.abl & 8); base += 64) {
-            const bool have = base + lane < n;
-            const unsigned row = have ? (unsigned)keys[base + lane] : 0u;
-            bool ex = false;
-            if (have && xrow) ex = (xrow[row >> 5] >> (row & 31)) & 1u;
-            const float* row_l = rows_lds + lane * ROWF;
-            float acc = 0.f;
+        // Stages = (round of 64 candidates) x (chunk of CH floats), software-pipelined one deep: the loads of stage s + 1 are in
+        // flight while stage s is copied to LDS and consumed -- a round trip per ROUND instead of one per chunk (and the
+        // second round's first chunk travels under the first round's last).
+        constexpr int NCH = D / CH;
+        const int rounds = (p.abl & 8) ? 0 : (n + 63) / 64;
+        const int S = rounds * NCH;
+        auto issue = [&](int st, f32x4 (&ld)[64 / RPI]) {
+            const int base = (st / NCH) * 64, c0 = (st % NCH) * CH;
 #pragma unroll
-            for (int c0 = 0; c0 < D; c0 += CH) {
-                f32x4 ld[64 / RPI];
+            for (int it = 0; it < 64 / RPI; ++it) {
+                const int sel = it * RPI + lane / LPR;
+                ld[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (base + sel < n) ld[it] = *reinterpret_cast<const f32x4*>(p.items + (int64_t)(unsigned)keys[base + sel] * D + c0 + 4 * (lane % LPR));
+            }
+        };
+        const float* row_l = rows_lds + lane * ROWF;
+        float acc = 0.f;
+        unsigned row = 0u;
+        bool have = false, ex = false;
+        auto consume = [&](int st, f32x4 (&ld)[64 / RPI]) {
+            const int base = (st / NCH) * 64, c0 = (st % NCH) * CH;
+            if (c0 == 0) {                                   // a round begins: this lane's candidate
+                have = base + lane < n;
+                row = have ? (unsigned)keys[base + lane] : 0u;
+                ex = have && xrow ? ((xrow[row >> 5] >> (row & 31)) & 1u) != 0u : false;
+                acc = 0.f;
+            }
 #pragma unroll
-                for (int it = 0; it < 64 / RPI; ++it) {
-                    const int sel = it * RPI + lane / LPR;
-                    ld[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (base + sel < n) ld[it] = *reinterpret_cast<const f32x4*>(p.items + (int64_t)(unsigned)keys[base + sel] * D + c0 + 4 * (lane % LPR));
-                }
-                if (c0) __syncthreads();                   // (the previous chunk has been consumed by every lane)
-#pragma unroll
-                for (int it = 0; it < 64 / RPI; ++it)
-                    *reinterpret_cast<f32x4*>(rows_lds + (it * RPI + lane / LPR) * ROWF + 4 * (lane % LPR)) = ld[it];
-                __syncthreads();
+            for (int it = 0; it < 64 / RPI; ++it)
+                *reinterpret_cast<f32x4*>(rows_lds + (it * RPI + lane / LPR) * ROWF + 4 * (lane % LPR)) = ld[it];
+            __syncthreads();
 #pragma unroll 4
-                for (int g = 0; g < CH; g += 8) {            // k order of mf_dot_chain
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(row_l + g), b = *reinterpret_cast<const f32x4*>(row_l + g + 4);
-                    const f32x4 xa = *reinterpret_cast<const f32x4*>(xq + c0 + g), xb = *reinterpret_cast<const f32x4*>(xq + c0 + g + 4);
+            for (int g = 0; g < CH; g += 8) {                // k order of mf_dot_chain
+                const f32x4 a = *reinterpret_cast<const f32x4*>(row_l + g), b = *reinterpret_cast<const f32x4*>(row_l + g + 4);
+                const f32x4 xa = *reinterpret_cast<const f32x4*>(xq + c0 + g), xb = *reinterpret_cast<const f32x4*>(xq + c0 + g + 4);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        acc = __builtin_fmaf(xa[t], a[t], acc);
-                        acc = __builtin_fmaf(xb[t], b[t], acc);
-                    }
+                for (int t = 0; t < 4; ++t) {
+                    acc = __builtin_fmaf(xa[t], a[t], acc);
+                    acc = __builtin_fmaf(xb[t], b[t], acc);
                 }
             }
-            __syncthreads();
-            if (have) keys[base + lane] = ex ? 0ull : mf_key_retrieval(acc, row);
+            __syncthreads();                                 // (the chunk has been consumed by every lane; the row ids of this round are read)
+            if (c0 + CH == D && have) keys[base + lane] = ex ? 0ull : mf_key_retrieval(acc, row);
+        };
+        f32x4 ldA[64 / RPI], ldB[64 / RPI];
+        if (S > 0) issue(0, ldA);
+        for (int st = 0; st < S; st += 2) {
+            if (st + 1 < S) issue(st + 1, ldB);
+            consume(st, ldA);
+            if (st + 1 < S) {
+                if (st + 2 < S) issue(st + 2, ldA);
+                consume(st + 1, ldB);
+            }
         }
         __syncthreads();
         if (p.abl & 16) m = 0;
@@ -823,9 +878,9 @@ extern "C" int mf_topk_bf3(const float* q, int64_t Q, const float* items, const 
         else bf3_run<256>(w, sp, excl, k, q, ix.ymax2, s);
         Bf3Final fp{q, items, N, d, k, w.plan.NT, w.plan.NTp, w.plan.Qp, w.plan.nwg * (BF3_WAVES / w.plan.xw), w.cand, w.ovf_list, w.ovf_cnt, w.ovf,
                     excl ? w.exclW : nullptr, idx_base, out_scores, out_idx, sp.abl, g_bf3_dbg};
-        if (d == 64) bf3_final_kernel<64><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
-        else if (d == 128) bf3_final_kernel<128><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
-        else bf3_final_kernel<256><<<dim3((unsigned)Q), 64, 0, s>>>(fp);
+        if (d == 64) bf3_final_kernel<64><<<dim3((unsigned)Q), 64 * BF3_FWAVES, 0, s>>>(fp);
+        else if (d == 128) bf3_final_kernel<128><<<dim3((unsigned)Q), 64 * BF3_FWAVES, 0, s>>>(fp);
+        else bf3_final_kernel<256><<<dim3((unsigned)Q), 64 * BF3_FWAVES, 0, s>>>(fp);
     });
     return mf_check_launch("mf_topk_bf3");
 }
