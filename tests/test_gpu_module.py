@@ -325,7 +325,10 @@ def test_captured_step_replays_bit_identically(mf, cfg):
 @pytest.mark.parametrize("cfg", [("adam", "PairwiseHingeLoss", 4, 32, 32, False, False), ("adam", "PairwiseHingeLoss", 4, 32, 128, True, False),
                                  ("sgd", "InfomationNoiseContrastiveEstimationLoss", 8, 128, 64, False, True),
                                  ("adam", "MutualInformationNeuralEstimationLoss", 64, 100, 256, True, True),
-                                 ("sgd", "ContrastiveLoss", 1, 5, 32, False, False)],
+                                 ("sgd", "ContrastiveLoss", 1, 5, 32, False, False),
+                                 ("adam", "AlignmentContrastiveLoss", 3, 7, 32, False, True),           # N = 14: less than one tile
+                                 ("sgd", "PairwiseLogisticLoss", 2, 64, 128, True, False),
+                                 ("adam", "InfomationNoiseContrastiveEstimationLoss", 16, 128, 32, False, False)],   # the largest batch
                          ids=lambda c: "-".join(map(str, c)))
 def test_fused_small_step_is_bit_identical_to_the_multi_kernel_step(mf, cfg):
     """The reference's default step (B = 32, PairwiseHinge, 4 mined negatives, AdamW; xfmr_rec/params.py:18, lightning.py:38-39)
