@@ -210,7 +210,12 @@ __device__ __forceinline__ unsigned mf_wave_max_u32(unsigned x) {
 __device__ __forceinline__ unsigned long long mf_wave_max_u64(unsigned long long x) {
     const unsigned hi = (unsigned)(x >> 32), lo = (unsigned)x;
     const unsigned mh = mf_wave_max_u32(hi);
-    const unsigned ml = mf_wave_max_u32(hi == mh ? lo : 0u);
+    const unsigned long long holders = __ballot(hi == mh);
+    unsigned ml;
+    if (__popcll(holders) == 1)                                 // (wave-uniform) the usual case: one lane holds the largest high word
+        ml = (unsigned)__builtin_amdgcn_readlane((int)lo, __builtin_ctzll(holders));
+    else
+        ml = mf_wave_max_u32(hi == mh ? lo : 0u);
     return ((unsigned long long)mh << 32) | ml;
 }
 __device__ __forceinline__ float mf_group_sum(float x, int width) {  // width: power of two <= 64 (a constant at every call site)

@@ -151,6 +151,7 @@ __device__ __forceinline__ void fused_runs_of(Keys K, int m, Params params, floa
     constexpr int NF = NFLIGHT;      // (rows are added in order whatever NF is: the sums do not depend on it)
     const int lane = mf_lane(), wave = threadIdx.x >> 6;
     const int grp = lane / LPR, c = lane % LPR;
+    int parked = 0;                     // this thread left a chunk sum for the second pass
     for (int pass = 0; pass < 2; ++pass) {
         for (int k0 = 0; k0 < m; k0 += FUSED_THREADS) {
             auto pos_of = [&](int ln) { return k0 + ln * NWAVE + ((wave - (k0 >> 5) - (ln >> 1)) & (NWAVE - 1)); };
@@ -218,7 +219,7 @@ __device__ __forceinline__ void fused_runs_of(Keys K, int m, Params params, floa
                     }
                     for (; q < e; ++q) acc += reinterpret_cast<const f32x4*>(p.grad + (int64_t)((unsigned)K[q] & FUSED_POS_MASK) * D)[c];
                     apply = head && (e >= m || (K[e] >> 24) != row);    // the run is this one chunk
-                    if (!apply) reinterpret_cast<f32x4*>(park)[c] = acc;
+                    if (!apply) { reinterpret_cast<f32x4*>(park)[c] = acc; parked = 1; }
                 } else {
                     acc = reinterpret_cast<const f32x4*>(park)[c];
                     int q = chunk_end;
@@ -250,7 +251,9 @@ __device__ __forceinline__ void fused_runs_of(Keys K, int m, Params params, floa
                 }
             }
         }
-        __syncthreads();                // parked chunk sums are visible to the workgroup's other waves
+        // parked chunk sums are visible to the workgroup's other waves -- and when nobody parked one (no run longer than a
+        // chunk: the usual batch) there is no second pass; nor a barrier behind it (every caller begins with one)
+        if (pass == 0 && !__syncthreads_or(parked)) return;
     }
 }
 
@@ -314,7 +317,13 @@ __device__ __forceinline__ void fused_update_body(const FusedUpdateParams& p, co
         if (tid < m) {
             const unsigned long long mine = lk[tid];
             int rank = 0;
-            for (int j = 0; j < m; ++j) rank += lk[j] < mine ? 1 : 0;
+            for (int j0 = 0; j0 < m; j0 += 8) {                      // (eight broadcast reads in flight)
+                unsigned long long o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = lk[j0 + u < m ? j0 + u : tid];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rank += o[u] < mine ? 1 : 0;
+            }
             sorted[rank] = mine;
         }
         __syncthreads();
@@ -410,19 +419,41 @@ __device__ __forceinline__ void fused_update_small(const FusedUpdateParams& pa, 
         s_pad[16] = at;
     }
     unsigned long long* sorted = lk + FUSED_CAP / 2;
+    int* rk = reinterpret_cast<int*>(lk + 2 * FUSED_SMALL_N);         // [2][FUSED_SMALL_N] ranks inside the segments
     for (int t = tid; t < 2 * FUSED_SMALL_N + 16 * RUN_CHUNK; t += FUSED_THREADS) sorted[t] = FUSED_PAD;
+    for (int t = tid; t < 2 * FUSED_SMALL_N; t += FUSED_THREADS) rk[t] = 0;
     __syncthreads();
     if (ma + mb == 0) return;
+    {
+        // ranks inside the bucket segments: a key's m comparisons are dealt to 512 / (m rounded up to 64) threads (m <= 64:
+        // one batch of 8 broadcast reads each), partial counts meet in LDS
+        const int which = tid >> 9, t5 = tid & 511;
+        const int m = which ? mb : ma;
+        const int mw = ((m + 63) & ~63) > 0 ? ((m + 63) & ~63) : 64, parts = 512 / mw;      // (mw in {64, 128, 192, 256}: parts 8, 4, 2, 2)
+        const int t = t5 % mw, part = t5 / mw;
+        if (t < m && part < parts) {
+            const unsigned long long* list = raw[which];
+            const unsigned long long mine = list[t];
+            const unsigned b = (unsigned)(mine >> 61);
+            const int per = (m + parts - 1) / parts, j_lo = part * per, j_hi = min(m, j_lo + per);
+            int below = 0;
+            for (int j0 = j_lo; j0 < j_hi; j0 += 8) {
+                unsigned long long o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = list[j0 + u < j_hi ? j0 + u : t];      // (own key: neither below nor counted)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) below += ((o[u] >> 61) == b && o[u] < mine) ? 1 : 0;
+            }
+            if (below) atomicAdd(&rk[which * FUSED_SMALL_N + t], below);
+        }
+    }
+    __syncthreads();
     {
         const int which = tid >> 9, t = tid & 511;
         const int m = which ? mb : ma;
         if (t < m) {
-            const unsigned long long* list = raw[which];
-            const unsigned long long mine = list[t];
-            const unsigned b = (unsigned)(mine >> 61);
-            int below = 0;                                           // keys of MY bucket below mine: the rank inside the segment
-            for (int j = 0; j < m; ++j) below += ((list[j] >> 61) == b && list[j] < mine) ? 1 : 0;
-            sorted[s_pad[8 * which + b] + below] = mine & ((1ull << 61) - 1ull);
+            const unsigned long long mine = raw[which][t];
+            sorted[s_pad[8 * which + (unsigned)(mine >> 61)] + rk[which * FUSED_SMALL_N + t]] = mine & ((1ull << 61) - 1ull);
         }
     }
     __syncthreads();
