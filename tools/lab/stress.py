@@ -1,6 +1,7 @@
 """Randomised cross-checks of the round-2 kernels (not part of the test suite: minutes of GPU time).
   * top-k: the three retrieval paths (fp32 tiles, few-query scan, bf16 prefilter) must return the same bits on random
     shapes -- Q, N (incl. N % 32 != 0 and tiny N), d, k, exclusion lists, idx_base, duplicate rows, scaled norms;
+  * the one-launch training step against the multi-kernel step (torch.equal) on random small shapes;
   * sparse update: the one-launch path against the oracle's coalesced row-Adam on random id multisets (Zipf, uniform,
     one dominant id, out-of-range ids), and bit-reproducibility of a repeated call.
     python tools/lab/stress.py [seconds]"""
@@ -155,10 +156,77 @@ def loss_case():
     return True
 
 
+def small_step_case():
+    """the one-launch step (mf_step_small) against the multi-kernel step: torch.equal on the loss, both tables and the Adam
+    moments after two steps, on random small shapes (B <= 128, N <= 256), every mined loss, padded / CSR / no positives,
+    logQ, duplicates, SGD and row-Adam"""
+    d = [32, 64, 128, 256][ri(0, 3)]
+    b = [ri(1, 8), ri(9, 64), ri(65, 128)][ri(0, 2)]
+    n = min(256, b + [0, ri(1, 32), b, ri(33, 128)][ri(0, 3)])
+    if n < 2:
+        n = 2
+    k = min([1, ri(1, 8), ri(9, 64), 64][ri(0, 3)], n - 1)
+    kind = ["ContrastiveLoss", "AlignmentContrastiveLoss", "InfomationNoiseContrastiveEstimationLoss",
+            "MutualInformationNeuralEstimationLoss", "PairwiseHingeLoss", "PairwiseLogisticLoss"][ri(0, 5)]
+    n_users, n_items = ri(max(2, b // 2), 400), ri(max(2, n // 2), 600)
+    adam = ri(0, 1)
+    mode = ri(0, 2)                      # padded / CSR / no positives
+    use_logq = ri(0, 1)
+    seed = ri(0, 10**6)
+
+    def make():
+        torch.manual_seed(seed)
+        towers = mf.models.init_towers(mf.models.ModelConfig(num_users=n_users, num_items=n_items, hidden_size=d), device=dev)
+        opt = mf.optim.RowAdam(towers.parameters(), lr=0.05) if adam else mf.optim.SparseSGD(towers.parameters(), lr=0.1, weight_decay=0.01)
+        return towers, opt
+
+    ta, oa = make()
+    tb, ob = make()
+    fn = getattr(mf.losses, kind)(num_negatives=k, sigma=[1.0, 1.7][ri(0, 1)], margin=[1.0, 0.3][ri(0, 1)])
+    logq = (torch.rand(n_items, generator=g) - 0.5).to(dev) if use_logq else None
+    lists = [torch.randint(0, n_items, (ri(0, 20),), generator=g) for _ in range(n_users)]
+    off = torch.tensor([0] + list(torch.tensor([x.numel() for x in lists]).cumsum(0).tolist()), dtype=torch.int64).to(dev)
+    flat = (torch.cat(lists) if sum(x.numel() for x in lists) else torch.zeros(1, dtype=torch.int64)).to(dev)
+    fused = mf.fused.FusedSmallStep(tb, ob, fn, logq_table=logq)
+    one = torch.ones((), device=dev)
+    tag = f"kind={kind} b={b} n={n} d={d} k={k} adam={adam} mode={mode} logq={use_logq} users={n_users} items={n_items}"
+    for step in range(2):
+        user = torch.randint(0, n_users, (b,), generator=g)
+        item = torch.randint(0, n_items, (n,), generator=g)
+        target = torch.randint(-1, 6, (b,), generator=g)
+        batch = {"user": user.to(dev), "item": item.to(dev), "target": target.to(dev)}
+        if mode == 0:
+            pos = torch.randint(0, n_items, (b, ri(1, 70)), generator=g)
+            pos[:, 0] = item[:b]
+            batch["pos"] = pos.to(dev)
+        elif mode == 1:
+            batch["pos_csr"] = (batch["user"], off, flat)
+        want = fn(ta["user"](batch["user"]), ta["item"](batch["item"]), batch["target"], item_idx=batch["item"], pos_idx=batch.get("pos"),
+                  logq_table=logq, pos_csr=batch.get("pos_csr"))
+        want.backward(one)
+        oa.step()
+        oa.zero_grad(set_to_none=True)
+        got = fused(batch)
+        if fused.fallback_steps:
+            print(f"SMALL STEP FELL BACK {tag}", flush=True)
+            return False
+        same = torch.equal(got, want.detach()) or (torch.isnan(got) and torch.isnan(want)) or (torch.isinf(got) and torch.isinf(want) and (got > 0) == (want > 0))
+        for name in ("user", "item"):
+            same = same and torch.equal(ta[name].weight, tb[name].weight)
+        if adam:
+            for pa, pb in zip(oa.param_groups[0]["params"], ob.param_groups[0]["params"]):
+                same = same and torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"]) and torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
+        if not same:
+            print(f"SMALL STEP MISMATCH step={step} {tag} got={float(got)} want={float(want)}", flush=True)
+            return False
+    return True
+
+
 n_kink = 0
 t0, n_ok, n_bad = time.time(), 0, 0
 while time.time() - t0 < budget:
-    for fn in ((loss_case,) if os.environ.get("STRESS_ONLY") == "loss" else (topk_case, update_case, loss_case)):
+    only = os.environ.get("STRESS_ONLY")
+    for fn in ((loss_case,) if only == "loss" else (small_step_case,) if only == "small" else (topk_case, update_case, loss_case, small_step_case)):
         ok = fn()
         n_ok += ok
         n_bad += not ok
