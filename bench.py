@@ -611,8 +611,22 @@ def main() -> None:
         # xfmr_rec/data/lightning.py:109) through the fused user + item exchange; MF_BENCH_USER_MODE=partitioned times the
         # user-partitioned stream instead (user rows never travel)
         user_mode = os.environ.get("MF_BENCH_USER_MODE", "routed")
-        trainer = mf.distributed.ShardedTrainer(mf, device, args.optimizer, args.num_negatives, num_users=NUM_USERS,
-                                                num_items=NUM_ITEMS, dim=DIM, logq=logq_table(device), user_mode=user_mode)
+        def make_trainer():
+            return mf.distributed.ShardedTrainer(mf, device, args.optimizer, args.num_negatives, num_users=NUM_USERS,
+                                                 num_items=NUM_ITEMS, dim=DIM, logq=logq_table(device), user_mode=user_mode)
+        comm_note = None
+        try:
+            trainer = make_trainer()
+        except mf._lib.MfHipError as e:
+            # default_comm raises on EVERY rank together when the C-side RCCL communicator fails its self-test (it has only
+            # ever run on one rank where this was built): the run goes on with torch.distributed's RCCL collectives -- still
+            # RCCL over xGMI, a few cross-stream joins slower -- and SAYS so (`transport`, `comm_note`)
+            if os.environ.get("MF_COMM") in ("torch", "rccl"):
+                raise
+            comm_note = f"mf_comm self-test failed, fell back to torch.distributed collectives: {e}"
+            print("bench.py: " + comm_note, file=sys.stderr)
+            os.environ["MF_COMM"] = "torch"
+            trainer = make_trainer()
         if user_mode == "partitioned":
             span_u = trainer.user_hi - trainer.user_lo
             for b in batches:
@@ -678,7 +692,8 @@ def main() -> None:
     csr = (torch.tensor(offs, dtype=torch.int64, device=device), torch.cat(pieces).to(device))
     index = None
     if dist_on:
-        searcher = mf.distributed.ShardedIndex(trainer.item_shard(), trainer.item_offset(), n_items_leg, stride=trainer.item_stride())
+        searcher = mf.distributed.ShardedIndex(trainer.item_shard(), trainer.item_offset(), n_items_leg, stride=trainer.item_stride(),
+                                               comm=trainer.comm)
         run_topk = lambda i: searcher.search(queries, TOP_K, exclude_csr=csr)   # noqa: E731
     else:
         index = mf.retrieval.ItemIndex(items)
@@ -840,6 +855,7 @@ def main() -> None:
                        "parallelism": f"dp{world}" + (f" + both tables row-sharded, {trainer.user_mode} users" if dist_on else "")},
             "rccl_ranks": trainer.comm.rccl_ranks if dist_on else None,
             "transport": trainer.comm.transport if dist_on else "none (one process, one GPU)",
+            **({"comm_note": comm_note} if dist_on and comm_note else {}),
             "cold_ms_per_step": None if cold_ms is None else round(cold_ms, 4),
             "roofline": train_roof,
             "topk": {"value": round(qps, 1), "unit": "queries/s", "ms_per_step": round(dt_topk / K * 1e3, 4),
