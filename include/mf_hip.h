@@ -106,6 +106,11 @@ int mf_scores(const float* u, int64_t B, const float* v, int64_t N, int d, float
 size_t mf_sort_ws_bytes(int64_t n);
 int mf_sort_keys(const int64_t* keys, int64_t n, int32_t* perm, int64_t* sorted_keys, void* ws,
                  size_t ws_bytes, mf_stream_t stream);
+/* Stable grouping by a SMALL key (0 <= key < nkeys <= 64, n <= 32,768; the owner rank of a routed id, distributed.py): perm
+ * and sorted_keys (nullable) as mf_sort_keys, bounds[nkeys + 1] = where each key's group starts.  One launch, one workgroup
+ * (a counting sort in LDS); MF_ENOTSUP beyond the limits. */
+int mf_group_keys(const int64_t* keys, int64_t n, int nkeys, int32_t* perm, int64_t* sorted_keys, int64_t* bounds,
+                  mf_stream_t stream);
 
 /* ------------------------------------------------------------------ losses ---
  * Replaces `EmbeddingLoss.forward` for all seven classes

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mf_scores": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp]),
     "mf_sort_ws_bytes": (c_sz, [c_i64]),
     "mf_sort_keys": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mf_group_keys": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
     "mf_loss_ws_bytes": (c_sz, [c_i64, c_i64, c_int, c_int, c_int]),
     "mf_loss_masks": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mf_loss_fwd": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp,

@@ -908,3 +908,20 @@ def test_device_batch_producer_matches_oracle_and_feeds_the_module(mf):
     m.configure_model(device=DEV)
     loss = m.training_step(seen[0], 0)
     assert torch.isfinite(loss)
+
+
+@pytest.mark.parametrize("n,nk", [(1, 1), (1000, 2), (24576, 8), (32768, 64), (5000, 3)])
+def test_group_keys_is_a_stable_counting_sort(mf, n, nk):
+    """mf_group_keys (the exchange plans' grouping by owner rank) against torch: stable permutation, sorted keys, group bounds."""
+    g = torch.Generator().manual_seed(n + nk)
+    keys = torch.randint(0, nk, (n,), generator=g)
+    if n > 100:
+        keys[: n // 3] = nk - 1                                      # a long run: whole waves of the first chunks hold one key
+    got = mf.distributed.HipOps(mf).group_by_key(keys.to(DEV), nk)
+    assert got is not None
+    perm, sk, bounds = (t.cpu() for t in got)
+    want = torch.argsort(keys, stable=True)
+    assert torch.equal(perm, want)
+    assert torch.equal(sk, keys[want])
+    assert torch.equal(bounds, torch.cat([torch.zeros(1, dtype=torch.int64), torch.bincount(keys, minlength=nk).cumsum(0)]))
+    assert mf.distributed.HipOps(mf).group_by_key(torch.zeros(40000, dtype=torch.int64, device=DEV), 8) is None      # beyond the limits
