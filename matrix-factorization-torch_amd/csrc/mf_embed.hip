@@ -332,10 +332,15 @@ __global__ __launch_bounds__(1024) void group_keys_kernel(const int64_t* __restr
     __shared__ int tot[GROUP_MAX_KEYS], start[GROUP_MAX_KEYS + 1], wcnt[16][GROUP_MAX_KEYS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int i = tid; i < n; i += 1024) {
-        long long k = keys[i];
-        k = k < 0 ? 0 : (k >= nk ? nk - 1 : k);                    // (precondition: 0 <= key < nkeys)
-        kb[i] = (unsigned char)k;
+    for (int i0 = tid; i0 < n; i0 += 8 * 1024) {                    // eight loads in flight per thread (one at a time: a memory round trip each)
+        long long k8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) k8[u] = i0 + u * 1024 < n ? keys[i0 + u * 1024] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long k = k8[u] < 0 ? 0 : (k8[u] >= nk ? nk - 1 : k8[u]);      // (precondition: 0 <= key < nkeys)
+            if (i0 + u * 1024 < n) kb[i0 + u * 1024] = (unsigned char)k;
+        }
     }
     if (tid < GROUP_MAX_KEYS) tot[tid] = 0;
     wcnt[wave][lane] = 0;

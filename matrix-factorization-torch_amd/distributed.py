@@ -573,7 +573,16 @@ class ShardedTrainer:
             ids = torch.cat([b["user"], b["item"]])
             tag = torch.zeros_like(ids)
             tag[b["user"].numel():] = 1
-            return RowExchange(ids, self.comm, self.ops, cap(ids.numel()), payload=ids * 2 + tag), None, None, None
+            ex = RowExchange(ids, self.comm, self.ops, cap(ids.numel()), payload=ids * 2 + tag)
+            # what this rank has to gather / update for the requests it received, per table (rows of the other table are
+            # asked for as -1: a zero row for the gather, skipped by the update) -- part of the PLAN: a dozen tiny
+            # launches that used to sit on the step's own stream between the updates and the next forward
+            req = ex.requests
+            none = torch.full_like(req, -1)
+            odd = torch.remainder(req, 2) == 1
+            lid = torch.div(req, 2 * self.world, rounding_mode="floor")           # (id * 2 + tag) // 2 // world
+            ex.table_ids = (torch.where((req >= 0) & ~odd, lid, none), torch.where((req >= 0) & odd, lid, none))
+            return ex, None, None, None
         user = b["user"]
         bad = ((user < self.user_lo) | (user >= self.user_hi)).any()
         return RowExchange(b["item"], self.comm, self.ops, cap(b["item"].numel())), None, None, bad
@@ -609,7 +618,7 @@ class ShardedTrainer:
             cur.wait_event(hit.ready)
             for ex in (hit.item, hit.user):
                 if ex is not None:
-                    for t in (ex.order, ex.local_ids, ex.requests):
+                    for t in (ex.order, ex.local_ids, ex.requests) + tuple(getattr(ex, "table_ids", ())):
                         t.record_stream(cur)
         return hit
 
@@ -673,12 +682,7 @@ class ShardedTrainer:
         elif self.user_mode == "routed":
             # requests carry the table in bit 0: rows of the other table are asked for as -1 (a zero row), so the two
             # gathers add up to the mixed block exactly
-            req = plan.item.requests
-            none = torch.full_like(req, -1)
-            is_user = (req >= 0) & (torch.remainder(req, 2) == 0)
-            is_item = (req >= 0) & (torch.remainder(req, 2) == 1)
-            lid = torch.div(torch.div(req, 2, rounding_mode="floor"), self.world, rounding_mode="floor")
-            uid, iid = torch.where(is_user, lid, none), torch.where(is_item, lid, none)
+            uid, iid = plan.item.table_ids
             rows = plan.item.fetch(ops.gather(self.user_table, uid, True) + ops.gather(self.item_table, iid, True))
             u, v = rows[:nb], rows[nb:]
         else:
