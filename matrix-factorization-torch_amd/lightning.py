@@ -22,7 +22,7 @@ from __future__ import annotations
 import torch
 
 from . import losses as mf_losses
-from . import models, optim
+from . import fused, models, optim
 from .params import INDEX_PATH, PROCESSORS_JSON, TOP_K, TOWERS_PATH
 from .retrieval import RetrievalMetrics, ItemProcessor
 
@@ -63,6 +63,7 @@ class MatrixFactorizationLitModule(_Base):
         self.history: dict[int, list[int]] = {}      # user_rn -> item ids already consumed (recommend excludes them)
         self.logq: torch.Tensor | None = None         # [num_items] log sampling probability, when use_logq
         self.metrics: dict[str, RetrievalMetrics] | None = None
+        self._fused: fused.FusedSmallStep | None = None
 
     # ------------------------------------------------------------------ towers ---
     def forward(self, idx: torch.Tensor, *, tower: str = "user") -> torch.Tensor:
@@ -206,6 +207,40 @@ class MatrixFactorizationLitModule(_Base):
         losses = self.compute_losses(batch, step_name="train")
         self.log_dict(losses)
         return losses[f"train/{self.config.train_loss}"]
+
+    def fused_training_step(self, batch, optimizer: torch.optim.Optimizer) -> torch.Tensor:
+        """``training_step`` + ``loss.backward()`` + ``optimizer.step()`` (xfmr_rec/lightning.py:189-192 and Lightning's
+        automatic optimisation around it) in ONE launch when the configuration is the reference's kind -- B <= 128 pairs,
+        plain embedding towers, a mined loss, ``optim.SparseSGD`` / ``optim.RowAdam`` -- through ``fused.FusedSmallStep``
+        (``mf_step_small``: bit-identical to the three calls); any other configuration runs those three calls.  Returns
+        the trained loss, detached (its gradient has been applied); logs all seven losses like ``training_step``."""
+        if self.loss_fns is None or self.towers is None:
+            msg = "`loss_fns` must be initialised first"
+            raise ValueError(msg)
+        cfg = self.config
+        if self._fused is None or self._fused.opt is not optimizer:
+            fn = next(f for f in self.loss_fns if f.__class__.__name__ == cfg.train_loss)
+            try:
+                self._fused = fused.FusedSmallStep(self.towers, optimizer, fn, all_losses=True,
+                                                   logq_table=self.logq if (cfg.use_logq and self.logq is not None) else None)
+            except mf_losses._lib.MfHipError:        # hash towers, a foreign optimiser: the ordinary three calls
+                self._fused = None
+        if self._fused is None:
+            loss = self.training_step(batch)
+            loss.backward()
+            optimizer.step()
+            optimizer.zero_grad(set_to_none=True)
+            return loss.detach()
+        flat = {"user": batch["user"]["idx"], "item": torch.cat([batch["item"]["idx"], batch["neg_item"]["idx"]]), "target": batch["target"]}
+        if batch["user"].get("pos_csr") is not None:
+            flat["pos_csr"] = (flat["user"],) + tuple(batch["user"]["pos_csr"][1:])
+        elif batch["user"].get("pos_idx") is not None:
+            flat["pos"] = batch["user"]["pos_idx"]
+        before = self._fused.fused_steps
+        loss = self._fused(flat)
+        if self._fused.fused_steps > before:       # (a fallback step evaluates the trained loss only)
+            self.log_dict({f"train/{name}": self._fused.losses[i] for i, name in enumerate(mf_losses.KINDS)})
+        return loss
 
     # ------------------------------------------------------------------- setup ---
     def configure_optimizers(self) -> torch.optim.Optimizer:

@@ -392,3 +392,38 @@ def test_fused_small_step_is_bit_identical_to_the_multi_kernel_step(mf, cfg):
     assert not fused.supported(big)
     fused(big)
     assert fused.fallback_steps == 1
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_module_fused_training_step_equals_the_three_calls(mf, opt):
+    """``fused_training_step`` (one launch) against ``training_step`` + ``backward`` + ``optimizer.step()`` at the reference's
+    default configuration (B = 32, hidden_size = 32, PairwiseHinge, 4 mined negatives): the same seven logged losses and --
+    torch.equal -- the same tables after three steps; a batch too large for one launch takes the three calls by itself."""
+    seen = []
+
+    def make():
+        torch.manual_seed(11)
+        m = mf.lightning.MatrixFactorizationLitModule({"num_users": 300, "num_items": 400, "learning_rate": 0.05, "optimizer": opt})
+        m.configure_model(device=DEV)
+        return m, m.configure_optimizers()
+
+    (ma, oa), (mb, ob) = make(), make()
+    assert ma.config.hidden_size == 32 and ma.config.train_loss == "PairwiseHingeLoss" and ma.config.num_negatives == 4
+    mb.log_dict = lambda d, *a, **k: seen.append({key: float(v) for key, v in d.items()})
+    data = mf.data.SyntheticInteractions(300, 400, max_positives=9, seed=5)
+    for step, bsz in enumerate((32, 32, 32, 200)):
+        batch = mf.data.to_device(data.batch(bsz), DEV)
+        want = ma.compute_losses(batch, step_name="train")
+        loss = want["train/PairwiseHingeLoss"]
+        loss.backward()
+        oa.step()
+        oa.zero_grad(set_to_none=True)
+        got = mb.fused_training_step(batch, ob)
+        assert float(got) == float(loss), step
+        for name in ("user", "item"):
+            assert torch.equal(ma.towers[name].weight, mb.towers[name].weight), (step, name)
+        if bsz <= 128:
+            assert list(seen[-1]) == [f"train/{k}" for k in ol.KINDS]
+            for k in ol.KINDS:
+                assert seen[-1][f"train/{k}"] == float(want[f"train/{k}"]), (step, k)
+    assert mb._fused.fused_steps == 3 and mb._fused.fallback_steps == 1
