@@ -53,8 +53,16 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 NUM_USERS, NUM_ITEMS, DIM = 162_541, 62_423, 128       # ML-25M shape
-TIME_EVERY = int(os.environ.get("MF_BENCH_TIME_EVERY", "4"))   # HIP-event pairs around every 4th launch of each timed kernel, inside the timed region
-                    # (an event pair costs ~6 us of stream time around the kernel it brackets)
+TIME_EVERY = int(os.environ.get("MF_BENCH_TIME_EVERY", "5"))   # HIP-event pairs around every 5th launch of each timed kernel, inside the timed region
+                    # (an event pair costs ~6 us of stream time around the kernel it brackets; an ODD period, so that the two
+                    # update launches of a step -- user table, item table -- are both sampled; every 16th measured the step 1.5 us
+                    # faster but left the spans noisier)
+
+
+def time_every(launches: int) -> int:
+    return max(1, TIME_EVERY)
+
+
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md)
 LDS_DMA_CHIP_GBS = 6400.0          # measured chip-wide LDS-DMA fill rate (MI355X_MICROARCH.md, 'ldsdma-fill')
 PEAK_F32_MFMA_TFLOPS = 157.3                            # MI355X_MICROARCH.md, fp32 matrix
@@ -310,7 +318,7 @@ def run_train_leg(mf, lib, device, *, batch: int, steps: int, warmup: int, optim
                   dim: int = DIM, pos_pad: int = POS_PAD, use_logq: bool = True, spin: bool = True, graph: bool = False,
                   seed: int = 1000, reps: int = 1, batches=None, num_hashes: int = 0, id_space=None) -> dict:
     """One single-GPU training leg: fresh tables, `warmup` untimed steps, then `reps` timed regions of `steps` steps each
-    (the reported ms / step is the MEDIAN region); HIP-event spans of the dominant kernels every TIME_EVERY-th launch.
+    (the reported ms / step is the MEDIAN region); HIP-event spans of the dominant kernels every time_every(launches)-th launch.
     graph=True: the step is captured in a hipGraph and replayed.  `batches`: pre-built flat batches (else synthetic padded
     ones); `id_space` = (users, items): ranges the synthetic ids are drawn from when they differ from the table heights
     (hash towers: ids far beyond the bucket counts)."""
@@ -330,7 +338,7 @@ def run_train_leg(mf, lib, device, *, batch: int, steps: int, warmup: int, optim
         step(batches[i % n_batches])
     lib.mf_timing_reset()
     if not graph:                                   # (event records inside a replayed graph would time nothing)
-        lib.mf_timing_enable(TIME_EVERY)
+        lib.mf_timing_enable(time_every(steps * max(reps, 1)))
     ms = []
     for r in range(reps):
         dt = timed(lambda i, r=r: step(batches[(warmup + r * steps + i) % n_batches]), steps, False)
@@ -643,7 +651,7 @@ def main() -> None:
         for i in range(W):
             run_step(i)
         lib.mf_timing_reset()
-        lib.mf_timing_enable(TIME_EVERY)
+        lib.mf_timing_enable(time_every(K * REPS))
         train_reps = [timed(lambda i, r=r: run_step(W + r * K + i), K, dist_on) / K * 1e3 for r in range(REPS)]
         dt_train = sorted(train_reps)[len(train_reps) // 2] * K / 1e3
         lib.mf_timing_enable(0)
@@ -702,7 +710,7 @@ def main() -> None:
     for i in range(W):
         run_topk(i)
     lib.mf_timing_reset()
-    lib.mf_timing_enable(TIME_EVERY)
+    lib.mf_timing_enable(time_every(K * REPS))
     topk_reps = [timed(run_topk, K, dist_on) / K * 1e3 for _ in range(REPS)]
     dt_topk = sorted(topk_reps)[len(topk_reps) // 2] * K / 1e3
     lib.mf_timing_enable(0)
