@@ -485,34 +485,34 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
             }
         }
         __syncthreads();
-        constexpr int LPR = 32, NE = D / LPR;
+        // D/4 lanes per row, four consecutive features each (one 16-byte LDS read per operand row; every feature's sum runs
+        // over the selections in the same order whichever lane holds it)
+        constexpr int LPR = D / 4;
         for (int t0 = 0; t0 < (B + N) * LPR; t0 += SS_THREADS) {
             const int t = t0 + tid;
             const int r = t / LPR, c = t % LPR;
             if (r < B) {
                 const int i = r;
-                float ui[NE], acc[NE];
-#pragma unroll
-                for (int e = 0; e < NE; ++e) { ui[e] = ubase[(size_t)i * rstride + c + LPR * e]; acc[e] = 0.f; }
+                const f32x4 ui = reinterpret_cast<const f32x4*>(ubase + (size_t)i * rstride)[c];
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 const int n = cnt_l[i];
                 for (int sl = -1; sl < n; ++sl) {
                     const int j = sl < 0 ? i : selp[i * sels + sl];
                     const float g = sl < 0 ? rowc_l[3 * Bp + i] : sel_Lp[i * sels + sl];
+                    const f32x4 vj = reinterpret_cast<const f32x4*>(vbase + (size_t)j * rstride)[c];
 #pragma unroll
-                    for (int e = 0; e < NE; ++e) acc[e] += g * (vbase[(size_t)j * rstride + c + LPR * e] - ui[e]);
+                    for (int e = 0; e < 4; ++e) acc[e] += g * (vj[e] - ui[e]);
                 }
-#pragma unroll
-                for (int e = 0; e < NE; ++e) dup[(size_t)i * D + c + LPR * e] = acc[e];
+                reinterpret_cast<f32x4*>(dup + (size_t)i * D)[c] = acc;
             } else if (r < B + N) {
                 const int j = r - B;
-                float vj[NE];
-                long long sum[NE];
-#pragma unroll
-                for (int e = 0; e < NE; ++e) { vj[e] = vbase[(size_t)j * rstride + c + LPR * e]; sum[e] = 0ll; }
+                const f32x4 vj = reinterpret_cast<const f32x4*>(vbase + (size_t)j * rstride)[c];
+                long long sum[4] = {0ll, 0ll, 0ll, 0ll};
                 auto add = [&](int i, float g) {
+                    const f32x4 ui = reinterpret_cast<const f32x4*>(ubase + (size_t)i * rstride)[c];
 #pragma unroll
-                    for (int e = 0; e < NE; ++e) {
-                        const float dvj = g * (ubase[(size_t)i * rstride + c + LPR * e] - vj[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float dvj = g * (ui[e] - vj[e]);
                         sum[e] += (long long)__builtin_rintf(fminf(fmaxf(dvj, -8388607.f), 8388607.f) * DV_FIX_SCALE);
                     }
                 };
@@ -528,8 +528,10 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                         add(i, sel_Lp[i * sels + sl]);
                     }
                 }
+                f32x4 o;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) dvp[(size_t)j * D + c + LPR * e] = (float)((double)sum[e] * (1.0 / 1099511627776.0));
+                for (int e = 0; e < 4; ++e) o[e] = (float)((double)sum[e] * (1.0 / 1099511627776.0));
+                reinterpret_cast<f32x4*>(dvp + (size_t)j * D)[c] = o;
             }
         }
     }
