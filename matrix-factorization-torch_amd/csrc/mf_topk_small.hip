@@ -222,6 +222,71 @@ __global__ __launch_bounds__(64 * SQ_NW) void topk_small_scan_kernel(SmallParams
     }
 }
 
+// Launch 1 for 2 .. 32 queries: the same hand-over (every row's score, every 64-row block's best key, per query) from the
+// MATRIX core.  32 queries are exactly one MFMA tile side: v_mfma_f32_32x32x2_f32 over a 32-row tile of the blocked copy
+// (lane (r, h) reads chunk 2g + h of row r: two coalesced 512-byte runs per load instruction) yields the canonical chain of
+// every (row, query) pair -- 0.5 GFLOP at Q = 32, 3.3 us at the fp32 MFMA peak, under the 5.5 us the 32 MB take from HBM --
+// so the scan costs the same for 2 queries as for 32, where the FMA-chain scan above pays per query (Q = 32: 99 us).
+// Scores leave through a 32 x 32 LDS transpose (rows of 128 contiguous bytes per query instead of 4-byte scatters).
+template <int D>
+__global__ __launch_bounds__(64 * SQ_NW) void topk_small_mfma_scan_kernel(SmallParams p) {
+    constexpr int CPR = D / 4;
+    __shared__ float tr[SQ_NW][32][33];
+    __shared__ unsigned long long exm[SQ_NW][32];
+    const int lane = mf_lane(), wave = mf_wave_id();
+    const int c = lane & 31, h = lane >> 5;
+    RowFrag<D> xq;                                               // B operand: query c (zeros beyond Q)
+    mf_load_frag<D>(xq, p.q, c, c < p.Q);
+    for (int64_t blk = (int64_t)blockIdx.x * SQ_NW + wave; blk < p.nblocks; blk += (int64_t)gridDim.x * SQ_NW) {
+        const int64_t row0 = blk * 64;
+        if (p.excl_off) {                     // every query's exclusion list against this block's 64 rows (as in the scan above)
+            for (int q = 0; q < p.Q; ++q) {
+                unsigned long long excl = 0ull;
+                for (int64_t e = p.excl_off[q] + lane; e < p.excl_off[q + 1]; e += 64) {
+                    const int64_t y = p.excl_idx[e] - p.idx_base - row0;
+                    if (y >= 0 && y < 64) excl |= 1ull << y;
+                }
+                excl = sq_wave_or_u64(excl);
+                if (lane == 0) exm[wave][q] = excl;
+            }
+            mf_wave_sync();
+        }
+        const unsigned long long myex = (p.excl_off && c < p.Q) ? exm[wave][c] : 0ull;
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.blocked) + blk * (int64_t)CPR * 64 + 32 * tile + c;
+            f32x4 a[D / 8];
+#pragma unroll
+            for (int g = 0; g < D / 8; ++g) a[g] = src[(int64_t)(2 * g + h) * 64];
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int g = 0; g < D / 8; ++g)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][t], xq.v[g][t], acc, 0, 0, 0);
+            // element e: row 32 tile + mf_acc_row(e, h) of the block, query c
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rb = 32 * tile + mf_acc_row(e, h);
+                const int64_t row = row0 + rb;
+                const bool ok = row < p.N && !((myex >> rb) & 1ull);
+                const unsigned long long key = ok ? mf_key_retrieval(acc[e], (unsigned)row) : 0ull;
+                best = key > best ? key : best;
+                tr[wave][mf_acc_row(e, h)][c] = ok ? acc[e] : __builtin_bit_cast(float, SQ_NOKEY);
+            }
+            mf_wave_sync();
+            // out: lane (r = c, q half = h) writes row r of queries h, h + 2, ...: 32 lanes = 128 contiguous bytes per query
+            for (int q = h; q < p.Q; q += 2) p.scores[(size_t)q * p.nblocks * 64 + row0 + 32 * tile + c] = tr[wave][c][q];
+            mf_wave_sync();
+        }
+        const unsigned long long other = mf_xor_lane_u64<32>(best);
+        best = other > best ? other : best;
+        if (h == 0 && c < p.Q) p.wmax[(size_t)c * p.nblocks + blk] = best;
+    }
+}
+
 // Launch 2, one 256-thread workgroup per query.  (a) wave 0 reduces the block maxima to two per lane and takes the k-th
 // largest of those 128 keys as the bound tau: a lower bound of the k-th best key (they are keys of distinct rows), at
 // most a few ranks below the exact k-th largest maximum.  (b) only blocks whose maximum reaches tau can hold a row of
@@ -439,8 +504,7 @@ extern "C" int mf_topk_small(const float* q, int64_t Q, const float* blocked, in
     MF_DISPATCH_D(d, {
         MF_TIMED("topk_small", s, {
             if (Q == 1) launch_small<D, 1>(sp, grid, s);
-            else if (Q <= 4) launch_small<D, 4>(sp, grid, s);
-            else launch_small<D, 8>(sp, grid, s);
+            else topk_small_mfma_scan_kernel<D><<<dim3((unsigned)grid), 64 * SQ_NW, 0, s>>>(sp);      // 2 .. 32 queries: one MFMA tile side
             topk_small_select_kernel<<<dim3((unsigned)Q), 64 * SQ_SEL_WAVES, 0, s>>>(w.scores, w.wmax, nblocks, k, idx_base, out_scores, out_idx);
         });
     });

@@ -51,9 +51,11 @@ class ItemIndex:
         self._ws: dict = {}                              # search workspaces, kept between calls
 
     SMALL_Q = 32       # at most this many queries can take the bandwidth-bound matrix-vector path (mf_topk_small)
-    # "auto" (measured at N = 62,423, d = 128, us per call): scan 17 / 26 / 40 / 107 at Q = 1 / 4 / 8 / 32; bf16 prefilter
-    # 31 / 33 / 37 / 51 / 76 at Q = 32 / 64 / 256 / 512 / 1024 (four launches: ~30 us floor); fp32 tiles 95 / 86 / 98 / 133 / 219
-    AUTO_SMALL_Q = 4   # scan up to here, then the bf16 prefilter (d >= 64), else the fp32 tile engine
+    # "auto" (measured at N = 62,423, d = 128, us of device time per call): scan 15 at Q = 1 (FMA chains, HBM-bound), and for
+    # 2 .. 32 queries -- one MFMA tile side: the fp32 matrix core computes all of them in the time of one -- see
+    # profiles/r03_topk_small_probe.log; bf16 prefilter 42 / 44 / 51 / 70 at Q = 32 / 256 / 512 / 1024 (five launches: ~35 us floor);
+    # fp32 tiles 95 / 86 / 98 / 133 / 219
+    AUTO_SMALL_Q = 32  # scan up to here, then the bf16 prefilter (d >= 64), else the fp32 tile engine
 
     def blocked(self) -> torch.Tensor:
         """The catalog in the blocked layout of ``mf_topk_small`` (``[64-row block][chunk][row]``), built once."""
