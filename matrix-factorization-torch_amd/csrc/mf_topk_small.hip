@@ -229,17 +229,70 @@ __global__ __launch_bounds__(64 * SQ_NW) void topk_small_scan_kernel(SmallParams
 // so the scan costs the same for 2 queries as for 32, where the FMA-chain scan above pays per query (Q = 32: 99 us).
 // Scores leave through a 32 x 32 LDS transpose (rows of 128 contiguous bytes per query instead of 4-byte scatters).
 template <int D>
-__global__ __launch_bounds__(64 * SQ_NW) void topk_small_mfma_scan_kernel(SmallParams p) {
+__global__ __launch_bounds__(64 * SQ_NW, (D <= 128 ? 2 : 1)) void topk_small_mfma_scan_kernel(SmallParams p) {      // (d = 256 spills at two)
     constexpr int CPR = D / 4;
     __shared__ float tr[SQ_NW][32][33];
     __shared__ unsigned long long exm[SQ_NW][32];
+    // the exclusion lists of all queries, once per workgroup, as (row, query) per entry: a block then walks the ENTRIES (a few
+    // thousand, from LDS, eight reads in flight) instead of every query's list from memory (32 dependent list walks per
+    // block: Q = 32 25 -> 59 us; this way 37).  All of a thread's list loads are in flight at once (EX_CAP / 256 = 24: one
+    // memory round trip; a loop over the queries would be one per query).  Measured and dropped: keeping only the entries of
+    // the workgroup's own blocks (46 us: the filtering costs more than the walks it saves).
+    constexpr int EX_CAP = 6144;
+    __shared__ int ex_row[EX_CAP];
+    __shared__ unsigned char ex_q[EX_CAP];
+    __shared__ long long ex_off[SQ_MAXQ + 1];
     const int lane = mf_lane(), wave = mf_wave_id();
     const int c = lane & 31, h = lane >> 5;
+    int64_t ex_total = 0;
+    bool ex_lds = false;
+    if (p.excl_off) {
+        if ((int)threadIdx.x <= p.Q) ex_off[threadIdx.x] = p.excl_off[threadIdx.x];
+        __syncthreads();
+        const int64_t e0 = ex_off[0];
+        ex_total = ex_off[p.Q] - e0;
+        ex_lds = ex_total <= EX_CAP;                            // (else: the per-query walks below)
+        if (ex_lds) {
+            constexpr int EPT = EX_CAP / (64 * SQ_NW);
+            int64_t idv[EPT];
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int64_t i = (int64_t)threadIdx.x + u * 64 * SQ_NW;
+                idv[u] = i < ex_total ? p.excl_idx[e0 + i] : -1;
+            }
+            int qrun = 0;                                        // (a thread's entries ascend: its query pointer only moves forward)
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int64_t i = (int64_t)threadIdx.x + u * 64 * SQ_NW;
+                if (i < ex_total) {
+                    while (qrun + 1 < p.Q && ex_off[qrun + 1] <= e0 + i) ++qrun;      // the q with off[q] <= e0 + i < off[q + 1]
+                    const int64_t y = idv[u] - p.idx_base;
+                    ex_row[i] = (y >= 0 && y < p.N) ? (int)y : -1;
+                    ex_q[i] = (unsigned char)qrun;
+                }
+            }
+            __syncthreads();
+        }
+    }
     RowFrag<D> xq;                                               // B operand: query c (zeros beyond Q)
     mf_load_frag<D>(xq, p.q, c, c < p.Q);
     for (int64_t blk = (int64_t)blockIdx.x * SQ_NW + wave; blk < p.nblocks; blk += (int64_t)gridDim.x * SQ_NW) {
         const int64_t row0 = blk * 64;
-        if (p.excl_off) {                     // every query's exclusion list against this block's 64 rows (as in the scan above)
+        if (p.excl_off && ex_lds) {
+            if (lane < 32) exm[wave][lane] = 0ull;
+            mf_wave_sync();
+            for (int i0 = lane; i0 < (int)ex_total; i0 += 8 * 64) {     // eight LDS reads in flight
+                int r8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r8[u] = i0 + 64 * u < (int)ex_total ? ex_row[i0 + 64 * u] : -1;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t y = (int64_t)r8[u] - row0;
+                    if (r8[u] >= 0 && y >= 0 && y < 64) atomicOr(&exm[wave][ex_q[i0 + 64 * u]], 1ull << y);
+                }
+            }
+            mf_wave_sync();
+        } else if (p.excl_off) {              // every query's exclusion list against this block's 64 rows (as in the scan above)
             for (int q = 0; q < p.Q; ++q) {
                 unsigned long long excl = 0ull;
                 for (int64_t e = p.excl_off[q] + lane; e < p.excl_off[q + 1]; e += 64) {
