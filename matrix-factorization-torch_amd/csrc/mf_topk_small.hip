@@ -276,8 +276,16 @@ __global__ __launch_bounds__(64 * SQ_NW, (D <= 128 ? 2 : 1)) void topk_small_mfm
     }
     RowFrag<D> xq;                                               // B operand: query c (zeros beyond Q)
     mf_load_frag<D>(xq, p.q, c, c < p.Q);
-    for (int64_t blk = (int64_t)blockIdx.x * SQ_NW + wave; blk < p.nblocks; blk += (int64_t)gridDim.x * SQ_NW) {
+    // a wave takes ONE 32-row tile: two waves per 64-row block, two blocks per workgroup, twice the waves of a block-per-wave
+    // cut -- at N = 62,423 that is two waves per SIMD, one's loads under the other's MFMAs (scan 13.5 -> see the probe log)
+    __shared__ unsigned long long bests[SQ_NW][32];
+    const int tile = wave & 1;
+    for (int64_t b0 = (int64_t)blockIdx.x * (SQ_NW / 2); b0 < p.nblocks; b0 += (int64_t)gridDim.x * (SQ_NW / 2)) {
+        const int64_t blk = b0 + (wave >> 1);
+        const bool active = blk < p.nblocks;                     // (wave-uniform; the workgroup's barriers are outside)
         const int64_t row0 = blk * 64;
+        unsigned long long best = 0ull;
+        if (active) {
         if (p.excl_off && ex_lds) {
             if (lane < 32) exm[wave][lane] = 0ull;
             mf_wave_sync();
@@ -305,9 +313,7 @@ __global__ __launch_bounds__(64 * SQ_NW, (D <= 128 ? 2 : 1)) void topk_small_mfm
             mf_wave_sync();
         }
         const unsigned long long myex = (p.excl_off && c < p.Q) ? exm[wave][c] : 0ull;
-        unsigned long long best = 0ull;
-#pragma unroll
-        for (int tile = 0; tile < 2; ++tile) {
+        {
             const f32x4* src = reinterpret_cast<const f32x4*>(p.blocked) + blk * (int64_t)CPR * 64 + 32 * tile + c;
             f32x4 a[D / 8];
 #pragma unroll
@@ -336,7 +342,14 @@ __global__ __launch_bounds__(64 * SQ_NW, (D <= 128 ? 2 : 1)) void topk_small_mfm
         }
         const unsigned long long other = mf_xor_lane_u64<32>(best);
         best = other > best ? other : best;
-        if (h == 0 && c < p.Q) p.wmax[(size_t)c * p.nblocks + blk] = best;
+        }
+        if (h == 0) bests[wave][c] = best;                       // the block's best key per query: the larger of its two tiles'
+        __syncthreads();
+        if (active && tile == 0 && h == 0 && c < p.Q) {
+            const unsigned long long o = bests[wave + 1][c];
+            p.wmax[(size_t)c * p.nblocks + blk] = o > best ? o : best;
+        }
+        __syncthreads();
     }
 }
 
@@ -557,7 +570,10 @@ extern "C" int mf_topk_small(const float* q, int64_t Q, const float* blocked, in
     MF_DISPATCH_D(d, {
         MF_TIMED("topk_small", s, {
             if (Q == 1) launch_small<D, 1>(sp, grid, s);
-            else topk_small_mfma_scan_kernel<D><<<dim3((unsigned)grid), 64 * SQ_NW, 0, s>>>(sp);      // 2 .. 32 queries: one MFMA tile side
+            else {                                               // 2 .. 32 queries: one MFMA tile side; a wave per 32-row tile
+                const int64_t nwg2 = (nblocks + SQ_NW / 2 - 1) / (SQ_NW / 2);
+                topk_small_mfma_scan_kernel<D><<<dim3((unsigned)(nwg2 < 4096 ? nwg2 : 4096)), 64 * SQ_NW, 0, s>>>(sp);
+            }
             topk_small_select_kernel<<<dim3((unsigned)Q), 64 * SQ_SEL_WAVES, 0, s>>>(w.scores, w.wmax, nblocks, k, idx_base, out_scores, out_idx);
         });
     });
