@@ -477,6 +477,25 @@ def test_topk_scan_path_equals_tile_path(mf, cfg):
         index.search(torch.zeros(33, d, device=DEV), k, path="scan")
 
 
+@pytest.mark.parametrize("d", [64, 256])
+def test_topk_few_query_scan_with_long_exclusion_lists(mf, d):
+    """The MFMA scan of the few-query path stages all queries' exclusion entries in LDS (6,144 entries); more than that --
+    31 queries x ~450 ids -- takes its per-query list walks.  Both against the tile engine, bit for bit; rows past N in the
+    last block, an id list that names rows outside the catalog."""
+    n, nq, k = 5003, 31, 20
+    g = torch.Generator().manual_seed(d)
+    q, items = _unit(nq, d, g), _unit(n, d, g)
+    index = mf.retrieval.ItemIndex(items.to(DEV))
+    for per in (150, 450):                                            # 4,650 entries: staged; 13,950: the fallback
+        excl = [torch.randint(-5, n + 5, (per,), generator=g).tolist() for _ in range(nq)]
+        st, it = index.search(q.to(DEV), k, exclude=excl, path="tiles")
+        ss, is_ = index.search(q.to(DEV), k, exclude=excl, path="scan")
+        assert torch.equal(it, is_), per
+        assert torch.equal(st.view(torch.int32), ss.view(torch.int32)), per
+        for row, ex in zip(is_.cpu().tolist(), excl):
+            assert not set(row) & set(ex)
+
+
 def test_topk_degenerate_inputs(mf):
     """All scores equal (zero queries): lowest rows win; fewer than k candidates: -1 padding."""
     items = torch.randn(400, 32)
