@@ -234,8 +234,7 @@ __global__ __launch_bounds__(64 * SQ_NW, (D <= 128 ? 2 : 1)) void topk_small_mfm
     __shared__ float tr[SQ_NW][32][33];
     __shared__ unsigned long long exm[SQ_NW][32];
     // the exclusion lists of all queries, once per workgroup, as (row, query) per entry: a block then walks the ENTRIES (a few
-    // thousand, from LDS, eight reads in flight) instead of every query's list from memory (32 dependent list walks per
-    // block: Q = 32 25 -> 59 us; this way 37).  All of a thread's list loads are in flight at once (EX_CAP / 256 = 24: one
+    // thousand, from LDS) instead of every query's list from memory (32 dependent list walks per block: Q = 32 25 -> 59 us).  All of a thread's list loads are in flight at once (EX_CAP / 256 = 24: one
     // memory round trip; a loop over the queries would be one per query).  Measured and dropped: keeping only the entries of
     // the workgroup's own blocks (46 us: the filtering costs more than the walks it saves).
     constexpr int EX_CAP = 6144;
@@ -285,21 +284,26 @@ __global__ __launch_bounds__(64 * SQ_NW, (D <= 128 ? 2 : 1)) void topk_small_mfm
         const bool active = blk < p.nblocks;                     // (wave-uniform; the workgroup's barriers are outside)
         const int64_t row0 = blk * 64;
         unsigned long long best = 0ull;
-        if (active) {
+        const int ex_slot = ex_lds ? (wave >> 1) : wave;         // staged entries: one mask row per block of the workgroup
         if (p.excl_off && ex_lds) {
-            if (lane < 32) exm[wave][lane] = 0ull;
-            mf_wave_sync();
-            for (int i0 = lane; i0 < (int)ex_total; i0 += 8 * 64) {     // eight LDS reads in flight
+            // ONE walk over the staged entries by the whole workgroup, for both of its blocks (128 consecutive rows), eight LDS
+            // reads in flight per thread -- not a walk per wave
+            if (threadIdx.x < 64) exm[threadIdx.x >> 5][threadIdx.x & 31] = 0ull;
+            __syncthreads();
+            for (int i0 = threadIdx.x; i0 < (int)ex_total; i0 += 8 * 64 * SQ_NW) {
                 int r8[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) r8[u] = i0 + 64 * u < (int)ex_total ? ex_row[i0 + 64 * u] : -1;
+                for (int u = 0; u < 8; ++u) r8[u] = i0 + 64 * SQ_NW * u < (int)ex_total ? ex_row[i0 + 64 * SQ_NW * u] : -1;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int64_t y = (int64_t)r8[u] - row0;
-                    if (r8[u] >= 0 && y >= 0 && y < 64) atomicOr(&exm[wave][ex_q[i0 + 64 * u]], 1ull << y);
+                    const int64_t y = (int64_t)r8[u] - b0 * 64;
+                    if (r8[u] >= 0 && y >= 0 && y < 128) atomicOr(&exm[y >> 6][ex_q[i0 + 64 * SQ_NW * u]], 1ull << (y & 63));
                 }
             }
-            mf_wave_sync();
+            __syncthreads();
+        }
+        if (active) {
+        if (p.excl_off && ex_lds) {
         } else if (p.excl_off) {              // every query's exclusion list against this block's 64 rows (as in the scan above)
             for (int q = 0; q < p.Q; ++q) {
                 unsigned long long excl = 0ull;
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(64 * SQ_NW, (D <= 128 ? 2 : 1)) void topk_small_mfm
             }
             mf_wave_sync();
         }
-        const unsigned long long myex = (p.excl_off && c < p.Q) ? exm[wave][c] : 0ull;
+        const unsigned long long myex = (p.excl_off && c < p.Q) ? exm[ex_slot][c] : 0ull;
         {
             const f32x4* src = reinterpret_cast<const f32x4*>(p.blocked) + blk * (int64_t)CPR * 64 + 32 * tile + c;
             f32x4 a[D / 8];
