@@ -830,20 +830,24 @@ def main() -> None:
         del leg, big, shard, hb
         torch.cuda.empty_cache()
         # small batches: eager against one hipGraph replay per step
+        ref_default = {"loss": "PairwiseHingeLoss", "num_negatives": 4, "use_logq": False}
         for name, bsz, kw in (("b1024", 1024, {}), ("b32", 32, {}),
-                              ("b32_reference_default", 32, {"loss": "PairwiseHingeLoss", "num_negatives": 4, "use_logq": False})):
+                              # the reference's DEFAULT configuration: BATCH_SIZE = 32 (params.py:18), hidden_size = 32
+                              # (lightning.py:33), PairwiseHingeLoss with 4 mined negatives (lightning.py:38-39); table heights of ML-25M
+                              ("b32_reference_default", 32, {**ref_default, "dim": 32}),
+                              # ... and the same step at the C3 table width (round 2 measured this leg at d = 128)
+                              ("b32_reference_default_d128", 32, ref_default)):
             eager = run_train_leg(mf, lib, device, batch=bsz, steps=200, warmup=20, spin=False, **kw)
             graphed = run_train_leg(mf, lib, device, batch=bsz, steps=200, warmup=20, spin=False, graph=True, **kw)
-            extras[name] = {"workload": f"C3 shape, B = {bsz}, " + (kw.get("loss", "InfoNCE + logQ")) + ", row-adam",
+            dim_leg = kw.get("dim", DIM)
+            extras[name] = {"workload": f"ML-25M table heights, d = {dim_leg}, B = {bsz}, " + (kw.get("loss", "InfoNCE + logQ")) + ", row-adam",
                             "eager_ms_per_step": round(eager["ms_per_step"], 4), "graph_ms_per_step": round(graphed["ms_per_step"], 4),
                             "eager_pairs_per_s": round(eager["pairs_per_s"], 1), "graph_pairs_per_s": round(graphed["pairs_per_s"], 1)}
             del eager, graphed
             if kw.get("num_negatives"):
-                # the same step in ONE launch (mf_step_small: bit-identical tables): device time per step from events around 200
-                # launches, wall time of the eager loop, and one hipGraph replay per step
-                extras[name].update(small_step_leg(mf, device, bsz, kw))
-                # ... and at the reference's own width (hidden_size = 32, xfmr_rec/lightning.py:33)
-                extras[name]["d32"] = small_step_leg(mf, device, bsz, kw, dim=32)
+                # the same step in ONE launch (mf_step_small: bit-identical tables): device time per step (median of ten
+                # 200-step regions, HIP events), wall time of the loop, phase stamps of the last step
+                extras[name].update(small_step_leg(mf, device, bsz, {k: v for k, v in kw.items() if k != "dim"}, dim=dim_leg))
         torch.cuda.empty_cache()
 
     # --------------------------------------------------------------------- CPU leg ----
