@@ -234,10 +234,10 @@ __global__ __launch_bounds__(64 * SQ_NW, (D <= 128 ? 2 : 1)) void topk_small_mfm
     __shared__ float tr[SQ_NW][32][33];
     __shared__ unsigned long long exm[SQ_NW][32];
     // the exclusion lists of all queries, once per workgroup, as (row, query) per entry: a block then walks the ENTRIES (a few
-    // thousand, from LDS) instead of every query's list from memory (32 dependent list walks per block: Q = 32 25 -> 59 us).  All of a thread's list loads are in flight at once (EX_CAP / 256 = 24: one
+    // thousand, from LDS) instead of every query's list from memory (32 dependent list walks per block: Q = 32 25 -> 59 us).  All of a thread's list loads are in flight at once (EX_CAP / 256 = 32: one
     // memory round trip; a loop over the queries would be one per query).  Measured and dropped: keeping only the entries of
     // the workgroup's own blocks (46 us: the filtering costs more than the walks it saves).
-    constexpr int EX_CAP = 6144;
+    constexpr int EX_CAP = 8192;
     __shared__ int ex_row[EX_CAP];
     __shared__ unsigned char ex_q[EX_CAP];
     __shared__ long long ex_off[SQ_MAXQ + 1];

@@ -56,6 +56,7 @@ class ItemIndex:
     # profiles/r03_topk_small_probe.log; bf16 prefilter 42 / 44 / 51 / 70 at Q = 32 / 256 / 512 / 1024 (five launches: ~35 us floor);
     # fp32 tiles 95 / 86 / 98 / 133 / 219
     AUTO_SMALL_Q = 32  # scan up to here, then the bf16 prefilter (d >= 64), else the fp32 tile engine
+    SCAN_MAX_EXCL = 8192     # exclusion entries (all queries of a call) the scan stages in LDS: EX_CAP of mf_topk_small.hip
 
     def blocked(self) -> torch.Tensor:
         """The catalog in the blocked layout of ``mf_topk_small`` (``[64-row block][chunk][row]``), built once."""
@@ -122,14 +123,21 @@ class ItemIndex:
         if path == "scan" and nq > self.SMALL_Q:
             msg = f"the scan path takes at most {self.SMALL_Q} queries: {nq = }"
             raise ValueError(msg)
-        if path == "scan" or (path == "auto" and nq <= self.AUTO_SMALL_Q):
+        # the few-query scan matches exclusion entries against every 64-row block: staged in LDS up to SCAN_MAX_EXCL entries
+        # (all queries together), a walk over each query's list per block beyond -- measured at N = 62,423: Q = 8 x 2,000 ids
+        # 89 us, Q = 32 x 30,000 ids 4 ms, against 46 / 85 us through the prefilter (which builds bit rows once).  So "auto"
+        # sends long lists -- a heavy user's history -- to the other engines
+        entries = 0 if ids is None else int(ids.numel())
+        bf16_ok = n >= self.BF16_MIN_N and d >= 64
+        scan_ok = nq <= self.AUTO_SMALL_Q and (entries <= self.SCAN_MAX_EXCL or not bf16_ok and entries <= 16 * self.SCAN_MAX_EXCL)
+        if path == "scan" or (path == "auto" and scan_ok):
             # the reference's own shape: one query (or a handful) per call -- bandwidth-bound scan, two launches
             ws = self._workspace(("small", nq, top_k), lib.mf_topk_small_ws_bytes(nq, n, d, top_k))
             _lib.check(lib.mf_topk_small(q.data_ptr(), nq, self.blocked().data_ptr(), n, d, top_k, _lib.ptr(off), _lib.ptr(ids),
                                          self.idx_base, ws.data_ptr(), ws.numel(), scores.data_ptr(), rows.data_ptr(),
                                          _lib.stream_ptr()))
             return scores, rows
-        if path == "bf16" or (path == "auto" and nq >= self.BF16_MIN_Q and n >= self.BF16_MIN_N and d >= 64):
+        if path == "bf16" or (path == "auto" and (nq >= self.BF16_MIN_Q or not scan_ok) and bf16_ok):
             ws = self._workspace(("bf16", nq, top_k), lib.mf_topk_bf3_ws_bytes(nq, n, d, top_k))
             rc = lib.mf_topk_bf3(q.data_ptr(), nq, self.embeddings.data_ptr(), self.bf16_index().data_ptr(), n, d, top_k,
                                  _lib.ptr(off), _lib.ptr(ids), self.idx_base, ws.data_ptr(), ws.numel(), scores.data_ptr(),

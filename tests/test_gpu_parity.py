@@ -486,12 +486,14 @@ def test_topk_few_query_scan_with_long_exclusion_lists(mf, d):
     g = torch.Generator().manual_seed(d)
     q, items = _unit(nq, d, g), _unit(n, d, g)
     index = mf.retrieval.ItemIndex(items.to(DEV))
-    for per in (150, 450):                                            # 4,650 entries: staged; 13,950: the fallback
+    for per in (150, 450):                                            # 4,650 entries: staged (<= 8,192); 13,950: the fallback
         excl = [torch.randint(-5, n + 5, (per,), generator=g).tolist() for _ in range(nq)]
         st, it = index.search(q.to(DEV), k, exclude=excl, path="tiles")
         ss, is_ = index.search(q.to(DEV), k, exclude=excl, path="scan")
         assert torch.equal(it, is_), per
         assert torch.equal(st.view(torch.int32), ss.view(torch.int32)), per
+        sa, ia = index.search(q.to(DEV), k, exclude=excl)             # "auto": the long lists go to the prefilter (d >= 64)
+        assert torch.equal(it, ia) and torch.equal(st.view(torch.int32), sa.view(torch.int32)), per
         for row, ex in zip(is_.cpu().tolist(), excl):
             assert not set(row) & set(ex)
 
