@@ -30,6 +30,7 @@ static constexpr int SS_MAXB = 128, SS_MAXN = 256, SS_THREADS = FUSED_THREADS, S
 // normalised rows of the batch when they fit (rows padded by 16 bytes: lanes reading the same 16 bytes of 16 different rows
 // hit 64 different banks) -- chains that read them from L2 instead cost a memory round trip per 8 features
 static constexpr int SS_ROWS0 = FUSED_CAP * 8, SS_ROWS_BYTES = 88 * 1024;
+static constexpr int SS_LONG = 512;      // positives of a user walked by its own half-wave; the rest of a longer list by the workgroup
 static_assert(SS_THREADS == 1024, "the update body runs with FUSED_THREADS threads");
 
 struct StepSmallWs {
@@ -114,7 +115,10 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
     float* bias_l = fl + 2704;                                                  // [2] Adam's bias corrections
     int32_t* cnt_l = reinterpret_cast<int32_t*>(fl + 2720);                     // [SS_MAXB] selected columns per user
     long long* itemid_l = reinterpret_cast<long long*>(cnt_l + SS_MAXB);        // [SS_MAXN] the columns' item ids
-    int32_t* sel_l = reinterpret_cast<int32_t*>(itemid_l + SS_MAXN);            // [B][k] selected columns, then [B][k] their logits
+    const long long** lists_l = reinterpret_cast<const long long**>(itemid_l + SS_MAXN);     // [SS_MAXB] the users' positive lists ...
+    int32_t* lens_l = reinterpret_cast<int32_t*>(lists_l + SS_MAXB);            // [SS_MAXB] ... and their lengths
+    int32_t* any_long = lens_l + SS_MAXB;                                       // [1] some user's list is longer than SS_LONG (+ 3 words of padding)
+    int32_t* sel_l = any_long + 4;                                              // [B][k] selected columns, then [B][k] their logits
     const bool sel_in_lds = (size_t)B * p.k * 8 <= (size_t)(SS_ROWS0 - ((char*)sel_l - smem));
     int32_t* selp = sel_in_lds ? sel_l : w.sel;
     float* sel_Lp = sel_in_lds ? reinterpret_cast<float*>(sel_l + (size_t)B * p.k) : w.sel_L;
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                 if (l32 + 32 * sl < p.P) pre[sl] = p.pos_idx[(size_t)i * p.P + l32 + 32 * sl];
         }
     }
+    if (tid == 0) *any_long = 0;
     for (int e = tid; e < SS_HT; e += SS_THREADS) {
         hkey[e] = NO_KEY;
         hset[4 * e] = hset[4 * e + 1] = hset[4 * e + 2] = hset[4 * e + 3] = 0ull;
@@ -251,6 +256,14 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                 len = p.P;
             }
         }
+        // a half-wave walks the first SS_LONG entries of its user's list; what lies beyond (a heavy user: tens of thousands
+        // of positives) is left to the whole workgroup below -- one half-wave would need a memory round trip per 256 of them
+        if (l32 == 0 && i < B) {
+            lists_l[i] = reinterpret_cast<const long long*>(list);
+            lens_l[i] = len;
+            if (len > SS_LONG) *any_long = 1;
+        }
+        if (len > SS_LONG) len = SS_LONG;
         unsigned long long m4[4] = {0ull, 0ull, 0ull, 0ull};
         auto look_up = [&](long long key) {
             unsigned h = slot_of(key);
@@ -271,7 +284,14 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
             for (int sl = 0; sl < 2; ++sl)
                 if (t < len) { look_up(pre[sl]); t += 32; }
         }
-        for (; t < len; t += 32) look_up(list[t]);
+        for (; t < len; t += 32 * 8) {                               // eight list loads in flight per lane (a heavy user's 30,000
+            long long k8[8];                                         // positives: a memory round trip per 256 of them, not per 32)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) k8[u] = t + 32 * u < len ? list[t + 32 * u] : NO_KEY;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k8[u] != NO_KEY) look_up(k8[u]);
+        }
         if (l32 == 0 && len >= 0) look_up(itemid_l[i]);              // the user's own item
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -295,6 +315,43 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
         keep_row(r, load_row(r, row));
     }
     __syncthreads();
+    if (*any_long) {                                             // (workgroup-uniform; rare: nothing but this test otherwise)
+        // the long lists' remainders, by all 1024 threads, eight loads in flight each (a 30,000-entry list: four round trips)
+        for (int i = 0; i < B; ++i) {
+            const int len = lens_l[i];
+            if (len <= SS_LONG) continue;                            // (workgroup-uniform)
+            const long long* list = lists_l[i];
+            unsigned long long m4[4] = {0ull, 0ull, 0ull, 0ull};
+            for (int t = SS_LONG + tid; t < len; t += SS_THREADS * 8) {
+                long long k8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) k8[u] = t + SS_THREADS * u < len ? list[t + SS_THREADS * u] : NO_KEY;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k8[u] == NO_KEY) continue;
+                    unsigned h = slot_of(k8[u]);
+                    for (;;) {
+                        const long long sv = hkey[h];
+                        if (sv == k8[u]) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) m4[q] |= hset[4 * h + q];
+                            break;
+                        }
+                        if (sv == NO_KEY) break;
+                        h = (h + 1) & (SS_HT - 1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned long long m = m4[q];
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1) m |= mf_shfl_xor_u64(m, sh);
+                if (lane == 0 && m) atomicOr(&hitm[4 * i + q], m);
+            }
+        }
+        ss_lds_barrier();
+    }
     stamp();
 
     // ---- chain norms of both operands, the diagonal, -logq (prep_kernel).  One chain per thread -- N of v.v, B of u.u, B of

@@ -427,3 +427,50 @@ def test_module_fused_training_step_equals_the_three_calls(mf, opt):
             for k in ol.KINDS:
                 assert seen[-1][f"train/{k}"] == float(want[f"train/{k}"]), (step, k)
     assert mb._fused.fused_steps == 3 and mb._fused.fallback_steps == 1
+
+
+@pytest.mark.parametrize("mode", ["csr", "padded"])
+def test_fused_small_step_with_long_positive_lists(mf, mode):
+    """Positive lists beyond the 512 entries a half-wave walks (a heavy user: thousands of positives; padded: P = 700) go
+    to the whole workgroup of the one-launch step: tables torch.equal to the multi-kernel step, masks therefore too."""
+    n_users, n_items, b, d = 40, 5000, 24, 32
+    g = torch.Generator().manual_seed(3)
+
+    def make():
+        torch.manual_seed(5)
+        towers = mf.models.init_towers(mf.models.ModelConfig(num_users=n_users, num_items=n_items, hidden_size=d), device=DEV)
+        return towers, mf.optim.RowAdam(towers.parameters(), lr=0.05)
+
+    (ta, oa), (tb, ob) = make(), make()
+    fn = mf.losses.PairwiseHingeLoss(num_negatives=4)
+    lens = torch.randint(0, 30, (n_users,), generator=g)
+    lens[3], lens[7], lens[11] = 3000, 600, 513
+    lists = [torch.randint(1, n_items, (int(ln),), generator=g) for ln in lens]
+    off = torch.tensor([0] + torch.tensor([x.numel() for x in lists]).cumsum(0).tolist(), dtype=torch.int64).to(DEV)
+    flat = torch.cat(lists).to(DEV)
+    fused = mf.fused.FusedSmallStep(tb, ob, fn)
+    one = torch.ones((), device=DEV)
+    for step in range(2):
+        user = torch.randint(1, n_users, (b,), generator=g)
+        user[:3] = torch.tensor([3, 7, 11])
+        item = torch.randint(1, n_items, (2 * b,), generator=g)
+        item[b:b + 8] = lists[3][2000:2008]                      # negatives that are positives of the heavy user, deep in its list
+        item[b + 8] = lists[7][599]
+        batch = {"user": user.to(DEV), "item": item.to(DEV), "target": torch.randint(1, 6, (b,), generator=g).to(DEV)}
+        if mode == "csr":
+            batch["pos_csr"] = (batch["user"], off, flat)
+        else:
+            pos = torch.randint(1, n_items, (b, 700), generator=g)
+            pos[0, 650:658] = item[b:b + 8]                      # beyond the half-wave's share
+            pos[:, 0] = item[:b]
+            batch["pos"] = pos.to(DEV)
+        want = fn(ta["user"](batch["user"]), ta["item"](batch["item"]), batch["target"], item_idx=batch["item"], pos_idx=batch.get("pos"),
+                  pos_csr=batch.get("pos_csr"))
+        want.backward(one)
+        oa.step()
+        oa.zero_grad(set_to_none=True)
+        got = fused(batch)
+        assert fused.fallback_steps == 0
+        assert torch.equal(got, want.detach()), step
+        for name in ("user", "item"):
+            assert torch.equal(ta[name].weight, tb[name].weight), (step, name)
