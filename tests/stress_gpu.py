@@ -4,7 +4,7 @@
   * the one-launch training step against the multi-kernel step (torch.equal) on random small shapes;
   * sparse update: the one-launch path against the oracle's coalesced row-Adam on random id multisets (Zipf, uniform,
     one dominant id, out-of-range ids), and bit-reproducibility of a repeated call.
-    python tools/lab/stress.py [seconds]"""
+    python tests/stress_gpu.py [seconds]      (test infrastructure: it checks the kernels against oracle/; pytest does not collect it)"""
 import importlib
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import embed as oembed  # noqa: E402
 
 mf = importlib.import_module("matrix-factorization-torch_amd")
