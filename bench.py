@@ -421,13 +421,22 @@ def cpu_baselines(args, batches, queries, items, pieces) -> dict:
     cores = os.cpu_count() or 1
     cands = [t for t in (32, 64, 16, 8) if t <= min(cores, CPU_MAX_THREADS)] or [cores]
     lq = logq_table("cpu")
-    sweep, t_start = {}, time.perf_counter()
+    full = batches[0]
+    wb = min(512, b)                                  # a reduced, untimed warm step per thread setting: thread-pool start-up,
+    warm = {"user": full["user"][:wb], "item": torch.cat([full["item"][:wb], full["item"][b:b + wb]]),      # first-touch page
+            "target": full["target"][:wb], "pos": full["pos"][:wb]}                                            # faults
+    sweep, t_start, cut = {}, time.perf_counter(), False
     for t in cands:
         if sweep and time.perf_counter() - t_start > CPU_BUDGET_S:
+            cut = True
             break
         torch.set_num_threads(t)
+        cpu_train_baseline([warm], lq, args.optimizer, 1, args.num_negatives)
         sweep[t] = cpu_train_baseline(batches[:1], lq, args.optimizer, 1, args.num_negatives)
     best_t = min(sweep, key=sweep.get)
+    torch.set_num_threads(best_t)                     # a second timed step at the chosen setting; the better of the two is kept
+    at_best = [sweep[best_t], cpu_train_baseline(batches[:1], lq, args.optimizer, 1, args.num_negatives)]
+    sweep[best_t] = min(at_best)
     # top-k
     qn = queries.shape[0]
     rows = torch.cat([torch.full((p.numel(),), r, dtype=torch.int64) for r, p in enumerate(pieces)])
@@ -444,9 +453,10 @@ def cpu_baselines(args, batches, queries, items, pieces) -> dict:
     return {"value": round(b / sweep[best_t], 1), "unit": "pairs/s", "cores": best_t, "kind": "port",
             "cpu_model": cpu_model(), "host_threads_available": cores,
             "thread_sweep_s_per_step": {str(t): round(v, 3) for t, v in sweep.items()},
+            "steps_s_at_best": [round(v, 3) for v in at_best], "sweep_cut_by_time_box": cut,
             "sample": f"one step of the same workload (B={b}, N={2 * b}, d={DIM}, InfoNCE+logQ, {args.optimizer}) by oracle/ on "
-                      f"torch CPU per thread count in {list(sweep)} (<= {CPU_MAX_THREADS} threads, {CPU_BUDGET_S:.0f} s time box), best "
-                      f"kept; top-k: 3 batches of Q={qn} per thread count, best kept",
+                      f"torch CPU per thread count in {list(sweep)} (<= {CPU_MAX_THREADS} threads, {CPU_BUDGET_S:.0f} s time box; an untimed "
+                      f"{wb}-pair warm step first), two timed steps at the best setting, best kept; top-k: 3 batches of Q={qn} per thread count, best kept",
             "topk_value": round(qn / tk[best_k], 1), "topk_unit": "queries/s", "topk_cores": best_k,
             "topk_thread_sweep_ms": {str(t): round(v * 1e3, 1) for t, v in tk.items()}}
 
@@ -883,6 +893,26 @@ def main() -> None:
             "extras": extras,
             "cpu_baseline": cpu,
         }
+        # the second half of the headline metric and the other figures with a bar attached, as TOP-LEVEL scalars at the END
+        # of the line: the driver's record keeps top-level scalars and the last 2 kB
+        def dig(obj, *path):
+            for key in path:
+                obj = obj.get(key) if isinstance(obj, dict) else None
+            return obj
+        ref_small = dig(extras, "b32_reference_default", "one_launch_device_ms_per_step")
+        ref_small128 = dig(extras, "b32_reference_default_d128", "one_launch_device_ms_per_step")
+        avg = dig(train_roof, "all_kernels_avg_ms") or {}
+        sweeps_ms = sum(avg.get(k, 0.0) for k in ("loss_fwd_dense", "loss_bwd_du", "loss_bwd_dv"))
+        line.update({
+            "topk_value": round(qps, 1), "topk_unit": "queries/s", "topk_ms_per_step": round(dt_topk / K * 1e3, 4),
+            "topk_frac": dig(topk_roof, "frac"), "topk_device_ms": dig(topk_roof, "avg_ms"), "topk_traffic_bytes": dig(topk_roof, "traffic"),
+            "q1_latency_us": dig(extras, "q_small", "q1", "latency_us"), "q32_latency_us": dig(extras, "q_small", "q32", "latency_us"),
+            "one_launch_us": None if ref_small is None else round(ref_small * 1e3, 2),
+            "one_launch_d128_us": None if ref_small128 is None else round(ref_small128 * 1e3, 2),
+            "train_frac": dig(train_roof, "frac"), "train_tail_us": round((dt_train / K - sweeps_ms * 1e-3) * 1e6, 1) if sweeps_ms else None,
+            "mined_frac": dig(extras, "mined", "roofline", "frac"), "c2_ms_per_step": dig(extras, "c2_ml1m_d64", "ms_per_step"),
+            "cpu_pairs_per_s": dig(cpu, "value"), "cpu_topk_queries_per_s": dig(cpu, "topk_value"),
+        })
         print(json.dumps(line), flush=True)
     if dist_on:
         torch.distributed.destroy_process_group()

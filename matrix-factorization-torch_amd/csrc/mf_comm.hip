@@ -42,21 +42,24 @@ RcclApi& api() {
         // runtimes in one process would each own a set of proxy threads and IPC handles.  First by soname without
         // loading (RTLD_NOLOAD), then whatever image already exports the symbols (torch may link RCCL into another of
         // its libraries), and only in a process that has no RCCL at all a fresh dlopen.
+        // (RTLD_DEFAULT is a NULL handle on glibc: "found" is tracked apart from the handle -- ADVICE r3)
         void* h = nullptr;
+        bool found = false;
         for (const char* name : {"librccl.so.1", "librccl.so"}) {
             h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-            if (h) { a.source = "shared: already mapped"; break; }
+            if (h) { found = true; a.source = "shared: already mapped"; break; }
         }
-        if (!h && dlsym(RTLD_DEFAULT, "ncclCommInitRank") && dlsym(RTLD_DEFAULT, "ncclSend")) {
+        if (!found && dlsym(RTLD_DEFAULT, "ncclCommInitRank") && dlsym(RTLD_DEFAULT, "ncclSend")) {
             h = RTLD_DEFAULT;
+            found = true;
             a.source = "shared: process symbols";
         }
-        if (!h) {
+        if (!found) {
             h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
             if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (h) a.source = "own: dlopen";
+            if (h) { found = true; a.source = "own: dlopen"; }
         }
-        if (!h) return;
+        if (!found) return;
         bool all = true;
         auto sym = [&](const char* n) { void* p = dlsym(h, n); all = all && p; return p; };
         a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));

@@ -417,4 +417,6 @@ def movielens_interactions(ratings_path, *, train_prop: float = 0.8, val_prop: f
 def to_device(batch, device):
     if isinstance(batch, dict):
         return {k: to_device(v, device) for k, v in batch.items()}
+    if isinstance(batch, (tuple, list)):             # ``pos_csr`` / ``history`` triples
+        return type(batch)(to_device(v, device) for v in batch)
     return batch.to(device) if isinstance(batch, torch.Tensor) else batch

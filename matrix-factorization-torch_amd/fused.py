@@ -27,7 +27,7 @@ class FusedSmallStep:
         if not isinstance(optimizer, (optim.SparseSGD, optim.RowAdam)):
             raise _lib.MfHipError("FusedSmallStep takes optim.SparseSGD or optim.RowAdam")
         self.towers, self.opt, self.loss_fn = towers, optimizer, loss_fn
-        self.logq_table = None if logq_table is None else _lib.dev_f32(logq_table, "logq_table").reshape(-1)
+        self.set_logq_table(logq_table)
         self.kind_mask = (1 << len(losses.KINDS)) - 1 if all_losses else 1 << loss_fn.kind
         self.user, self.item = towers["user"].weight, towers["item"].weight
         if self.user.shape[1] != self.item.shape[1] or towers["user"].normalize != towers["item"].normalize:
@@ -38,6 +38,11 @@ class FusedSmallStep:
         if isinstance(optimizer, optim.RowAdam):
             optimizer.init_state()
         self._group = {id(p): g for g in optimizer.param_groups for p in g["params"]}
+
+    def set_logq_table(self, logq_table: torch.Tensor | None) -> None:
+        """The logQ table the NEXT steps use (None: no correction) -- read at every call, so a table set or refreshed after
+        the first step is honoured (the module's ``logq`` may appear after the first fused step)."""
+        self.logq_table = None if logq_table is None else _lib.dev_f32(logq_table, "logq_table").reshape(-1)
 
     def supported(self, batch) -> bool:
         b, n = batch["user"].numel(), batch["item"].numel()
@@ -84,12 +89,12 @@ class FusedSmallStep:
         adam = isinstance(self.opt, optim.RowAdam)
         if adam:
             su, si = self.opt.state[self.user], self.opt.state[self.item]
-            su["step"] += 1
-            si["step"] += 1
             if su["step"] != si["step"]:
                 raise _lib.MfHipError("the two tables' Adam step counts differ: they were not always stepped together")
             b1, b2 = group["betas"]
-            args_opt = (1, su["step"], None, group["lr"], b1, b2, group["eps"], group["weight_decay"])
+            # the counters are committed only after the launch has been accepted (a refused call must not advance the
+            # bias corrections of later steps -- ADVICE r3)
+            args_opt = (1, su["step"] + 1, None, group["lr"], b1, b2, group["eps"], group["weight_decay"])
             state = (su["exp_avg"].data_ptr(), su["exp_avg_sq"].data_ptr(), si["exp_avg"].data_ptr(), si["exp_avg_sq"].data_ptr())
         else:
             args_opt = (0, 1, None, group["lr"], 0.0, 0.0, 0.0, group["weight_decay"])
@@ -103,6 +108,9 @@ class FusedSmallStep:
             0 if csr is None else n_pos_users, user_ids.numel(), item_ids.numel(), fn.kind, self.kind_mask, int(fn.num_negatives),
             float(fn.sigma), float(fn.margin), _lib.ptr(lq), 0 if lq is None else lq.numel(), *args_opt, self._ws.data_ptr(),
             self._ws.numel(), out.data_ptr(), _lib.stream_ptr()))
+        if adam:
+            su["step"] += 1
+            si["step"] += 1
         self.fused_steps += 1
         self.losses = out
         return out[fn.kind]

@@ -225,6 +225,8 @@ class MatrixFactorizationLitModule(_Base):
                                                    logq_table=self.logq if (cfg.use_logq and self.logq is not None) else None)
             except mf_losses._lib.MfHipError:        # hash towers, a foreign optimiser: the ordinary three calls
                 self._fused = None
+        if self._fused is not None:                  # the table of THIS step (it may be set / refreshed after the first one)
+            self._fused.set_logq_table(self.logq if (cfg.use_logq and self.logq is not None) else None)
         if self._fused is None:
             loss = self.training_step(batch)
             loss.backward()

@@ -308,7 +308,21 @@ class EmbeddingLoss(torch.nn.Module, abc.ABC):
 
     @property
     def kind(self) -> int:
-        return KINDS.index(type(self).__name__)
+        """Which of the seven kernels' losses this instance is.  Upstream a subclass is free to bring its own ``loss`` /
+        ``score_loss_fn`` (losses.py:81-90, 342, 348-349) because everything is a torch expression; here the arithmetic is
+        compiled into ``libmf_hip.so``, so a class (or a patched ``score_loss_fn``) the kernels do not know is refused
+        loudly instead of being trained as something else."""
+        known = next((c for c in type(self).__mro__ if c.__module__ == __name__ and c.__name__ in KINDS), None)
+        if known is None:
+            msg = (f"{type(self).__name__} is not one of the seven losses compiled into libmf_hip.so ({', '.join(KINDS)}): "
+                   "a custom EmbeddingLoss needs its own kernel -- subclass one of the seven, or override loss() with torch code")
+            raise NotImplementedError(msg)
+        phi = known.__dict__.get("score_loss_fn")
+        if phi is not None and ("score_loss_fn" in self.__dict__ or type(self).score_loss_fn is not phi):
+            msg = (f"{type(self).__name__}.score_loss_fn differs from {known.__name__}'s: the kernels apply the built-in "
+                   "softplus / relu per tile element and would ignore it")
+            raise NotImplementedError(msg)
+        return KINDS.index(known.__name__)
 
     def check_inputs(self, user_embed: torch.Tensor, item_embed: torch.Tensor, target: torch.Tensor) -> None:
         check_inputs(user_embed, item_embed, target)

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import losses as ol
+from oracle import embed as oembed, losses as ol
+from tests.conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -394,6 +395,63 @@ def test_fused_small_step_is_bit_identical_to_the_multi_kernel_step(mf, cfg):
     assert fused.fallback_steps == 1
 
 
+@pytest.mark.parametrize("path_kind", ["one_launch", "multi_kernel"])
+@pytest.mark.parametrize("opt_name", ["sgd", "adam"])
+def test_default_step_matches_the_reference_on_a_table_consistent_fixture(mf, opt_name, path_kind):
+    """``mf_step_small`` (and the multi-kernel sequence it must equal) against the REFERENCE, not against another HIP path:
+    tests/golden/step_B32_N64_d32_P16.npz holds raw tables, ids (duplicates share rows), and what xfmr_rec/losses.py +
+    torch.autograd + torch.optim.SGD / AdamW make of them at the reference's default shape (params.py:18,
+    lightning.py:33,38-39,189-192,238-239).  Per trained loss: all seven ``out_losses`` within 1e-4 of the reference's
+    values; the tables after the step against the fixture's (SGD: 1e-5 abs; AdamW's first step is lr * g / (|g| + eps),
+    compared where |g| > 1e-4), and against oracle.embed.sgd_update fed the reference's du / dv through
+    oracle.embed.normalize_backward; untouched rows bit-unchanged."""
+    z = np.load(GOLDEN / "step_B32_N64_d32_P16.npz")
+    t = {k: torch.from_numpy(z[k]) for k in ("U", "V", "user", "item", "target", "pos_idx")}
+    k = int(z["num_negatives"])
+    batch = {"user": t["user"].to(DEV), "item": t["item"].to(DEV), "target": t["target"].to(DEV), "pos": t["pos_idx"].to(DEV)}
+    one = torch.ones((), device=DEV)
+    for ki, kind in enumerate(ol.KINDS):
+        if ki == 0:
+            continue                                  # AlignmentLoss has no negatives to mine: not a one-launch shape
+        towers = mf.models.init_towers(mf.models.ModelConfig(num_users=t["U"].shape[0], num_items=t["V"].shape[0], hidden_size=32), device=DEV)
+        with torch.no_grad():
+            towers["user"].weight.copy_(t["U"].to(DEV))
+            towers["item"].weight.copy_(t["V"].to(DEV))
+        opt = (mf.optim.SparseSGD(towers.parameters(), lr=float(z["lr_sgd"])) if opt_name == "sgd"
+               else mf.optim.RowAdam(towers.parameters(), lr=float(z["lr_adam"]), weight_decay=0.0))
+        fn = getattr(mf.losses, kind)(num_negatives=k)
+        if path_kind == "one_launch":
+            step = mf.fused.FusedSmallStep(towers, opt, fn, all_losses=True)
+            got = step(batch)
+            assert step.fused_steps == 1 and step.fallback_steps == 0
+            seven = step.losses.cpu().numpy()
+            for kj, other in enumerate(ol.KINDS):
+                want = float(z[f"loss_{kj}"])
+                assert abs(float(seven[kj]) - want) <= 1e-4 * max(1.0, abs(want)), (kind, other, float(seven[kj]), want)
+        else:
+            got = fn(towers["user"](batch["user"]), towers["item"](batch["item"]), batch["target"], item_idx=batch["item"], pos_idx=batch["pos"])
+            got.backward(one)
+            opt.step()
+        want = float(z[f"loss_{ki}"])
+        assert abs(float(got) - want) <= 1e-4 * max(1.0, abs(want)), (kind, float(got), want)
+        for name, ids, tab in (("U", t["user"], towers["user"].weight), ("V", t["item"], towers["item"].weight)):
+            new = tab.detach().cpu()
+            touched = torch.zeros(new.shape[0], dtype=torch.bool)
+            touched[ids] = True
+            assert torch.equal(new[~touched], t[name][~touched]), (kind, name)
+            if opt_name == "sgd":
+                np.testing.assert_allclose(new.numpy(), z[f"{name}_sgd_{ki}"], rtol=0, atol=1e-5, err_msg=f"{kind} {name}")
+                small = "du" if name == "U" else "dv"
+                raw = oembed.normalize_backward(t[name][ids], torch.from_numpy(z[f"{small}_{ki}"]))
+                mine = t[name].clone()
+                oembed.sgd_update(mine, ids, raw, float(z["lr_sgd"]))
+                np.testing.assert_allclose(new.numpy(), mine.numpy(), rtol=0, atol=1e-5, err_msg=f"{kind} {name} (oracle update)")
+            else:
+                firm = np.abs(z[f"d{name}_{ki}"]) > 1e-4
+                np.testing.assert_allclose(new.numpy()[firm], z[f"{name}_adam_{ki}"][firm], rtol=0, atol=2e-5, err_msg=f"{kind} {name}")
+                assert firm.sum() > 0.5 * touched.sum().item() * new.shape[1]
+
+
 @pytest.mark.parametrize("opt", ["adam", "sgd"])
 def test_module_fused_training_step_equals_the_three_calls(mf, opt):
     """``fused_training_step`` (one launch) against ``training_step`` + ``backward`` + ``optimizer.step()`` at the reference's
@@ -427,6 +485,34 @@ def test_module_fused_training_step_equals_the_three_calls(mf, opt):
             for k in ol.KINDS:
                 assert seen[-1][f"train/{k}"] == float(want[f"train/{k}"]), (step, k)
     assert mb._fused.fused_steps == 3 and mb._fused.fallback_steps == 1
+
+
+def test_fused_training_step_uses_the_logq_table_of_the_step(mf):
+    """``self.logq`` set (None -> table) and refreshed AFTER the first fused step must reach the one-launch path like it
+    reaches ``training_step``: tables torch.equal to the three calls at every step."""
+    def make():
+        torch.manual_seed(7)
+        m = mf.lightning.MatrixFactorizationLitModule({"num_users": 200, "num_items": 300, "learning_rate": 0.05, "use_logq": True,
+                                                       "train_loss": "InfomationNoiseContrastiveEstimationLoss"})
+        m.configure_model(device=DEV)
+        return m, m.configure_optimizers()
+
+    (ma, oa), (mb, ob) = make(), make()
+    data = mf.data.SyntheticInteractions(200, 300, max_positives=7, seed=9)
+    g = torch.Generator().manual_seed(1)
+    tables = [None, torch.rand(300, generator=g).log().to(DEV), torch.rand(300, generator=g).log().to(DEV)]
+    for step, table in enumerate(tables):
+        ma.logq = mb.logq = table
+        batch = mf.data.to_device(data.batch(32), DEV)
+        loss = ma.training_step(batch)
+        loss.backward()
+        oa.step()
+        oa.zero_grad(set_to_none=True)
+        got = mb.fused_training_step(batch, ob)
+        assert float(got) == float(loss), step
+        for name in ("user", "item"):
+            assert torch.equal(ma.towers[name].weight, mb.towers[name].weight), (step, name)
+    assert mb._fused.fused_steps == 3
 
 
 @pytest.mark.parametrize("mode", ["csr", "padded"])

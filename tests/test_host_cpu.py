@@ -107,6 +107,43 @@ def test_check_inputs_raise_like_reference(mf):
         fn(u, v, torch.ones(5), item_idx=torch.arange(8), pos_idx=None)
 
 
+def test_losses_the_kernels_do_not_know_are_refused(mf):
+    """Upstream a subclass supplies its own phi through ``score_loss_fn`` (xfmr_rec/losses.py:342,348-359) or its own
+    ``loss`` (:81-90); here the seven are compiled code.  A renamed subclass of a known loss is that loss; anything whose
+    arithmetic the kernels cannot honour raises NotImplementedError naming the class -- before any GPU work."""
+    L = mf.losses
+
+    class Renamed(L.PairwiseHingeLoss):
+        pass
+
+    class OwnPhi(L.PairwiseEmbeddingLoss):
+        def score_loss_fn(self, score):
+            return score.exp()
+
+    class OverriddenPhi(L.PairwiseLogisticLoss):
+        def score_loss_fn(self, score):
+            return score.relu() ** 2
+
+    class Foreign(L.EmbeddingLoss):
+        pass
+
+    assert Renamed(num_negatives=4).kind == L.KINDS.index("PairwiseHingeLoss")
+    u, v = torch.randn(4, 32), torch.randn(8, 32)
+    for cls, text in ((OwnPhi, "not one of the seven"), (Foreign, "not one of the seven"), (OverriddenPhi, "score_loss_fn differs")):
+        with pytest.raises(NotImplementedError, match=text):
+            cls()(u, v, torch.ones(4), item_idx=torch.arange(8), pos_idx=None)
+    patched = L.PairwiseHingeLoss()
+    patched.score_loss_fn = lambda score: score * 0
+    with pytest.raises(NotImplementedError, match="score_loss_fn differs"):
+        patched(u, v, torch.ones(4), item_idx=torch.arange(8), pos_idx=None)
+
+    class TorchLoss(L.EmbeddingLoss):                      # the upstream extension point that still works: plain torch code
+        def loss(self, user_embed, item_embed, target, **_):
+            return (user_embed.sum() + item_embed.sum()) * target.sum()
+
+    assert float(TorchLoss()(u, v, torch.ones(4), item_idx=torch.arange(8))) == pytest.approx(float((u.sum() + v.sum()) * 4))
+
+
 def test_loss_class_names_and_order(mf):
     module = mf.lightning.MatrixFactorizationLitModule({"num_users": 10, "num_items": 10, "hidden_size": 32})
     with pytest.raises(ValueError, match="`loss_fns` must be initialised first"):
