@@ -58,6 +58,7 @@ struct LossWs {
     unsigned* gtau;
     float* sel_L;
     long long* dvfix;            // mined backward: exact fixed-point accumulator of dv [N][d]
+    float* dvsc;                 // its unit for this batch: {2^E, clamp, 2^-E} (dv_fix_of, mf_loss_math.h)
     size_t total;
 };
 
@@ -115,6 +116,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
     w.rowc = a.take<float>((size_t)4 * w.Bp);
     w.blockpart = a.take<float>((size_t)MF_NUM_KINDS * (w.Bp / 64 + 1));
     w.ticket = a.take<unsigned>(4);
+    w.dvsc = a.take<float>(4);
     if (w.mined) {
         w.cand = a.take<unsigned long long>((size_t)w.Bp * w.plan.rowcap);
         w.priv = a.take<unsigned long long>((size_t)w.plan.nsets * w.Bp * w.plan.CAP);
@@ -1216,24 +1218,50 @@ __global__ __launch_bounds__(256) void diag_bwd_kernel(const float* __restrict__
 }
 
 // Mined backward.  du_i accumulates in registers, in selection order.  dv_j sums contributions of many users:
-// they are added as 64-bit FIXED-POINT integers (2^-40 units) with integer atomics -- integer addition is
-// associative, so the sum is the same bits whatever order the atomics land in (run-to-run deterministic, unlike
-// the fp32 atomics this replaces), and it is rounded to fp32 once, by dv_fix_to_f32_kernel.  A contribution is
-// exact on the 2^-40 grid down to |x| = 2^-17 and off by <= 2^-41 below; |sum| < 2^23.  Lane c of a 32-lane row
-// group owns the features c, c + 32, ..: one atomic instruction covers 256 contiguous bytes of a row.
+// they are added as 64-bit FIXED-POINT integers with integer atomics -- integer addition is associative, so the sum is
+// the same bits whatever order the atomics land in (run-to-run deterministic, unlike the fp32 atomics this replaces),
+// and it is rounded to fp32 once, by dv_fix_to_f32_kernel.  The unit 2^-E is chosen per batch by dv_scale_kernel so
+// that the sum cannot wrap (dv_fix_of, mf_loss_math.h): 2^-40 for ordinary batches -- a contribution is then exact on the
+// grid down to |x| = 2^-17 and off by <= 2^-41 below.  Lane c of a 32-lane row group owns the features c, c + 32, ..:
+// one atomic instruction covers 256 contiguous bytes of a row.
+__global__ __launch_bounds__(1024) void dv_scale_kernel(const float* __restrict__ rowc, const float* __restrict__ grad_out,
+                                                        const float* __restrict__ nu, const float* __restrict__ nv, int64_t B, int64_t N,
+                                                        int64_t Bp, float* __restrict__ dvsc) {
+    // (maxima of magnitudes as unsigned bit patterns: exact, order-free, and the same rule as the one-launch step's)
+    __shared__ unsigned red[3][16];
+    const int tid = threadIdx.x, lane = mf_lane(), wave = mf_wave_id();
+    const float go = grad_out[0];
+    unsigned g = 0u, a = 0u, b = 0u;
+    for (int64_t i = tid; i < B; i += 1024) {
+        g = max(g, max(dv_mag(go * rowc[2 * Bp + i]), dv_mag(go * rowc[3 * Bp + i])));
+        a = max(a, dv_mag(nu[i]));
+    }
+    for (int64_t j = tid; j < N; j += 1024) b = max(b, dv_mag(nv[j]));
+    g = mf_wave_max_u32(g); a = mf_wave_max_u32(a); b = mf_wave_max_u32(b);
+    if (lane == 0) { red[0][wave] = g; red[1][wave] = a; red[2][wave] = b; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) { g = max(g, red[0][w]); a = max(a, red[1][w]); b = max(b, red[2][w]); }
+        const DvFix f = dv_fix_of(__builtin_bit_cast(float, g), __builtin_bit_cast(float, a), __builtin_bit_cast(float, b), (long long)B);
+        dvsc[0] = f.scale; dvsc[1] = f.clamp; dvsc[2] = f.inv;
+    }
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                         const float* __restrict__ rowc, const int32_t* __restrict__ sel,
                                                         const int32_t* __restrict__ sel_cnt,
                                                         const float* __restrict__ sel_L, const float* __restrict__ grad_out,
                                                         int64_t B, int64_t Bp,
-                                                        int gmode, float* __restrict__ du, long long* __restrict__ dvfix) {
+                                                        int gmode, float* __restrict__ du, long long* __restrict__ dvfix,
+                                                        const float* __restrict__ dvsc) {
     constexpr int LPR = 32, NE = D / LPR;            // lanes per row, features per lane (c, c + 32, ...)
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / LPR;
     const int c = (int)(t % LPR);
     if (i >= B) return;
     const float go = grad_out[0];
+    const float fix_scale = dvsc[0], fix_clamp = dvsc[1];
     const float a = rowc[i], b = rowc[Bp + i], cg = go * rowc[2 * Bp + i], gd = go * rowc[3 * Bp + i];
     float ui[NE], acc[NE];
 #pragma unroll
@@ -1250,7 +1278,7 @@ __global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict_
             const float vj = v[j * D + c + LPR * e];
             acc[e] += g * (vj - ui[e]);
             const float dvj = g * (ui[e] - vj);
-            const long long q = (long long)__builtin_rintf(fminf(fmaxf(dvj, -8388607.f), 8388607.f) * DV_FIX_SCALE);
+            const long long q = dv_fix_term(dvj, fix_scale, fix_clamp);
             atomicAdd(o + LPR * e, (unsigned long long)q);       // two's complement: the unsigned add IS the signed add
         }
     }
@@ -1258,10 +1286,11 @@ __global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict_
     for (int e = 0; e < NE; ++e) du[i * D + c + LPR * e] = acc[e];
 }
 
-__global__ __launch_bounds__(256) void dv_fix_to_f32_kernel(const long long* __restrict__ dvfix, int64_t n, float* __restrict__ dv) {
+__global__ __launch_bounds__(256) void dv_fix_to_f32_kernel(const long long* __restrict__ dvfix, int64_t n, float* __restrict__ dv,
+                                                            const float* __restrict__ dvsc) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
-    dv[t] = (float)((double)dvfix[t] * (1.0 / 1099511627776.0));
+    dv[t] = (float)((double)dvfix[t] * (double)dvsc[2]);
 }
 
 // ------------------------------------------------------------------ C ABI ------
@@ -1502,12 +1531,13 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
         });
     } else if (w.mined) {
         mf_zero_async(w.dvfix, (size_t)N * d * 8, s);
+        dv_scale_kernel<<<dim3(1), 1024, 0, s>>>(w.rowc, grad_out, w.nu, w.nv, B, N, w.Bp, w.dvsc);
         MF_DISPATCH_D(d, {
             const int64_t nthreads = B * 32;
             mined_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, w.sel, w.sel_cnt, w.sel_L, grad_out, B,
-                                                                                        w.Bp, gmode, du, w.dvfix);
+                                                                                        w.Bp, gmode, du, w.dvfix, w.dvsc);
         });
-        dv_fix_to_f32_kernel<<<dim3((unsigned)((N * d + 255) / 256)), 256, 0, s>>>(w.dvfix, N * d, dv);
+        dv_fix_to_f32_kernel<<<dim3((unsigned)((N * d + 255) / 256)), 256, 0, s>>>(w.dvfix, N * d, dv, w.dvsc);
     } else {
         if ((size_t)w.tps_u * 32 * d * 4 > MF_SRD_MAX_BYTES || (size_t)w.tps_v * 32 * d * 4 > MF_SRD_MAX_BYTES)
             return mf_set_error(MF_ENOTSUP, "mf_loss_bwd: a sweep's share of the batch exceeds 4 GiB (buffer descriptor)");

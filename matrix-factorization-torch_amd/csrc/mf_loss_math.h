@@ -119,7 +119,40 @@ __device__ __forceinline__ float g_of(int gmode, float x) {
 }
 
 
-static constexpr float DV_FIX_SCALE = 1099511627776.0f;      // 2^40
+// The mined dV accumulator is a 64-bit fixed-point integer per feature (integer addition commutes: the sum is the same
+// bits in whatever order the terms arrive).  Its unit is 2^-E with E chosen PER BATCH so that the sum can never wrap:
+// every term is g (u_e - v_e) with |g| <= gmax = max_i max(|cg_i|, |gd_i|) (the row coefficients; exp / step / sigmoid
+// factors are <= 1) and |u_e - v_e| <= xmax = sqrt(max |u|^2) + sqrt(max |v|^2); a column receives at most B + 1 terms.
+// With 2^ce > gmax xmax and 2^nb >= B + 2:  E = min(40, 61 - nb - ce), terms clamped to +-2^ce  =>  |sum| < 2^61.
+// E = 40 (the unit every round before used) whenever gmax xmax (B + 2) < 2^21 -- sigma = 1, ratings <= 5, B = 8192 --
+// so those batches keep their bits; sigma = 1000 takes E = 34 at B = 8192 instead of wrapping.  The maxima
+// are exact whatever the reduction order, so the multi-kernel path and the one-launch step pick the same E.
+struct DvFix {
+    float scale;        // 2^E
+    float clamp;        // 2^ce (FLT_MAX when that overflows)
+    float inv;          // 2^-E
+};
+__host__ __device__ static inline DvFix dv_fix_of(float gmax, float nu2max, float nv2max, long long B) {
+    const float p = gmax * (sqrtf(nu2max) + sqrtf(nv2max));
+    int ce = 128;
+    if (p < __builtin_inff()) {                 // (false for NaN too)
+        ce = -126;
+        if (p > 0.f) { (void)frexpf(p, &ce); }  // p = m 2^ce, m in [0.5, 1)
+    }
+    int nb = 1;
+    while ((1ll << nb) < B + 2) ++nb;
+    int E = 61 - nb - ce;
+    E = E > 40 ? 40 : (E < -120 ? -120 : E);
+    DvFix f;
+    f.scale = ldexpf(1.f, E);
+    f.inv = ldexpf(1.f, -E);
+    f.clamp = ce >= 128 ? 3.4028234663852886e38f : ldexpf(1.f, ce);
+    return f;
+}
+__device__ __forceinline__ unsigned dv_mag(float x) { return __builtin_bit_cast(unsigned, x) & 0x7FFFFFFFu; }
+__device__ __forceinline__ long long dv_fix_term(float x, float scale, float clamp) {
+    return (long long)__builtin_rintf(fminf(fmaxf(x, -clamp), clamp) * scale);
+}
 
 
 #endif  // __HIPCC__

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
     float *nu_l = fl, *lii_l = fl + 128, *dii_l = fl + 256, *sgn_l = fl + 384, *tgt_l = fl + 512, *nv_l = fl + 640, *nlq_l = fl + 896,
           *stats_l = fl + 1152, *rowc_l = fl + 2176, *bpart_l = fl + 2688;
     float* bias_l = fl + 2704;                                                  // [2] Adam's bias corrections
+    unsigned* dvred_l = reinterpret_cast<unsigned*>(fl + 2708);                 // [4] magnitudes behind the dV unit: |cg|, |gd| per 64-row block; max |u|^2; max |v|^2
     int32_t* cnt_l = reinterpret_cast<int32_t*>(fl + 2720);                     // [SS_MAXB] selected columns per user
     long long* itemid_l = reinterpret_cast<long long*>(cnt_l + SS_MAXB);        // [SS_MAXN] the columns' item ids
     const long long** lists_l = reinterpret_cast<const long long**>(itemid_l + SS_MAXN);     // [SS_MAXB] the users' positive lists ...
@@ -506,12 +507,21 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
             if (i < B) rowc_row(p.kind, tgt_l[i], sgn_l[i], lii_l[i], acc[ST_CNT], acc[ST_MX], acc[ST_SE], acc[ST_HC], acc[ST_LS],
                                 p.sigma, p.margin, a, b, cg, gd);
             rowc_l[i] = a; rowc_l[Bp + i] = b; rowc_l[2 * Bp + i] = cg; rowc_l[3 * Bp + i] = gd;
+            const unsigned gm = mf_wave_max_u32(i < B ? max(dv_mag(cg), dv_mag(gd)) : 0u);       // (dv_scale_kernel's maxima)
+            if (lane == 0) dvred_l[wave] = gm;
         }
         for (int k = 0; k < MF_NUM_KINDS; ++k) {
             float v = o[k];
             v = mf_wave_sum(v);
             if (lane == 0) bpart_l[k * (Bp / 64) + wave] = v;
         }
+    }
+    else if (wave == 2 || wave == 3) {                          // (Bp / 64 <= 2) the squared-norm maxima: users by wave 2, columns by wave 3
+        unsigned m = 0u;
+        if (wave == 2) { for (int i = lane; i < B; i += 64) m = max(m, dv_mag(nu_l[i])); }
+        else { for (int j = lane; j < N; j += 64) m = max(m, dv_mag(nv_l[j])); }
+        m = mf_wave_max_u32(m);
+        if (lane == 0) dvred_l[wave] = m;
     }
     __syncthreads();
     if (wave == 0) {
@@ -532,6 +542,8 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
         for (int e = tid; e < 2 * N; e += SS_THREADS) colm[e] = 0ull;
         __syncthreads();
         const int gmode = gmode_of(p.kind);
+        const DvFix fix = dv_fix_of(__builtin_bit_cast(float, Bp > 64 ? max(dvred_l[0], dvred_l[1]) : dvred_l[0]),
+                                    __builtin_bit_cast(float, dvred_l[2]), __builtin_bit_cast(float, dvred_l[3]), (long long)B);
         for (int e = tid; e < B * p.k; e += SS_THREADS) {
             const int i = e / p.k, sl = e % p.k;
             if (sl < cnt_l[i]) {
@@ -570,7 +582,7 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float dvj = g * (ui[e] - vj[e]);
-                        sum[e] += (long long)__builtin_rintf(fminf(fmaxf(dvj, -8388607.f), 8388607.f) * DV_FIX_SCALE);
+                        sum[e] += dv_fix_term(dvj, fix.scale, fix.clamp);
                     }
                 };
                 if (j < B) add(j, rowc_l[3 * Bp + j]);
@@ -587,7 +599,7 @@ __global__ __launch_bounds__(SS_THREADS) void step_small_kernel(StepSmallParams 
                 }
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (float)((double)sum[e] * (1.0 / 1099511627776.0));
+                for (int e = 0; e < 4; ++e) o[e] = (float)((double)sum[e] * (double)fix.inv);
                 reinterpret_cast<f32x4*>(dvp + (size_t)j * D)[c] = o;
             }
         }

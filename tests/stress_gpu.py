@@ -1,10 +1,10 @@
-"""Randomised cross-checks of the round-2 kernels (not part of the test suite: minutes of GPU time).
+"""Randomised cross-checks of the kernels (minutes of GPU time as a script; tests/test_gpu_stress.py runs a time-boxed slice).
   * top-k: the three retrieval paths (fp32 tiles, few-query scan, bf16 prefilter) must return the same bits on random
     shapes -- Q, N (incl. N % 32 != 0 and tiny N), d, k, exclusion lists, idx_base, duplicate rows, scaled norms;
   * the one-launch training step against the multi-kernel step (torch.equal) on random small shapes;
   * sparse update: the one-launch path against the oracle's coalesced row-Adam on random id multisets (Zipf, uniform,
     one dominant id, out-of-range ids), and bit-reproducibility of a repeated call.
-    python tests/stress_gpu.py [seconds]      (test infrastructure: it checks the kernels against oracle/; pytest does not collect it)"""
+    python tests/stress_gpu.py [seconds]      (test infrastructure: it checks the kernels against oracle/)"""
 import importlib
 import os
 import sys
@@ -18,7 +18,6 @@ from oracle import embed as oembed  # noqa: E402
 mf = importlib.import_module("matrix-factorization-torch_amd")
 lib = mf._lib.lib()
 dev = torch.device("cuda:0")
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 g = torch.Generator().manual_seed(int(os.environ.get("STRESS_SEED", "1")))
 
 
@@ -223,12 +222,24 @@ def small_step_case():
 
 
 n_kink = 0
-t0, n_ok, n_bad = time.time(), 0, 0
-while time.time() - t0 < budget:
-    only = os.environ.get("STRESS_ONLY")
-    for fn in ((loss_case,) if only == "loss" else (small_step_case,) if only == "small" else (topk_case, update_case, loss_case, small_step_case)):
-        ok = fn()
-        n_ok += ok
-        n_bad += not ok
-print(f"stress: {n_ok} cases ok, {n_bad} failed in {time.time() - t0:.0f} s ({n_kink} hinge-kink flips tolerated)", flush=True)
-sys.exit(1 if n_bad else 0)
+CASES = {"topk": topk_case, "update": update_case, "loss": loss_case, "small": small_step_case}
+
+
+def run(budget: float, only: str | None = None, seed: int | None = None) -> tuple[int, int]:
+    """Round-robin over the case generators for ``budget`` seconds; (cases ok, cases failed)."""
+    if seed is not None:
+        g.manual_seed(seed)
+    fns = (CASES[only],) if only else tuple(CASES.values())
+    t0, n_ok, n_bad = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        for fn in fns:
+            ok = fn()
+            n_ok += ok
+            n_bad += not ok
+    print(f"stress: {n_ok} cases ok, {n_bad} failed in {time.time() - t0:.0f} s ({n_kink} hinge-kink flips tolerated)", flush=True)
+    return n_ok, n_bad
+
+
+if __name__ == "__main__":
+    _, bad = run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, os.environ.get("STRESS_ONLY"))
+    sys.exit(1 if bad else 0)

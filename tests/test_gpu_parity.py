@@ -138,6 +138,44 @@ def test_losses_match_reference_over_the_tuners_range(mf, path):
     assert skipped <= 0.05 * total, (skipped, total)
 
 
+@pytest.mark.parametrize("kind", ["MutualInformationNeuralEstimationLoss", "InfomationNoiseContrastiveEstimationLoss", "PairwiseLogisticLoss"])
+def test_mined_dv_sum_at_its_bound_does_not_wrap(mf, kind):
+    """The mined dV accumulator is 64-bit fixed point (csrc/mf_loss_math.h ``dv_fix_of``).  Worst case of the reference's own
+    range (xfmr_rec/ray.py:147-149): sigma = 1000, |target| = 5, and ONE column mined by every row of B = 8192, every term
+    of the same sign and |u - v| = 2: the column's gradient is ~8e7 > 2^23, where the fixed 2^-40 unit of rounds 1-3 wrapped
+    an int64 silently.  The unit now follows the batch: the column must match the oracle (run on the 8193
+    columns that matter -- the others are never mined), never wrap."""
+    b, n, d, sigma = 8192, 16384, 32, 1000.0
+    g = torch.Generator().manual_seed(11)
+    c = torch.zeros(d)
+    c[0] = 1.0
+    u = torch.nn.functional.normalize(c[None, :] + 0.01 * torch.randn(b, d, generator=g), dim=-1)
+    v = torch.empty(n, d)
+    v[:b] = -u                                   # the positives: as far as a unit vector gets (targets are negative: far = high logit)
+    v[b] = -c                                    # THE column: just below every row's positive -> the closest semi-hard negative of all of them
+    v[b + 1:] = torch.nn.functional.normalize(c[None, :] + 0.3 * torch.randn(n - b - 1, d, generator=g), dim=-1)      # far below
+    target = torch.full((b,), -5, dtype=torch.int64)
+    item_idx = torch.arange(n, dtype=torch.int64) + 100
+    item_idx[:b] = 7                             # one id for every positive: the other rows' positives are accidental hits, never mined
+    fn = getattr(mf.losses, kind)(num_negatives=1, sigma=sigma, margin=1.0)
+    ud, vd = u.to(DEV).requires_grad_(), v.to(DEV).requires_grad_()
+    mask = mf.losses.negative_mask(ud.detach(), vd.detach(), target.to(DEV), item_idx=item_idx.to(DEV), pos_idx=None, num_negatives=1, sigma=sigma)
+    assert bool(mask[:, b].all()) and int(mask.sum()) == b                  # every row mined column b and nothing else
+    val = fn(ud, vd, target.to(DEV), item_idx=item_idx.to(DEV), pos_idx=None)
+    val.backward()
+    uo, vo = u.clone().requires_grad_(), v[: b + 1].clone().requires_grad_()
+    want = ol.loss(kind, uo, vo, target, item_idx=item_idx[: b + 1], pos_idx=None, num_negatives=1, sigma=sigma, margin=1.0)
+    want.backward()
+    assert abs(float(val) - float(want)) <= gu.loss_tolerance(float(want), sigma, target.numpy())
+    dv = vd.grad.cpu().numpy()
+    col = vo.grad[b].numpy()
+    assert np.abs(col).max() > 2.0**23, float(np.abs(col).max())             # the case IS beyond the old accumulator's range
+    assert not dv[b + 1:].any()
+    gu.assert_grads_close(dv[b:b + 1], col[None, :], sigma, (kind, "the column"))
+    gu.assert_grads_close(dv[:b:64], vo.grad[:b:64].numpy(), sigma, (kind, "dv"))
+    gu.assert_grads_close(ud.grad.cpu().numpy()[::64], uo.grad.numpy()[::64], sigma, (kind, "du"))
+
+
 @pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.stem)
 def test_masks_bit_exact_vs_oracle(mf, path):
     z = np.load(path)
