@@ -5,7 +5,8 @@
 // accumulation) and a RIGOROUS error bound decides which rows are rescored with the canonical fp32 fmaf chain:
 //
 //   index      yb = bf16(y) for every catalog row (round to nearest even), ymax = max row norm      (built once)
-//   prep       per query: its exclusion list as a row of bit words, its bf16 fragments in MFMA operand order, counters
+//   prep       per query tile: the exclusion lists as bit words laid out [4-tile block][query][4 words] (what a scan wave
+//              wants for its 32 queries and one block is 512 contiguous bytes), the bf16 fragments in MFMA operand order, counters
 //   seed       a(q, y) = xb_q . yb_y for a SAMPLE of the catalog (one 4-tile block in every `bs`: half of a long
 //              catalog, all of a short one); per query only the maximum of every block (by lane half: two values per
 //              block) is kept -- each is the score of a distinct, non-excluded row, so the k-th largest of them,
@@ -43,7 +44,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 static constexpr int BF3_BLOCK = 4;         // tiles per block: the unit of sampling, of maxima groups and of exclusion-word loads
 static constexpr int BF3_SLOTS = 2;         // hits a lane keeps per query tile and chunk, in registers (more: the query's overflow list)
 static constexpr int BF3_OVF = 256;         // entries of a query's overflow list
-static constexpr int BF3_CAND = 1024;       // candidates rescored per query
+static constexpr int BF3_CAND = 512;        // candidates rescored per query (more: the exact scan of the whole catalog)
 static constexpr int BF3_WAVES = 8;         // waves per scan workgroup
 
 __device__ __forceinline__ unsigned short bf3_round(float x) {
@@ -132,7 +133,9 @@ static Bf3Plan bf3_plan(int64_t Q, int64_t N, int d) {
     p.gy = (int)(p.Qp / per_wg);
     // long catalogs: the bound comes from a quarter of the rows; short ones are sampled whole (few maxima otherwise)
     p.bs = p.nblk >= 256 ? 2 : 1;          // (measured at Q = 1024, N = 62,423: every 4th / 2nd / every block -> 76.5 / 70.4 / 75.9 us, 151 / 78 / 40 candidates per query)
-    if (const char* e = getenv("MF_BF3_BS")) { const int v = atoi(e); if (v >= 1 && p.nblk >= 64 * v) p.bs = v; }   // lab knob
+#ifdef MF_BF3_LAB
+    if (const char* e = getenv("MF_BF3_BS")) { const int v = atoi(e); if (v >= 1 && p.nblk >= 64 * v) p.bs = v; }   // lab knob (make EXTRA=-DMF_BF3_LAB)
+#endif
     p.nvb_seed = (p.nblk + p.bs - 1) / p.bs;
     auto cut = [&](int blocks, int* bpc, int* nwg) {
         int want = (256 + p.gy - 1) / p.gy;                 // one workgroup per CU
@@ -156,7 +159,7 @@ struct Bf3Ws {
     uint32_t* ovf_list;     // [Qp][BF3_OVF]: hits beyond a lane's slots
     int32_t* ovf_cnt;       // [Qp]: their number
     int32_t* ovf;           // [Qp]: the overflow list overflowed too (thousands of duplicate rows, a zero query): exact path
-    uint32_t* exclW;        // [Qp][NTp]: bit r of word t = row 32 t + r is excluded for the query
+    uint32_t* exclW;        // [nblk + 1][Qp][4]: bit r of word (t & 3) of block t / 4 = row 32 t + r is excluded for the query
     size_t total;
 };
 static Bf3Ws bf3_ws(void* base, int64_t Q, int64_t N, int d) {
@@ -170,7 +173,7 @@ static Bf3Ws bf3_ws(void* base, int64_t Q, int64_t N, int d) {
     w.ovf_list = a.take<uint32_t>((size_t)w.plan.Qp * BF3_OVF);
     w.ovf_cnt = a.take<int32_t>((size_t)w.plan.Qp);
     w.ovf = a.take<int32_t>((size_t)w.plan.Qp);
-    w.exclW = a.take<uint32_t>((size_t)w.plan.NTp * w.plan.Qp + 64);
+    w.exclW = a.take<uint32_t>((size_t)(w.plan.nblk + 1) * w.plan.Qp * 4 + 64);
     w.total = a.used();
     return w;
 }
@@ -188,7 +191,7 @@ struct Bf3Scan {
     int bs, bpc, nvb;           // this launch: block stride of the sample, virtual blocks per workgroup, virtual blocks in all
     int xw;                     // distinct query-tile sets among the four waves
     int nvals;
-    const uint32_t* exclW;      // [Qp][NTp]
+    const uint32_t* exclW;      // [nblk + 1][Qp][4]
     float* gmax;                // PASS 0 out: [Qp][nvals]
     const float* thr;           // PASS 1 in
     const bf16x8* xfrag;
@@ -264,15 +267,18 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
             asm volatile("" : "+v"(toff[q]));
         }
     }
-    // exclusion words: lane c (lower half-wave) fetches the 16 bytes = 4 tiles of its query's row; the descriptor starts at the
-    // workgroup's first query (blockIdx only: provably uniform), so offsets stay below 32 XT xw rows of NTp words
+    // exclusion words: lane c (lower half-wave) fetches the 16 bytes = 4 tiles of its query in the block's row of the
+    // [block][query][4] array -- a wave's 32 queries are 512 contiguous bytes.  The descriptor starts at the workgroup's first
+    // block and first query (blockIdx only: provably uniform); the block comes in as the scalar offset
     mf_rsrc_t arsrc;
     uint32_t aoff = MF_SRD_DEAD;
     if (EXCL) {
-        if (lane < 32) aoff = (uint32_t)(((x0 - xb0 + c) * (int64_t)p.NTp) * 4);
+        if (lane < 32) aoff = (uint32_t)((x0 - xb0 + c) * 16);
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint64_t ab = ((uint64_t)p.NTp * (uint64_t)(p.Qp - xb0) + 64u) * 4u;
-        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.exclW + xb0 * p.NTp), 0,
+        const int64_t blk0 = (int64_t)vb0 * p.bs;
+        const int64_t left = ((int64_t)(p.nblk + 1) - blk0) * p.Qp - xb0;      // 16-byte entries from the base to the end of the array
+        const uint64_t ab = left > 0 ? (uint64_t)left * 16u : 0u;
+        arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.exclW + (blk0 * p.Qp + xb0) * 4), 0,
                                                   (int)(ab > MF_SRD_MAX_BYTES ? MF_SRD_MAX_BYTES : ab), 0x00020000);
 #else
         (void)arsrc;
@@ -292,11 +298,11 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
                                                      16, (int)toff[q], soff, 0, 0);
         if (EXCL && (v & 3) == 0) {
             char* dst = exl + ((v >> 2) % L::EXS) * L::EXW;
+            const int boff = live ? (int)((int64_t)(v >> 2) * p.bs * p.Qp * 16) : (int)MF_SRD_DEAD;      // blocks past the workgroup's first
 #pragma unroll
             for (int xt = 0; xt < XT; ++xt)
                 if (lane < 32)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (mf_lds_ptr)(dst + xt * 512), 16,
-                                                             (int)(aoff + (uint32_t)(xt * 32 * p.NTp * 4 + t * 4)), live ? 0 : (int)MF_SRD_DEAD, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (mf_lds_ptr)(dst + xt * 512), 16, (int)(aoff + (uint32_t)(xt * 512)), boff, 0, 0);
         }
 #else
         (void)live;
