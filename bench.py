@@ -567,6 +567,38 @@ def spawn_ranks(args) -> int:
     return worst
 
 
+def restart_on_torch_collectives(why: str) -> None:
+    """The C-side RCCL communicator failed its self-test on some rank: RCCL is then in an unknown state in THIS process
+    (a mismatched or half-completed operation), so nothing more is attempted here -- no in-process continuation.
+    Every rank (``default_comm`` raises on all of them together) agrees on a fresh rendezvous port through the still-working
+    torch.distributed group, tears it down, and starts ONE fresh child of itself with ``MF_COMM=torch`` -- torch.distributed's
+    own RCCL collectives, a few cross-stream joins slower, never a CPU path -- waits for it and exits with its code.  The child
+    of rank 0 prints the JSON line, with ``transport`` = "torch" and a ``comm_note`` saying what happened.  Works the same
+    under ``bench.py --gpus N`` (our own parent) and under ``python -m torch.distributed.run`` (the driver's launcher)."""
+    import subprocess
+    import torch.distributed as dist
+
+    port = int(os.environ.get("MASTER_PORT", "29517")) + 1
+    try:
+        box = [None]
+        if dist.get_rank() == 0:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                box[0] = sk.getsockname()[1]
+        dist.broadcast_object_list(box, src=0)
+        port = int(box[0])
+    except Exception:  # noqa: BLE001  (the agreed fall-back: the old port + 1)
+        pass
+    try:
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
+    print(f"bench.py: {why}; restarting this rank in a fresh process on torch.distributed collectives", file=sys.stderr, flush=True)
+    env = dict(os.environ, MF_COMM="torch", MASTER_PORT=str(port), MF_BENCH_COMM_NOTE=why[:300])
+    sys.exit(subprocess.call([sys.executable, str(pathlib.Path(__file__).resolve()), *sys.argv[1:]], env=env))
+
+
 def dry_run(args, world: int, rank: int) -> None:
     """The launch contract on CPU (no GPU, no kernels): gloo group, W stub warm-up steps, K stub steps between barriers,
     max over ranks, one JSON line from rank 0 with the fields the driver and the tests read."""
@@ -575,6 +607,8 @@ def dry_run(args, world: int, rank: int) -> None:
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if dist.get_world_size() != args.gpus:
         raise SystemExit(2)
+    if os.environ.get("MF_BENCH_FAKE_COMM_FAILURE") == "1" and os.environ.get("MF_COMM") != "torch":
+        restart_on_torch_collectives("mf_comm self-test failed (simulated: MF_BENCH_FAKE_COMM_FAILURE)")      # the restart path, on CPU
     step = lambda i: time.sleep(0.001)          # noqa: E731
     for i in range(args.warmup):
         step(i)
@@ -592,7 +626,8 @@ def dry_run(args, world: int, rank: int) -> None:
                           "n_gpus": int(ranks), "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t) / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
                           "config": {"workload": "dry run: launch / barrier / reduction plumbing only", "parallelism": f"dp{world}"},
-                          "rccl_ranks": None, "transport": "dry-run (gloo, no kernels)"}), flush=True)
+                          "rccl_ranks": None, "transport": "dry-run (gloo, no kernels)",
+                          **({"comm_note": os.environ["MF_BENCH_COMM_NOTE"]} if os.environ.get("MF_BENCH_COMM_NOTE") else {})}), flush=True)
     dist.destroy_process_group()
 
 
@@ -639,19 +674,15 @@ def main() -> None:
         def make_trainer():
             return mf.distributed.ShardedTrainer(mf, device, args.optimizer, args.num_negatives, num_users=NUM_USERS,
                                                  num_items=NUM_ITEMS, dim=DIM, logq=logq_table(device), user_mode=user_mode)
-        comm_note = None
+        comm_note = os.environ.get("MF_BENCH_COMM_NOTE")       # set when this process IS the restarted one
         try:
             trainer = make_trainer()
         except mf._lib.MfHipError as e:
             # default_comm raises on EVERY rank together when the C-side RCCL communicator fails its self-test (it has only
-            # ever run on one rank where this was built): the run goes on with torch.distributed's RCCL collectives -- still
-            # RCCL over xGMI, a few cross-stream joins slower -- and SAYS so (`transport`, `comm_note`)
+            # ever run on one rank where this was built).  RCCL is then in an unknown state HERE: fresh processes take over
             if os.environ.get("MF_COMM") in ("torch", "rccl"):
                 raise
-            comm_note = f"mf_comm self-test failed, fell back to torch.distributed collectives: {e}"
-            print("bench.py: " + comm_note, file=sys.stderr)
-            os.environ["MF_COMM"] = "torch"
-            trainer = make_trainer()
+            restart_on_torch_collectives(f"mf_comm self-test failed: {e}")
         if user_mode == "partitioned":
             span_u = trainer.user_hi - trainer.user_lo
             for b in batches:

@@ -1037,7 +1037,8 @@ __global__ __launch_bounds__(64 * mf_nw(D), (D == 128 || D == 64) ? BWD_MIN_WG :
         const float g = p.grad_out[0];
         xa = p.rowc[x]; xb = p.rowc[p.Bp + x]; xc = g * p.rowc[2 * p.Bp + x]; xd = g * p.rowc[3 * p.Bp + x];
     }
-    const float xa2 = -xa * 1.44269504088896341f;      // exp(L - a) = exp2(L log2e - a log2e)
+    const float xb2 = xb * 1.44269504088896341f;       // exp((L - a) + b) = exp2((L - a) log2e + b log2e): a is the row's largest logit
+                                                       // (L - a: exact where it matters), b = -log(sum) is small -- rowc_row
     f32x16 dacc[D / 32];
 #pragma unroll
     for (int mb = 0; mb < D / 32; ++mb)
@@ -1098,7 +1099,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), (D == 128 || D == 64) ? BWD_MIN_WG :
             // masked logits -> G' (masked entries are -inf: exp / step / sigmoid give exactly 0)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                if (GMODE == G_EXP) Gv[e] = xc * __builtin_amdgcn_exp2f(__builtin_fmaf(Gv[e], 1.44269504088896341f, xa2));   // xb = 0
+                if (GMODE == G_EXP) Gv[e] = xc * __builtin_amdgcn_exp2f(__builtin_fmaf(Gv[e] - xa, 1.44269504088896341f, xb2));
                 else Gv[e] = xc * g_of(GMODE, (Gv[e] - xa) + xb);
             }
             if (ty == xt) {             // only the diagonal tile holds the user's own positive

@@ -90,12 +90,20 @@ __device__ __forceinline__ void rowc_row(int kind, float t, float s, float l, fl
         case MF_ALIGNMENT: gd = -base; break;
         case MF_CONTRASTIVE: b = s * margin; cg = base / den; break;
         case MF_ALIGNMENT_CONTRASTIVE: b = s * margin; cg = base / den; gd = -base; break;
+        // softmax weights as exp((L - max) - log(sum)): `a` is a logit (the subtraction is exact for the logits that matter),
+        // `b` is small.  With a = lse -- one fp32 number at the logits' magnitude, 2000 at sigma = 1000 -- every weight of the
+        // row carried lse's rounding (6e-5 relative at 2000) and the diagonal's 1 - p_ii did not match the sum of the others:
+        // the components of du along v_j ~ v_i lost their leading digits (round 4; torch's log_softmax backward has the form below)
         case MF_INFONCE: {
             const float m2 = fmaxf(mx, l);
-            const float lse = m2 + __logf(se * __expf(mx - m2) + __expf(l - m2));
-            a = lse; cg = base; gd = base * (__expf(l - lse) - 1.f);
+            const float neg = se * __expf(mx - m2);                  // sum over the valid negatives, relative to the row maximum
+            const float se2 = neg + __expf(l - m2);
+            a = m2; b = -__logf(se2); cg = base; gd = -base * (neg / se2);      // 1 - p_ii = (sum of the others) / (sum of all)
         } break;
-        case MF_MINE: a = cnt > 0.f ? mx + __logf(se) : 0.f; cg = cnt > 0.f ? base : 0.f; gd = -base; break;
+        case MF_MINE:
+            if (cnt > 0.f) { a = mx; b = -__logf(se); cg = base; }
+            gd = -base;
+            break;
         case MF_PAIRWISE_HINGE: a = l; b = margin; cg = base / den; gd = -cg * hc; break;
         case MF_PAIRWISE_LOGISTIC: a = l; b = margin; cg = base / den; gd = -cg * ls; break;
     }

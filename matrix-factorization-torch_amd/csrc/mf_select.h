@@ -488,7 +488,15 @@ __global__ __launch_bounds__(64 * mf_nw(D), T >= 32 ? 1 : mf_wg_per_cu(D)) void 
 // rank word; 32 more on the column word only if equal ranks straddle the cut), the <= k winners are
 // compacted and ordered by rank counting.  Lists longer than 64 KPL keys go through in batches, the
 // winners so far riding along.  Returns m = min(n, k); sorted[0..m) (LDS) is in descending key order.
-template <int KPL>
+// WAVE_LOCAL: the calling wave is one of several in its workgroup, each on its OWN win / sorted arrays -- a workgroup barrier
+// would be wrong (the waves run different trip counts); the LDS executes one wave's operations in order, so ordering the
+// compiler is enough.
+template <bool WAVE_LOCAL>
+__device__ __forceinline__ void mf_row_topk_sync() {
+    if (WAVE_LOCAL) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+    else mf_row_topk_sync<WAVE_LOCAL>();
+}
+template <int KPL, bool WAVE_LOCAL = false>
 __device__ __forceinline__ int mf_row_topk(const unsigned long long* __restrict__ src, int n, int k,
                                            unsigned long long* win, unsigned long long* sorted) {
     const int lane = mf_lane();
@@ -502,7 +510,7 @@ __device__ __forceinline__ int mf_row_topk(const unsigned long long* __restrict_
             v[j] = idx < n ? src[idx] : 0ull;
         }
         v[KPL] = lane < carry ? win[lane] : 0ull;
-        __syncthreads();                                   // win[] was read by everyone before it is rewritten
+        mf_row_topk_sync<WAVE_LOCAL>();                                   // win[] was read by everyone before it is rewritten
         const int have = min(n - base, 64 * KPL) + carry;
         unsigned long long tau = 1ull;                     // keeps every real key
         if (have > k) {
@@ -543,7 +551,7 @@ __device__ __forceinline__ int mf_row_topk(const unsigned long long* __restrict_
             pos += __popcll(m);
         }
         carry = pos;                                       // == min(#real keys, k)
-        __syncthreads();
+        mf_row_topk_sync<WAVE_LOCAL>();
     }
     const int m = carry;
     if (lane < m) {
@@ -552,7 +560,7 @@ __device__ __forceinline__ int mf_row_topk(const unsigned long long* __restrict_
         for (int q = 0; q < m; ++q) r += win[q] > mine ? 1 : 0;
         sorted[r] = mine;
     }
-    __syncthreads();
+    mf_row_topk_sync<WAVE_LOCAL>();
     return m;
 }
 

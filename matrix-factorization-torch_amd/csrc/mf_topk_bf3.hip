@@ -137,6 +137,8 @@ static Bf3Plan bf3_plan(int64_t Q, int64_t N, int d) {
     if (const char* e = getenv("MF_BF3_BS")) { const int v = atoi(e); if (v >= 1 && p.nblk >= 64 * v) p.bs = v; }   // lab knob (make EXTRA=-DMF_BF3_LAB)
 #endif
     p.nvb_seed = (p.nblk + p.bs - 1) / p.bs;
+    // (measured and dropped in round 4: XT = 2 at d <= 128 with two workgroups per CU -- the 128-register budget of four waves
+    // per SIMD spills 26..49 registers of the scan)
     auto cut = [&](int blocks, int* bpc, int* nwg) {
         int want = (256 + p.gy - 1) / p.gy;                 // one workgroup per CU
         if (want > blocks) want = blocks;
@@ -155,7 +157,8 @@ struct Bf3Ws {
     float* gmax;            // [Qp][nvals]
     float* thr;             // [Qp]
     bf16x8* xfrag;          // [Qp / 32][d / 16][64]: the queries rounded to bf16, in MFMA operand order
-    uint32_t* cand;         // [nwg x waves per set][Qp][2][BF3_SLOTS]: candidate rows by scan workgroup, query, lane half (0xFFFFFFFF: none)
+    uint32_t* cand;         // [nwg x waves per set][Qp][2 lane halves][4]: {row, row, score - thr, score - thr} of the half's two slots (row 0xFFFFFFFF: none)
+    float* eps;             // [Qp]: the queries' error bounds (written by the bound kernel, read by the final one)
     uint32_t* ovf_list;     // [Qp][BF3_OVF]: hits beyond a lane's slots
     int32_t* ovf_cnt;       // [Qp]: their number
     int32_t* ovf;           // [Qp]: the overflow list overflowed too (thousands of duplicate rows, a zero query): exact path
@@ -169,7 +172,8 @@ static Bf3Ws bf3_ws(void* base, int64_t Q, int64_t N, int d) {
     w.gmax = a.take<float>((size_t)w.plan.Qp * w.plan.nvals);
     w.thr = a.take<float>((size_t)w.plan.Qp);
     w.xfrag = a.take<bf16x8>((size_t)w.plan.Qp * d / 8);
-    w.cand = a.take<uint32_t>((size_t)w.plan.nwg * (BF3_WAVES / w.plan.xw) * w.plan.Qp * 2 * BF3_SLOTS);
+    w.cand = a.take<uint32_t>((size_t)w.plan.nwg * (BF3_WAVES / w.plan.xw) * w.plan.Qp * 2 * 2 * BF3_SLOTS);
+    w.eps = a.take<float>((size_t)w.plan.Qp);
     w.ovf_list = a.take<uint32_t>((size_t)w.plan.Qp * BF3_OVF);
     w.ovf_cnt = a.take<int32_t>((size_t)w.plan.Qp);
     w.ovf = a.take<int32_t>((size_t)w.plan.Qp);
@@ -200,6 +204,7 @@ struct Bf3Scan {
     int32_t* ovf_cnt;
     int32_t* ovf;
     int abl;                    // lab knob (MF_BF3_ABL): 1 = no arithmetic, 2 = hits are not parked, 4 = no query fragments -- wrong results, for timing only
+    unsigned long long* stamps; // lab: [pass][workgroup][4] s_memrealtime at entry / loop start / loop end / exit (NULL: off)
 };
 
 // The scans stage tiles with all eight waves: the tile geometry of mf_stream.h is written for four, so a tile's pieces are
@@ -235,6 +240,10 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
     constexpr int INFLIGHT = (NS - 2) * L::PPW + (EXCL ? XT * ((NS - 2) / BF3_BLOCK) : 0);
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int wave = mf_wave_id();
+#ifdef MF_BF3_LAB
+    unsigned long long* st = p.stamps ? p.stamps + ((size_t)PASS * 4096 + blockIdx.y * gridDim.x + blockIdx.x) * 4 : nullptr;
+    if (st && threadIdx.x == 0) st[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int nsub = BF3_WAVES / p.xw, set = wave % p.xw, sub = wave / p.xw;   // waves of one set deal the chunk's tiles round-robin
     const int64_t xb0 = (int64_t)blockIdx.y * p.xw * XT * 32;               // first query of the workgroup
     const int64_t x0 = xb0 + (int64_t)set * XT * 32;                        // this wave's XT query tiles
@@ -323,16 +332,31 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
         thr[xt] = (PASS == 1 && x < p.Q) ? p.thr[x] : __builtin_inff();      // (bf3_bound_kernel: already nudged below the bound)
     }
     uint32_t slot_[XT][BF3_SLOTS];                            // PASS 1: this lane's hits per query tile, newest first (0xFFFFFFFF: free)
+    float sval_[XT][BF3_SLOTS];                               // ... and their approximate scores minus thr (what the accumulator holds)
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt)
 #pragma unroll
-        for (int j = 0; j < BF3_SLOTS; ++j) slot_[xt][j] = 0xFFFFFFFFu;
-    float gm[XT];                                            // PASS 0: running maximum of the current block
+        for (int j = 0; j < BF3_SLOTS; ++j) { slot_[xt][j] = 0xFFFFFFFFu; sval_[xt][j] = 0.f; }
+    // PASS 0: the running maximum of the lane's share of the current block -- as INTEGER bit patterns (v_max3_i32: two
+    // elements per instruction, no canonicalising moves): for floats of either sign the integer maximum is the float
+    // maximum whenever that is >= 0, and SOME element's value otherwise -- the bound only needs scores of distinct rows --
+    // A lane's 16 rows of a tile that hold a row which must not count for its query (excluded, or past N) are left out of the
+    // maxima whole (~4 % of the shares at 150 exclusions per query: the bound does not notice), instead of a mask select per element.
+    int gmi[XT];
 #pragma unroll
-    for (int xt = 0; xt < XT; ++xt) gm[xt] = -__builtin_inff();
+    for (int xt = 0; xt < XT; ++xt) gmi[xt] = (int)0x80000000;
     const int tail_tile = (p.N & 31) ? p.NT - 1 : -1;        // its rows past N score 0: they are not rows
     const int tail_rows = (int)(p.N & 31);
+    // Round 4: the epilogues were the scans' limit -- every vector instruction beside the MFMAs costs ~2.8 cycles of matrix
+    // time (two waves per SIMD share its issue), and a 32 x 32 x 128 block is only 8 MFMAs = 256 cycles.  PASS 0 went from
+    // ~60 instructions per block (mask select + v_med3 per element, accumulator zeroing) to ~14 (8 v_max3_i32 + the share's
+    // mask test; its accumulators start from the inline constant 0): seed loop 9.5 -> 7.8 us.
+    typedef int i32x16_t __attribute__((ext_vector_type(16)));
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+#ifdef MF_BF3_LAB
+    if (st && threadIdx.x == 0) { asm volatile("" : : "v"(xb[0][0]) : "memory"); st[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     for (int v = 0; v < nv; ++v) {
         // tile v (and, at a block start, the block's exclusion words) is older than what the BLOCK stages behind it issued
         mf_wait_vmcnt<INFLIGHT>();
@@ -351,38 +375,81 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
                 for (int s = 0; s < KS; ++s) afr[s] = *reinterpret_cast<const bf16x8*>(rowp + (((2 * s + h) ^ sw) << 4));
             }
             const uint32_t tdead = t == tail_tile ? (~0u << tail_rows) : 0u;
-            uint32_t hmw[(XT + 1) / 2];                      // PASS 1: 16 hit bits per query tile
-#pragma unroll
-            for (int i = 0; i < (XT + 1) / 2; ++i) hmw[i] = 0u;
-            // epilogue of one query tile's 32 x 32 block (branch-free: it is threaded between the next block's MFMAs):
-            // PASS 0 the running maximum, PASS 1 the hit bits
+            const unsigned row0t = (unsigned)t * 32u + 4u * (unsigned)h;     // element e of this lane is row row0t + (e & 3) + 8 (e >> 2)
+            // epilogue of one query tile's 32 x 32 block
             auto epi = [&](int xt, const f32x16& acc) {
-                uint32_t dead = tdead;
-                if (EXCL) dead |= reinterpret_cast<const uint32_t*>(exl + ((v >> 2) % L::EXS) * L::EXW + xt * 512 + c * 16)[v & 3];
-                // bit e of m: element e (row mf_acc_row(e, h) of the tile) does not count for this lane's query
-                const uint32_t d4 = dead >> (4 * h);
-                const uint32_t m = (d4 & 0xFu) | ((d4 >> 4) & 0xF0u) | ((d4 >> 8) & 0xF00u) | ((d4 >> 12) & 0xF000u);
                 if (PASS == 0) {
-                    // (v_med3(a, b, +inf) = max(a, b) on finite scores, without the NaN-quieting moves fmaxf asks for)
+                    uint32_t dead = tdead;
+                    if (EXCL) dead |= reinterpret_cast<const uint32_t*>(exl + ((v >> 2) % L::EXS) * L::EXW + xt * 512 + c * 16)[v & 3];
+                    // (the whole vector is bit-cast, THEN indexed: a bit-cast of an extracted element is folded to element 0 by
+                    // this compiler, the same family as the permlane swap fold in mf_common.h)
+                    const i32x16_t ai = __builtin_bit_cast(i32x16_t, acc);
+                    int g = (int)0x80000000;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float x = (EXCL || true) ? (((m >> e) & 1u) ? -__builtin_inff() : acc[e]) : acc[e];
-                        gm[xt] = __builtin_amdgcn_fmed3f(gm[xt], x, __builtin_inff());
-                    }
+                    for (int e = 0; e < 16; e += 2) g = max(max(g, ai[e]), ai[e + 1]);
+                    // the lane's 16 rows of this tile (4 h + {0..3} + 8 j) hold a row that must not count: the tile's share is left out
+                    g = ((dead >> (4 * h)) & 0x0F0F0F0Fu) != 0u ? (int)0x80000000 : g;
+                    gmi[xt] = max(gmi[xt], g);
                 } else {
                     // bit e: element e reaches the bound.  The accumulators START at -thr (the matrix core does the subtraction: a
                     // lane's 16 elements are one query's), so ONE instruction per element shifts the sign of score - thr in
                     // (v_alignbit), last element first; sign clear = hit.  (The extra rounding of the accumulation from -thr is
-                    // inside eps' allowance for the accumulations, bf3_bound_kernel.)
+                    // inside eps' allowance for the accumulations, bf3_bound_kernel.)  Measured against it in round 4: 16 compares
+                    // into wave masks + scalar "any" + a branch per element -- fewer vector instructions, 23 us instead of 17.
                     uint32_t hm = 0u;
-                    // (the whole vector is bit-cast, THEN indexed: `bit_cast<uint32_t>(acc[e])` -- a bit-cast of an extracted element --
-                    // is folded to element 0 by this compiler, the same family as the permlane swap fold in mf_common.h)
                     typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
                     const u32x16_t ab = __builtin_bit_cast(u32x16_t, acc);
 #pragma unroll
                     for (int e = 15; e >= 0; --e) hm = __builtin_amdgcn_alignbit(hm, ab[e], 31);
+                    const uint32_t d4 = tdead >> (4 * h);            // rows past N (the last tile): they score 0, they are not rows
+                    const uint32_t m = (d4 & 0xFu) | ((d4 >> 4) & 0xF0u) | ((d4 >> 8) & 0xF00u) | ((d4 >> 12) & 0xF000u);
                     hm = ~hm & 0xFFFFu & ~m;
-                    hmw[xt >> 1] |= hm << (16 * (xt & 1));
+                    // Hits are parked HERE, while the accumulator still holds the block: a slot keeps the row and its score - thr,
+                    // so that the final kernel can cut the candidates a second time, against the k-th best approximate score of
+                    // the WHOLE catalog (the seed's bound saw half of it): ~78 -> ~40 rows whose fp32 copies are gathered.
+                    if (__any(hm != 0u) && !(p.abl & 2)) {
+                        uint32_t w = hm;
+                        uint32_t xword = 0u;
+                        if (EXCL) xword = reinterpret_cast<const uint32_t*>(exl + ((v >> 2) % L::EXS) * L::EXW + xt * 512 + c * 16)[v & 3];
+                        while (w) {                              // (1.3 hits per block of 1024 elements: rarely a second trip)
+                            const int e = __builtin_ctz(w);
+                            w &= w - 1;
+                            const unsigned row = row0t + (unsigned)((e & 3) + 8 * (e >> 2));
+                            // a row on the query's exclusion list is dropped here (the block's words are in LDS): the final kernel's
+                            // second cut then needs no exclusion words -- one dependent memory round trip less in its chain
+                            if (EXCL && ((xword >> (row & 31u)) & 1u)) continue;
+                            // element e of the accumulator, e differing from lane to lane: a select tree over the 16 registers
+                            // (v_cndmask by hand: the compiler rewrites a select between two elements of a vector into a dynamic vector
+                            // index and answers it through scratch memory.  The accumulator was last written long before -- the sixteen
+                            // v_alignbit above have read it -- so no MFMA hazard is in reach of these instructions)
+                            const unsigned long long m8 = __ballot((e & 8) != 0), m4 = __ballot((e & 4) != 0), m2 = __ballot((e & 2) != 0),
+                                                     m1 = __ballot((e & 1) != 0);
+                            auto pick = [](float lo, float hi, unsigned long long msk) {
+                                float o;
+                                asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(lo), "v"(hi), "s"(msk));
+                                return o;
+                            };
+                            float t8[8], t4[4], t2[2];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) t8[i] = pick(acc[i], acc[8 + i], m8);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) t4[i] = pick(t8[i], t8[4 + i], m4);
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) t2[i] = pick(t4[i], t4[2 + i], m2);
+                            const float val = pick(t2[0], t2[1], m1);
+                            if (slot_[xt][BF3_SLOTS - 1] == 0xFFFFFFFFu) {      // a free slot left
+#pragma unroll
+                                for (int j = BF3_SLOTS - 1; j > 0; --j) { slot_[xt][j] = slot_[xt][j - 1]; sval_[xt][j] = sval_[xt][j - 1]; }
+                                slot_[xt][0] = row;
+                                sval_[xt][0] = val;
+                            } else {                              // beyond the slots: the query's overflow list (an atomic: rare)
+                                const int64_t x = x0 + 32 * xt + c;
+                                const int at = atomicAdd(&p.ovf_cnt[x], 1);
+                                if (at < BF3_OVF) p.ovf_list[x * BF3_OVF + at] = row;
+                                else p.ovf[x] = 1;
+                            }
+                        }
+                    }
                 }
             };
             if constexpr (D <= 128 && PASS == 1 && XT > 1) {
@@ -407,18 +474,24 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
                 for (int xt = 0; xt < XT; ++xt) {
                     f32x16& cur = (xt & 1) ? accB : accA;
                     const f32x16& prev = (xt & 1) ? accA : accB;
-                    float nt = PASS == 1 ? -thr[xt] : 0.f;
-                    if (PASS == 1) asm volatile("" : "+v"(nt));
+                    if (PASS == 1) {
+                        float nt = -thr[xt];
+                        asm volatile("" : "+v"(nt));
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) cur[e] = nt;
+                        for (int e = 0; e < 16; ++e) cur[e] = nt;
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], xb[xt][s], cur, 0, 0, 0);
+                        for (int s = 0; s < KS; ++s) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], xb[xt][s], cur, 0, 0, 0);
+                    } else {
+                        cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], xb[xt][0], zero16, 0, 0, 0);
+#pragma unroll
+                        for (int s = 1; s < KS; ++s) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[s], xb[xt][s], cur, 0, 0, 0);
+                    }
                     if (xt > 0) {
                         epi(xt - 1, prev);
 #pragma unroll
                         for (int s = 0; s < KS; ++s) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x006, (PASS == 1 ? 32 : 64) / KS, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x006, (PASS == 1 ? 32 : 16) / KS, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -445,56 +518,36 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
                     epi(xt, acc);
                 }
             }
-            if (PASS == 1) {
-                bool any = false;
-#pragma unroll
-                for (int i = 0; i < (XT + 1) / 2; ++i) any = any || hmw[i] != 0u;
-                if (__any(any) && !(p.abl & 2)) {
-                    const unsigned row0t = (unsigned)t * 32u + 4u * (unsigned)h;
-#pragma unroll
-                    for (int xt = 0; xt < XT; ++xt) {
-                        uint32_t w = (hmw[xt >> 1] >> (16 * (xt & 1))) & 0xFFFFu;
-                        while (w) {                              // (a few per query and workgroup: rarely more than one trip)
-                            const int e = __builtin_ctz(w);
-                            w &= w - 1;
-                            const unsigned row = row0t + (unsigned)((e & 3) + 8 * (e >> 2));
-                            if (slot_[xt][BF3_SLOTS - 1] == 0xFFFFFFFFu) {      // a free slot left
-#pragma unroll
-                                for (int j = BF3_SLOTS - 1; j > 0; --j) slot_[xt][j] = slot_[xt][j - 1];
-                                slot_[xt][0] = row;
-                            } else {                              // beyond the slots: the query's overflow list (an atomic: rare)
-                                const int64_t x = x0 + 32 * xt + c;
-                                const int at = atomicAdd(&p.ovf_cnt[x], 1);
-                                if (at < BF3_OVF) p.ovf_list[x * BF3_OVF + at] = row;
-                                else p.ovf[x] = 1;
-                            }
-                        }
-                    }
-                }
-            }
         }
         if (PASS == 0 && (v & 3) == 3) {
             // one block done: the maximum per (query, lane half) over THIS wave's tiles of the block (the waves of a set deal
-            // the tiles among them: each writes its own value -- scores of distinct rows either way)
+            // the tiles among them: each writes its own value -- scores of distinct rows either way); -inf: no row in sight
             const int vb = vb0 + (v >> 2);
 #pragma unroll
             for (int xt = 0; xt < XT; ++xt) {
                 const int64_t x = x0 + 32 * xt + c;
-                if (x < p.Q) p.gmax[x * p.nvals + ((int64_t)vb * 2 + h) * nsub + sub] = gm[xt];
-                gm[xt] = -__builtin_inff();
+                const float gmf = gmi[xt] == (int)0x80000000 ? -__builtin_inff() : __builtin_bit_cast(float, gmi[xt]);
+                if (x < p.Q) p.gmax[x * p.nvals + ((int64_t)vb * 2 + h) * nsub + sub] = gmf;
+                gmi[xt] = (int)0x80000000;
             }
         }
     }
     mf_wait_vmcnt<0>();                                      // nothing of this workgroup may still be on its way into LDS when it ends
+#ifdef MF_BF3_LAB
+    if (st && threadIdx.x == 0) st[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (PASS == 1) {
-        // this lane's slots of every query tile: 8 bytes each, a wave's 32 queries x 2 halves contiguous (no counters, no atomics)
+        // this lane's slots of every query tile: 16 bytes each, a wave's 32 queries x 2 halves contiguous (no counters, no atomics)
 #pragma unroll
         for (int xt = 0; xt < XT; ++xt) {
             const int64_t x = x0 + 32 * xt + c;
-            *reinterpret_cast<uint2*>(p.cand + ((((int64_t)blockIdx.x * nsub + sub) * p.Qp + x) * 2 + h) * BF3_SLOTS) =
-                uint2{slot_[xt][0], slot_[xt][1]};
+            *reinterpret_cast<uint4*>(p.cand + ((((int64_t)blockIdx.x * nsub + sub) * p.Qp + x) * 2 + h) * (2 * BF3_SLOTS)) =
+                uint4{slot_[xt][0], slot_[xt][1], __builtin_bit_cast(uint32_t, sval_[xt][0]), __builtin_bit_cast(uint32_t, sval_[xt][1])};
         }
     }
+#ifdef MF_BF3_LAB
+    if (st && threadIdx.x == 0) { mf_wait_vmcnt<0>(); st[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // ------------------------------------------------------------------- bound ----
@@ -502,7 +555,8 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
 // share of the maxima to its two best; the k-th largest of those 128 values (all scores of distinct rows) is at
 // most a few ranks below the exact k-th largest, at a tenth of the cost of searching all of them.
 __global__ __launch_bounds__(64) void bf3_bound_kernel(const float* __restrict__ gmax, int nvals, int k, const float* __restrict__ q,
-                                                       int d, const float* __restrict__ ymax2, float* __restrict__ thr) {
+                                                       int d, const float* __restrict__ ymax2, float* __restrict__ thr,
+                                                       float* __restrict__ eps_out) {
     const int64_t r = blockIdx.x;
     const int lane = mf_lane();
     const unsigned ninf = mf_orderable(-__builtin_inff());
@@ -539,18 +593,21 @@ __global__ __launch_bounds__(64) void bf3_bound_kernel(const float* __restrict__
         t = t - fabsf(t) * 0x1p-22f - 1e-37f;
         if (!(t == t)) t = -__builtin_inff();
         thr[r] = t;
+        eps_out[r] = eps;
     }
 }
 
 // ------------------------------------------------------------------- final ----
 struct Bf3Final {
+    int64_t Q;
     const float* q;
     const float* items;
     int64_t N;
     int d, k, NT, NTp;
     int64_t Qp;
     int nlists;                 // candidate blocks per query: scan workgroups x waves sharing a query tile
-    const uint32_t* cand;       // [nlists][Qp][2][BF3_SLOTS]
+    const uint32_t* cand;       // [nlists][Qp][2][2 BF3_SLOTS]: rows, then their scores - thr
+    const float* eps;           // [Qp]
     const uint32_t* ovf_list;
     const int32_t* ovf_cnt;
     const int32_t* ovf;
@@ -559,7 +616,8 @@ struct Bf3Final {
     float* out_scores;
     int64_t* out_idx;
     int abl;                    // lab knob (MF_BF3_ABL): 8 = no rescoring, 16 = no selection -- wrong results, for timing only
-    unsigned long long* dbg;    // lab: [0] += candidates gathered, [1] += queries (NULL: off)
+    unsigned long long* dbg;    // lab: [0] += candidates gathered, [1] += queries, [2] += candidates rescored (NULL: off)
+    unsigned long long* stamps; // lab: [query][8] s_memrealtime at the phases of the final kernel (NULL: off)
 };
 
 // the canonical chain (mf_dot_chain's order) with up to 128 floats of the row in flight at a time
@@ -583,136 +641,228 @@ __device__ __forceinline__ float bf3_exact_dot(const float* xq, const float* __r
     return acc;
 }
 
-// One wave per query.  (Two waves sharing the rescoring rounds measured SLOWER, 19.2 -> 22.6 us: 45 KB of LDS per workgroup
-// leave 3 workgroups per CU, and 1024 queries no longer run in one round of workgroups.)
-static constexpr int BF3_FWAVES = 1;
+// The second cut (one wave, its own list in LDS: {orderable(score - thr) << 32 | row}, n <= 64 VPL entries).  Every row whose
+// approximate score a reaches thr is in the list (that is what the full scan guarantees; rows on the exclusion list were
+// dropped by it), so the k-th largest a in the list, tau', is the k-th largest a of the whole admissible catalog: k distinct
+// rows have exact scores >= tau' - eps, and a row of the exact top k has a >= tau' - 2 eps.  The seed's bound saw half of the
+// catalog; this one sees all of it -- the list shrinks from ~78 to ~40 rows before any fp32 row is fetched.  Rows of unknown
+// score (overflow list; thr = -inf) are kept and not counted.  Leaves the survivors' ROWS at the list's front; returns their
+// number.
+template <int VPL>
+__device__ __forceinline__ int bf3_second_cut(unsigned long long* keys, int n, int k, float eps) {
+    constexpr unsigned ORD_INF = 0xFF800000u;
+    const int lane = mf_lane();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long kk[VPL];
+    unsigned ov[VPL];                                        // orderable scores that count (0: unknown / none)
+    int known = 0;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int i = lane + 64 * j;
+        kk[j] = i < n ? keys[i] : 0ull;
+        const unsigned o = (unsigned)(kk[j] >> 32);
+        ov[j] = (kk[j] != 0ull && o != ORD_INF) ? o : 0u;
+        known += __popcll(__ballot(ov[j] != 0u));
+    }
+    unsigned cut = 0u;                                       // (fewer than k known scores: nothing can be cut)
+    if (known >= k) {
+        unsigned th = 0u;
+        for (int b = 31; b >= 0; --b) {                      // largest th with #{ov >= th} >= k
+            const unsigned cnd = th | (1u << b);
+            int cge = 0;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) cge += __popcll(__ballot(ov[j] >= cnd));
+            if (cge >= k) th = cnd;
+        }
+        float t = mf_unorderable(th) - 2.f * eps;
+        t = t - fabsf(t) * 0x1p-22f - 1e-37f;                // strictly below the bound
+        cut = (t == t) ? mf_orderable(t) : 0u;
+    }
+    mf_row_topk_sync<true>();                                // (every entry is in a register by now)
+    int n2 = 0;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const bool keep = kk[j] != 0ull && (unsigned)(kk[j] >> 32) >= cut;
+        const unsigned long long bal = __ballot(keep);
+        if (keep) keys[n2 + __popcll(bal & below)] = kk[j] & 0xFFFFFFFFull;      // (row ids for now)
+        n2 += __popcll(bal);
+    }
+    mf_row_topk_sync<true>();
+    return n2;
+}
+
+// One wave per query, FOUR queries (waves) per workgroup.  Round 4:
+//  * the scan's slot blocks are laid out [block][query][32 bytes]: one query's share is 244 pieces on 244 cache lines, each
+//    line shared with three neighbours -- a wave per query fetched 32 MB of lines for 8 MB of slots (5.7 of its 13.6 us).  The
+//    four waves of a workgroup take four NEIGHBOURING queries and read their blocks together: 128 contiguous bytes per
+//    block, every byte used once, the entries dealt to the queries' LDS lists with LDS atomics;
+//  * a second cut (below) halves the list before any fp32 row is fetched;
+//  * the survivors' fp32 rows are GATHERED BY LDS-DMA -- `global_load_lds_dwordx4` takes a 64-bit address per lane, so one
+//    instruction brings 64 / (D / 4) whole rows (1 KiB) and all instructions of a round are in flight together: ONE memory
+//    round trip per round of 64 candidates (round 3 went through registers, a chunk of 64 floats at a time).  The 16-byte
+//    chunks of candidate s land XOR-swizzled by s & 15 (on the SOURCE address: the DMA's destination is lane-linear), so the
+//    16 lanes of a ds_read_b128 phase -- 16 candidates, the same chunk -- hit 64 different banks.  Then every lane runs the
+//    canonical chain over ITS candidate's row from LDS.
+// After the gather the waves never meet again: every later synchronisation is wave-local.
+static constexpr int BF3_FQ = 4;                        // queries (waves) per workgroup of the final kernel
 template <int D>
-__global__ __launch_bounds__(64 * BF3_FWAVES) void bf3_final_kernel(Bf3Final p) {
-    constexpr int CH = 64;                                   // floats of a row staged at a time (the chain runs chunk after chunk)
-    constexpr int ROWF = CH + 4;                             // LDS row stride in floats: + 16 bytes, so 16 lanes reading 16 bytes at the
-                                                             // same offset of 16 different rows hit 64 different banks
-    __shared__ __attribute__((aligned(16))) float rows_all[BF3_FWAVES * 64 * ROWF];      // 17 KiB per wave
-    __shared__ int s_n, s_overflow;
-    __shared__ unsigned long long keys[BF3_CAND];
-    __shared__ unsigned long long win[64], sorted[64];
-    __shared__ __attribute__((aligned(16))) float xq[256];
-    const int64_t r = blockIdx.x;
+struct Bf3FinalGeom {
+    static constexpr int CPR = D / 4;                   // 16-byte chunks of an fp32 row: 16, 32, 64
+    static constexpr int RPI = 64 / CPR;                // rows per DMA instruction: 4, 2, 1
+    static constexpr int RB = D <= 128 ? 64 : 32;       // candidates per round (32 KiB of rows at d >= 128, 16 at d = 64)
+    static constexpr int NI = RB / RPI;                 // DMA instructions of a full round
+};
+template <int D>
+__global__ __launch_bounds__(64 * BF3_FQ) void bf3_final_kernel(Bf3Final p) {
+    using G = Bf3FinalGeom<D>;
+    extern __shared__ __attribute__((aligned(1024))) char fsm[];
     const int lane = mf_lane(), wave = mf_wave_id();
-    float* rows_lds = rows_all + wave * 64 * ROWF;
+    // per wave: rows [RB][D] floats | keys [BF3_CAND] | win [64] | sorted [64] | xq [D]; behind them the four list lengths
+    constexpr int PER_WAVE = G::RB * D * 4 + BF3_CAND * 8 + 64 * 8 * 2 + D * 4;
+    char* mine_ = fsm + wave * PER_WAVE;
+    float* rows_lds = reinterpret_cast<float*>(mine_);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(mine_ + G::RB * D * 4);
+    unsigned long long* win = keys + BF3_CAND;
+    unsigned long long* sorted = win + 64;
+    float* xq = reinterpret_cast<float*>(sorted + 64);
+    int* lcnt = reinterpret_cast<int*>(fsm + BF3_FQ * PER_WAVE);          // [BF3_FQ] entries appended to the queries' lists
+    auto keys_of = [&](int qq) { return reinterpret_cast<unsigned long long*>(fsm + qq * PER_WAVE + G::RB * D * 4); };
+    const int64_t q0 = (int64_t)blockIdx.x * BF3_FQ;
+    const int64_t r = q0 + wave;
+    const bool real = r < p.Q;
     const unsigned long long below = (1ull << lane) - 1ull;
     int n = 0;
-    bool overflow = false;
-    if (wave == 0) {
-    // everything the wave needs first, in ONE round trip: the query, the overflow counters, its 16 bytes (two lane halves x
-    // BF3_SLOTS rows) of every scan workgroup's candidate block
-    static_assert(BF3_SLOTS == 2, "one 16-byte load = the two lane halves of a block");
-    for (int i = lane; i < p.d; i += 64) xq[i] = p.q[r * p.d + i];
-    const int novf = p.ovf_cnt[r];
-    overflow = p.ovf[r] != 0 || novf > BF3_OVF;
-    for (int j0 = 0; j0 < p.nlists; j0 += 64 * 4) {          // four 16-byte loads in flight per lane (256 blocks: one trip)
-        uint4 v4[4];
+#ifdef MF_BF3_LAB
+    unsigned long long* st = (p.stamps && real && r < 4096) ? p.stamps + (size_t)2 * 4096 * 4 + r * 8 : nullptr;
+#define BF3_STAMP(i) do { if (st && lane == 0) st[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BF3_STAMP(i) do { } while (0)
+#endif
+    BF3_STAMP(0);
+    if (threadIdx.x < BF3_FQ) lcnt[threadIdx.x] = 0;
+    __syncthreads();
+    static_assert(BF3_SLOTS == 2 && BF3_FQ == 4, "a block's share of the workgroup = 4 queries x 2 lane halves x 16 bytes = 128 bytes");
+    constexpr unsigned ORD_INF = 0xFF800000u;                // mf_orderable(+inf): "score unknown" (overflow-list entries)
+    // the workgroup's records: block j, query q0 + qq, lane half hh -> 16 bytes {row, row, score, score}; record index
+    // 8 j + 2 qq + hh is also its position in memory (Qp is a multiple of 32: the four queries never straddle a row end)
+    {
+        const int nrec = p.nlists * 8;
+        constexpr int PF = 8;                                  // records in flight per thread (244 blocks: one trip)
+        for (int i0 = 0; i0 < nrec; i0 += 64 * BF3_FQ * PF) {
+            uint4 v[PF];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = j0 + jj * 64 + lane;                 // block j: {half 0 slots, half 1 slots}
-            v4[jj] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            if (j < p.nlists) v4[jj] = *reinterpret_cast<const uint4*>(p.cand + (((int64_t)j * p.Qp + r) * 2) * BF3_SLOTS);
-        }
+            for (int j = 0; j < PF; ++j) {
+                const int idx = i0 + j * 64 * BF3_FQ + (int)threadIdx.x;
+                v[j] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+                if (idx < nrec) v[j] = *reinterpret_cast<const uint4*>(p.cand + (((int64_t)(idx >> 3) * p.Qp + q0) * 2) * (2 * BF3_SLOTS) + (idx & 7) * 4);
+            }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const uint32_t w4[4] = {v4[jj].x, v4[jj].z, v4[jj].y, v4[jj].w};      // (slots fill from the front: first slots first)
+            for (int j = 0; j < PF; ++j) {
+                const int idx = i0 + j * 64 * BF3_FQ + (int)threadIdx.x;
+                const int qq = (idx >> 1) & 3;
+                const uint32_t rw[2] = {v[j].x, v[j].y}, vl[2] = {v[j].z, v[j].w};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const bool ok = w4[t] != 0xFFFFFFFFu;
-                const unsigned long long bal = __ballot(ok);
-                if (!bal) continue;
-                const int at = n + __popcll(bal & below);
-                if (ok && at < BF3_CAND) keys[at] = (unsigned long long)w4[t];    // (row ids for now)
-                n += __popcll(bal);
+                for (int t = 0; t < 2; ++t) {
+                    if (rw[t] != 0xFFFFFFFFu) {
+                        // (orderable score - thr above, the row below; a non-finite score -- thr = -inf: fewer than k rows were
+                        // in sight of the seed -- counts as unknown)
+                        const float a = __builtin_bit_cast(float, vl[t]);
+                        const unsigned oa = (a - a == 0.f) ? mf_orderable(a) : ORD_INF;
+                        const int at = atomicAdd(&lcnt[qq], 1);
+                        if (at < BF3_CAND) keys_of(qq)[at] = ((unsigned long long)oa << 32) | (unsigned long long)rw[t];
+                    }
+                }
             }
         }
     }
+    if (real) for (int i = lane; i < D; i += 64) xq[i] = p.q[r * D + i];
+    const int novf = real ? p.ovf_cnt[r] : 0;
+    const float eps = real ? p.eps[r] : 0.f;
+    bool overflow = real && (p.ovf[r] != 0 || novf > BF3_OVF);
+    __syncthreads();                                         // the four lists are complete; from here on every wave is on its own
+    if (!real) return;
+    n = lcnt[wave];
     for (int i0 = 0; i0 < min(novf, BF3_OVF); i0 += 64) {
         const bool ok = i0 + lane < novf;
         const uint32_t row = ok ? p.ovf_list[r * BF3_OVF + i0 + lane] : 0u;
         const unsigned long long bal = __ballot(ok);
         const int at = n + __popcll(bal & below);
-        if (ok && at < BF3_CAND) keys[at] = (unsigned long long)row;
+        if (ok && at < BF3_CAND) keys[at] = ((unsigned long long)ORD_INF << 32) | (unsigned long long)row;
         n += __popcll(bal);
     }
     overflow = overflow || n > BF3_CAND;
     if (p.dbg && lane == 0) { atomicAdd(p.dbg, (unsigned long long)n); atomicAdd(p.dbg + 1, 1ull); }
-    if (lane == 0) { s_n = n; s_overflow = overflow ? 1 : 0; }
+    mf_row_topk_sync<true>();
+    BF3_STAMP(1);
+    if (!overflow && n > 0) {
+        int n2;
+        if (n <= 64) n2 = bf3_second_cut<1>(keys, n, p.k, eps);
+        else if (n <= 128) n2 = bf3_second_cut<2>(keys, n, p.k, eps);
+        else n2 = bf3_second_cut<BF3_CAND / 64>(keys, n, p.k, eps);
+        if (p.dbg && lane == 0) atomicAdd(p.dbg + 2, (unsigned long long)n2);
+        n = n2;
     }
-    __syncthreads();
-    n = s_n;
-    overflow = s_overflow != 0;
+    BF3_STAMP(2);
     int m = 0;
     if (!overflow) {
-        // Exact rescoring, 64 candidates a round.  The rows are fetched by the WAVE -- D/4 lanes per row, whole 512-byte rows
-        // per half-wave instruction -- into LDS, then every lane runs the canonical chain over ITS candidate's row from there
-        // (one row per lane straight from memory meant 64 cache lines per load instruction and each line fetched four times:
-        // 6.7 us per round).  A candidate on the query's exclusion list gets no key (the scan does not look at exclusions).
-        constexpr int LPR = CH / 4, RPI = 64 / LPR;          // lanes per row chunk (256 bytes), rows per load instruction
-        const uint32_t* xrow = p.exclW ? p.exclW + r * p.NTp : nullptr;
-        // Stages = (round of 64 candidates) x (chunk of CH floats), software-pipelined one deep: the loads of stage s + 1 are in
-        // flight while stage s is copied to LDS and consumed -- a round trip per ROUND instead of one per chunk (and the
-        // second round's first chunk travels under the first round's last).
-        constexpr int NCH = D / CH;
-        const int rounds = (p.abl & 8) ? 0 : (n + 63) / 64;
-        const int S = rounds * NCH;
-        auto issue = [&](int st, f32x4 (&ld)[64 / RPI]) {
-            const int base = (st / NCH) * 64, c0 = (st % NCH) * CH;
+        // (candidates on the query's exclusion list were dropped with the second cut: the full scan does not look at exclusions)
+        const int pz = lane % G::CPR, sub = lane / G::CPR;   // this lane's piece of a DMA instruction: chunk position, row among RPI
+        const int sl = lane & (G::RB - 1);                   // the candidate slot this lane scores (d = 256: the lower half-wave)
+        const float* row_l = rows_lds + sl * D;
+        const int sw = sl & 15;
+#ifdef MF_BF3_LAB
+        const int rounds_cap = (p.abl & 8) ? 0 : (1 << 30);
+#else
+        constexpr int rounds_cap = 1 << 30;
+#endif
+        for (int base = 0; base < n && base < rounds_cap; base += G::RB) {
+            const int nr = min(G::RB, n - base);
+            const bool have = lane < nr;
+            const unsigned row = have ? (unsigned)keys[base + lane] : 0u;          // (LDS reads BEFORE the first DMA is issued)
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the row ids have arrived
 #pragma unroll
-            for (int it = 0; it < 64 / RPI; ++it) {
-                const int sel = it * RPI + lane / LPR;
-                ld[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (base + sel < n) ld[it] = *reinterpret_cast<const f32x4*>(p.items + (int64_t)(unsigned)keys[base + sel] * D + c0 + 4 * (lane % LPR));
-            }
-        };
-        const float* row_l = rows_lds + lane * ROWF;
-        float acc = 0.f;
-        unsigned row = 0u;
-        bool have = false, ex = false;
-        auto consume = [&](int st, f32x4 (&ld)[64 / RPI]) {
-            const int base = (st / NCH) * 64, c0 = (st % NCH) * CH;
-            if (c0 == 0) {                                   // a round begins: this lane's candidate
-                have = base + lane < n;
-                row = have ? (unsigned)keys[base + lane] : 0u;
-                ex = have && xrow ? ((xrow[row >> 5] >> (row & 31)) & 1u) != 0u : false;
-                acc = 0.f;
-            }
+            for (int t = 0; t < G::NI; ++t) {
+                if (t * G::RPI < nr) {                       // (wave-uniform)
+                    // the candidate this lane fetches a piece of: slot RPI t + sub (compile-time lanes: v_readlane, no LDS traffic
+                    // between the DMAs -- the compiler drains vmcnt before any LDS access it cannot tell apart from their target)
+                    unsigned rr = (unsigned)__builtin_amdgcn_readlane((int)row, G::RPI * t);
 #pragma unroll
-            for (int it = 0; it < 64 / RPI; ++it)
-                *reinterpret_cast<f32x4*>(rows_lds + (it * RPI + lane / LPR) * ROWF + 4 * (lane % LPR)) = ld[it];
-            __syncthreads();
+                    for (int j = 1; j < G::RPI; ++j) {
+                        const unsigned rj = (unsigned)__builtin_amdgcn_readlane((int)row, G::RPI * t + j);
+                        rr = sub == j ? rj : rr;
+                    }
+                    const int ch = pz ^ ((G::RPI * t + sub) & 15);
+                    const float* src = p.items + (int64_t)rr * D + 4 * ch;
+                    __builtin_amdgcn_global_load_lds((mf_glb_ptr)src, (mf_lds_ptr)(rows_lds + t * 256), 16, 0, 0);
+                }
+            }
+            // (a REAL s_waitcnt, not inline asm: the compiler's own counter tracking must see it, or it assumes the loads above
+            // still pending at the loop's back edge and drains vmcnt in front of every DMA of the next round)
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+            asm volatile("" ::: "memory");
+            if (base == 0) BF3_STAMP(3);
+            float acc = 0.f;
 #pragma unroll 4
-            for (int g = 0; g < CH; g += 8) {                // k order of mf_dot_chain
-                const f32x4 a = *reinterpret_cast<const f32x4*>(row_l + g), b = *reinterpret_cast<const f32x4*>(row_l + g + 4);
-                const f32x4 xa = *reinterpret_cast<const f32x4*>(xq + c0 + g), xb = *reinterpret_cast<const f32x4*>(xq + c0 + g + 4);
+            for (int g = 0; g < D / 8; ++g) {                // k order of mf_dot_chain
+                const f32x4 a = *reinterpret_cast<const f32x4*>(row_l + (((2 * g) ^ sw) << 2));
+                const f32x4 b = *reinterpret_cast<const f32x4*>(row_l + (((2 * g + 1) ^ sw) << 2));
+                const f32x4 xa = *reinterpret_cast<const f32x4*>(xq + 8 * g), xb = *reinterpret_cast<const f32x4*>(xq + 8 * g + 4);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     acc = __builtin_fmaf(xa[t], a[t], acc);
                     acc = __builtin_fmaf(xb[t], b[t], acc);
                 }
             }
-            __syncthreads();                                 // (the chunk has been consumed by every lane; the row ids of this round are read)
-            if (c0 + CH == D && have) keys[base + lane] = ex ? 0ull : mf_key_retrieval(acc, row);
-        };
-        f32x4 ldA[64 / RPI], ldB[64 / RPI];
-        if (S > 0) issue(0, ldA);
-        for (int st = 0; st < S; st += 2) {
-            if (st + 1 < S) issue(st + 1, ldB);
-            consume(st, ldA);
-            if (st + 1 < S) {
-                if (st + 2 < S) issue(st + 2, ldA);
-                consume(st + 1, ldB);
-            }
+            if (have) keys[base + lane] = mf_key_retrieval(acc, row);
         }
-        __syncthreads();
-        if (p.abl & 16) m = 0;
-        else if (n <= 64) m = mf_row_topk<1>(keys, n, p.k, win, sorted);
-        else if (n <= 256) m = mf_row_topk<4>(keys, n, p.k, win, sorted);
-        else m = mf_row_topk<BF3_CAND / 64>(keys, n, p.k, win, sorted);
+        mf_row_topk_sync<true>();
+        BF3_STAMP(4);
+#ifdef MF_BF3_LAB
+        if (p.abl & 16) n = 0;
+#endif
+        if (n <= 64) m = mf_row_topk<1, true>(keys, n, p.k, win, sorted);
+        else if (n <= 256) m = mf_row_topk<4, true>(keys, n, p.k, win, sorted);
+        else m = mf_row_topk<BF3_CAND / 64, true>(keys, n, p.k, win, sorted);
     } else {
         // the whole catalog by the exact chain, 64 rows a round; the winners so far ride along in win[]
         int carry = 0;
@@ -720,11 +870,11 @@ __global__ __launch_bounds__(64 * BF3_FWAVES) void bf3_final_kernel(Bf3Final p) 
             const int64_t row = base + lane;
             unsigned long long v0 = 0ull;
             if (row < p.N) {
-                const bool ex = p.exclW && ((p.exclW[r * p.NTp + (row >> 5)] >> (row & 31)) & 1u);
+                const bool ex = p.exclW && ((p.exclW[((row >> 7) * p.Qp + r) * 4 + ((row >> 5) & 3)] >> (row & 31)) & 1u);
                 if (!ex) v0 = mf_key_retrieval(bf3_exact_dot<D>(xq, p.items + row * D), (unsigned)row);
             }
             const unsigned long long v1 = lane < carry ? win[lane] : 0ull;
-            __syncthreads();
+            mf_row_topk_sync<true>();
             const int have = __popcll(__ballot(v0 != 0ull)) + carry;
             unsigned long long tau = 1ull;
             if (have > p.k) {
@@ -748,7 +898,7 @@ __global__ __launch_bounds__(64 * BF3_FWAVES) void bf3_final_kernel(Bf3Final p) 
                 pos += __popcll(m1);
             }
             carry = pos;
-            __syncthreads();
+            mf_row_topk_sync<true>();
         }
         m = carry;
         if (lane < m) {
@@ -757,8 +907,9 @@ __global__ __launch_bounds__(64 * BF3_FWAVES) void bf3_final_kernel(Bf3Final p) 
             for (int qq = 0; qq < m; ++qq) rk += win[qq] > mine ? 1 : 0;
             sorted[rk] = mine;
         }
-        __syncthreads();
+        mf_row_topk_sync<true>();
     }
+    BF3_STAMP(5);
     if (lane < p.k) {
         if (lane < m) {
             p.out_scores[r * p.k + lane] = mf_key_retrieval_score(sorted[lane]);
@@ -770,44 +921,69 @@ __global__ __launch_bounds__(64 * BF3_FWAVES) void bf3_final_kernel(Bf3Final p) 
     }
 }
 
-// Prep, one workgroup per (padded) query: its bf16 fragments in MFMA operand order (zeros for padding queries), its
-// candidate counters, and -- with exclusion lists -- its row of bit words, through an LDS window (no memset, no global atomics)
-static constexpr int BF3_EXCL_WIN = 8192;       // words per window (262,144 catalog rows)
+// Prep, one workgroup per FOUR queries: their bf16 fragments in MFMA operand order (zeros for padding queries), their
+// candidate counters, and -- with exclusion lists -- their bit words through an LDS window (no memset, no global atomics),
+// written out as [4-tile block][query][4 words]: a scan wave's 32 queries x one block are 512 contiguous bytes (round 3 kept a
+// row of words per query: that DMA touched 32 cache lines for 512 bytes).  The four lists are one contiguous range of the CSR
+// array: all 256 threads stride over it with their loads in flight together; a workgroup writes 64-byte pieces, its
+// neighbours the rest of the line.
+static constexpr int BF3_PREP_Q = 4;            // queries per workgroup
+static constexpr int BF3_PREP_W = 2048;         // words per query in a window (65,536 catalog rows; longer catalogs: more windows)
 __global__ __launch_bounds__(256) void bf3_prep_kernel(const int64_t* __restrict__ excl_off, const int64_t* __restrict__ excl_idx,
-                                                       int64_t idx_base, int64_t Q, int64_t N, int NT, int NTp,
+                                                       int64_t idx_base, int64_t Q, int64_t Qp, int64_t N, int nblk,
                                                        uint32_t* __restrict__ exclW, const float* __restrict__ q, int d,
                                                        bf16x8* __restrict__ xfrag, int32_t* __restrict__ ovf_cnt, int32_t* __restrict__ ovf) {
-    __shared__ uint32_t win[BF3_EXCL_WIN];
-    const int64_t r = blockIdx.x;
-    const bool real = r < Q;
-    // lane (c, h) of query tile r / 32, step s: k = 16 s + 8 h .. + 7
-    if ((int)threadIdx.x < d / 8) {
-        const int s = threadIdx.x >> 1, h = threadIdx.x & 1;
+    __shared__ __attribute__((aligned(16))) uint32_t win[BF3_PREP_Q][BF3_PREP_W];
+    const int64_t q0 = (int64_t)blockIdx.x * BF3_PREP_Q;
+    const int tid = threadIdx.x;
+    // entry (query j, step s, lane half h): k = 16 s + 8 h .. + 7 of query q0 + j, at its place in the 32-query tile's block
+    for (int e = tid; e < BF3_PREP_Q * (d / 8); e += 256) {
+        const int j = e & (BF3_PREP_Q - 1), sh = e / BF3_PREP_Q, s = sh >> 1, h = sh & 1;
+        const int64_t r = q0 + j;
         bf16x8 f = {};
-        if (real) {
+        if (r < Q) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(q + r * d + 16 * s + 8 * h);
             const f32x4 b = *reinterpret_cast<const f32x4*>(q + r * d + 16 * s + 8 * h + 4);
             f = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
         }
         xfrag[((r >> 5) * (d / 16) + s) * 64 + h * 32 + (r & 31)] = f;
     }
-    if (threadIdx.x == 0) { ovf_cnt[r] = 0; ovf[r] = 0; }
+    if (tid < BF3_PREP_Q) { ovf_cnt[q0 + tid] = 0; ovf[q0 + tid] = 0; }
     if (!exclW) return;
-    const int64_t e0 = real && excl_off ? excl_off[r] : 0, e1 = real && excl_off ? excl_off[r + 1] : 0;
-    for (int w0 = 0; w0 < NTp; w0 += BF3_EXCL_WIN) {
-        const int nw = min(BF3_EXCL_WIN, NTp - w0);
-        for (int i = threadIdx.x; i < nw; i += 256) win[i] = 0u;
+    int64_t off[BF3_PREP_Q + 1];
+#pragma unroll
+    for (int j = 0; j <= BF3_PREP_Q; ++j) off[j] = excl_off[min(q0 + j, Q)];      // (padding queries: empty lists)
+    const int nwords = (nblk + 1) * BF3_BLOCK;
+    for (int w0 = 0; w0 < nwords; w0 += BF3_PREP_W) {
+        const int nw = min(BF3_PREP_W, nwords - w0);
+        for (int i = tid; i < BF3_PREP_Q * BF3_PREP_W / 4; i += 256) reinterpret_cast<uint4*>(&win[0][0])[i] = uint4{0u, 0u, 0u, 0u};
         __syncthreads();
-        for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
-            const int64_t y = excl_idx[e] - idx_base;
-            const int64_t wd = (y >> 5) - w0;
-            if (y >= 0 && y < N && wd >= 0 && wd < nw) atomicOr(&win[wd], 1u << (y & 31));
+        for (int64_t eb = off[0]; eb < off[BF3_PREP_Q]; eb += 256 * 4) {
+            int64_t y[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t e = eb + j * 256 + tid;
+                y[j] = e < off[BF3_PREP_Q] ? excl_idx[e] - idx_base : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t e = eb + j * 256 + tid;
+                const int64_t wd = (y[j] >> 5) - w0;
+                if (y[j] >= 0 && y[j] < N && wd >= 0 && wd < nw) {
+                    int qq = 0;                              // the list the entry belongs to (empty lists share a boundary: the last wins)
+#pragma unroll
+                    for (int t = 1; t < BF3_PREP_Q; ++t) qq += off[t] <= e ? 1 : 0;
+                    atomicOr(&win[qq][wd], 1u << (y[j] & 31));
+                }
+            }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < nw; i += 256) exclW[r * NTp + w0 + i] = win[i];
+        for (int i = tid; i < BF3_PREP_Q * (nw / 4); i += 256) {
+            const int qq = i & (BF3_PREP_Q - 1), bb = i / BF3_PREP_Q;
+            *reinterpret_cast<uint4*>(exclW + (((int64_t)(w0 / 4) + bb) * Qp + q0 + qq) * 4) = *reinterpret_cast<const uint4*>(&win[qq][4 * bb]);
+        }
         __syncthreads();
     }
-    (void)NT;
 }
 
 template <int D, int XT, bool EXCL, int PASS>
@@ -826,9 +1002,10 @@ static void bf3_run_xt(const Bf3Ws& w, Bf3Scan sp, bool excl, int k, const float
     const Bf3Plan& pl = w.plan;
     sp.bs = pl.bs; sp.bpc = pl.bpc_seed; sp.nvb = pl.nvb_seed;
     if (excl) bf3_launch_scan<D, XT, true, 0>(pl.nwg_seed, pl.gy, sp, s); else bf3_launch_scan<D, XT, false, 0>(pl.nwg_seed, pl.gy, sp, s);
-    bf3_bound_kernel<<<dim3((unsigned)sp.Q), 64, 0, s>>>(w.gmax, pl.nvals, k, q, D, ymax2, w.thr);
+    bf3_bound_kernel<<<dim3((unsigned)sp.Q), 64, 0, s>>>(w.gmax, pl.nvals, k, q, D, ymax2, w.thr, w.eps);
     sp.bs = 1; sp.bpc = pl.bpc; sp.nvb = pl.nblk;
-    bf3_launch_scan<D, XT, false, 1>(pl.nwg, pl.gy, sp, s);      // (exclusions are applied to the candidates, by the final kernel)
+    // (the full scan stages the exclusion words too: excluded rows are dropped where they are found)
+    if (excl) bf3_launch_scan<D, XT, true, 1>(pl.nwg, pl.gy, sp, s); else bf3_launch_scan<D, XT, false, 1>(pl.nwg, pl.gy, sp, s);
 }
 template <int D>
 static void bf3_run(const Bf3Ws& w, const Bf3Scan& sp, bool excl, int k, const float* q, const float* ymax2, hipStream_t s) {
@@ -838,18 +1015,43 @@ static void bf3_run(const Bf3Ws& w, const Bf3Scan& sp, bool excl, int k, const f
 
 // lab: device counters of the final kernel (candidates gathered, queries); tools/lab/bf3_probe.py
 static unsigned long long* g_bf3_dbg = nullptr;
+static unsigned long long* g_bf3_stamps = nullptr;       // lab: [2 passes][4096 workgroups][4], then [4096 queries][8] of the final kernel
+// lab: out = host buffer of (2 x 4096 x 4 + 4096 x 8) stamps of the LAST search (100 MHz ticks); enable = 1 allocates and switches them on
+extern "C" int mf_probe_bf3_stamps(unsigned long long* out, int enable) {
+    const size_t bytes = ((size_t)2 * 4096 * 4 + (size_t)4096 * 8) * 8;
+    if (!g_bf3_stamps && enable) {
+        if (hipMalloc(reinterpret_cast<void**>(&g_bf3_stamps), bytes) != hipSuccess) return -1;
+        (void)hipMemset(g_bf3_stamps, 0, bytes);
+    }
+    (void)hipDeviceSynchronize();
+    if (out && g_bf3_stamps) (void)hipMemcpy(out, g_bf3_stamps, bytes, hipMemcpyDeviceToHost);
+    return 0;
+}
 extern "C" int mf_probe_bf3_candidates(unsigned long long* out2, int enable) {
     static unsigned long long* buf = nullptr;
     if (!buf) {
-        if (hipMalloc(reinterpret_cast<void**>(&buf), 16) != hipSuccess) return -1;
-        (void)hipMemset(buf, 0, 16);
+        if (hipMalloc(reinterpret_cast<void**>(&buf), 32) != hipSuccess) return -1;
+        (void)hipMemset(buf, 0, 32);
     }
     (void)hipDeviceSynchronize();
-    if (out2) (void)hipMemcpy(out2, buf, 16, hipMemcpyDeviceToHost);
-    (void)hipMemset(buf, 0, 16);
+    if (out2) (void)hipMemcpy(out2, buf, 24, hipMemcpyDeviceToHost);      // (three counters: callers pass room for three)
+    (void)hipMemset(buf, 0, 32);
     g_bf3_dbg = enable ? buf : nullptr;          // counting costs two contended atomics per query: off while timing
     return 0;
 }
+
+template <int D>
+static void bf3_launch_final(unsigned grid, const Bf3Final& fp, hipStream_t s) {
+    using G = Bf3FinalGeom<D>;
+    constexpr int bytes = BF3_FQ * (G::RB * D * 4 + BF3_CAND * 8 + 64 * 8 * 2 + D * 4) + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)bf3_final_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        attr_set = true;
+    }
+    bf3_final_kernel<D><<<dim3(grid), 64 * BF3_FQ, bytes, s>>>(fp);
+}
+#define MF_DISPATCH_BF3_FINAL(DD) if (d == DD) bf3_launch_final<DD>(fgrid, fp, s);
 
 extern "C" int mf_topk_bf3(const float* q, int64_t Q, const float* items, const void* index, int64_t N, int d, int k,
                            const int64_t* excl_off, const int64_t* excl_idx, int64_t idx_base, void* ws, size_t ws_bytes,
@@ -865,28 +1067,32 @@ extern "C" int mf_topk_bf3(const float* q, int64_t Q, const float* items, const 
     const Bf3Plan plan = bf3_plan(Q, N, d);
     const uint64_t span_tiles = (uint64_t)plan.bpc * BF3_BLOCK, span_seed = (uint64_t)plan.bpc_seed * plan.bs * BF3_BLOCK;
     if ((span_tiles > span_seed ? span_tiles : span_seed) * 32 * d * 2 > MF_SRD_MAX_BYTES) return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: chunk beyond 4 GiB");
-    // exclusion words are staged through a 32-bit buffer descriptor based at a workgroup's first query: its 32 XT xw query
-    // rows of NTp words must fit (NT < ~4 M tiles at 256 queries per workgroup: 134 M catalog rows per shard)
-    if (excl_off && ((uint64_t)plan.NTp * (uint64_t)(32 * plan.XT * plan.xw) + 64u) * 4u > MF_SRD_MAX_BYTES)
-        return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: exclusion words of one query block beyond 4 GiB (use mf_topk)");
+    // exclusion words are staged through a 32-bit buffer descriptor based at a workgroup's first block and first query: the
+    // blocks of its chunk (bpc_seed x bs rows of Qp 16-byte entries) plus one workgroup's queries must fit
+    if (excl_off && ((uint64_t)(plan.bpc_seed * plan.bs > plan.bpc ? plan.bpc_seed * plan.bs : plan.bpc) * (uint64_t)plan.Qp +
+                     (uint64_t)(32 * plan.XT * plan.xw)) * 16u + 64u > MF_SRD_MAX_BYTES)
+        return mf_set_error(MF_ENOTSUP, "mf_topk_bf3: exclusion words of one chunk beyond 4 GiB (use mf_topk)");
     if (ws_bytes < mf_topk_bf3_ws_bytes(Q, N, d, k)) return mf_set_error(MF_ENOSPC, "mf_topk_bf3: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Bf3Ws w = bf3_ws(ws, Q, N, d);
     Bf3Index ix = bf3_index(const_cast<void*>(index), N, d);
     const bool excl = excl_off != nullptr;
     MF_TIMED("topk_bf3", s, {
-        bf3_prep_kernel<<<dim3((unsigned)w.plan.Qp), 256, 0, s>>>(excl_off, excl_idx, idx_base, Q, N, w.plan.NT, w.plan.NTp,
-                                                                  excl ? w.exclW : nullptr, q, d, w.xfrag, w.ovf_cnt, w.ovf);
+        bf3_prep_kernel<<<dim3((unsigned)(w.plan.Qp / BF3_PREP_Q)), 256, 0, s>>>(excl_off, excl_idx, idx_base, Q, w.plan.Qp, N, w.plan.nblk,
+                                                                                 excl ? w.exclW : nullptr, q, d, w.xfrag, w.ovf_cnt, w.ovf);
+        int abl = 0;
+#ifdef MF_BF3_LAB
+        if (const char* e = getenv("MF_BF3_ABL")) abl = atoi(e);        // lab build only (make EXTRA=-DMF_BF3_LAB): wrong results, for timing
+#endif
         Bf3Scan sp{Q, w.plan.Qp, ix.plane, N, w.plan.NT, w.plan.NTp, w.plan.nblk, 1, 1, 1, w.plan.xw, w.plan.nvals, w.exclW, w.gmax,
-                   w.thr, w.xfrag, w.cand, w.ovf_list, w.ovf_cnt, w.ovf, getenv("MF_BF3_ABL") ? atoi(getenv("MF_BF3_ABL")) : 0};
+                   w.thr, w.xfrag, w.cand, w.ovf_list, w.ovf_cnt, w.ovf, abl, g_bf3_stamps};
         if (d == 64) bf3_run<64>(w, sp, excl, k, q, ix.ymax2, s);
         else if (d == 128) bf3_run<128>(w, sp, excl, k, q, ix.ymax2, s);
         else bf3_run<256>(w, sp, excl, k, q, ix.ymax2, s);
-        Bf3Final fp{q, items, N, d, k, w.plan.NT, w.plan.NTp, w.plan.Qp, w.plan.nwg * (BF3_WAVES / w.plan.xw), w.cand, w.ovf_list, w.ovf_cnt, w.ovf,
-                    excl ? w.exclW : nullptr, idx_base, out_scores, out_idx, sp.abl, g_bf3_dbg};
-        if (d == 64) bf3_final_kernel<64><<<dim3((unsigned)Q), 64 * BF3_FWAVES, 0, s>>>(fp);
-        else if (d == 128) bf3_final_kernel<128><<<dim3((unsigned)Q), 64 * BF3_FWAVES, 0, s>>>(fp);
-        else bf3_final_kernel<256><<<dim3((unsigned)Q), 64 * BF3_FWAVES, 0, s>>>(fp);
+        Bf3Final fp{Q, q, items, N, d, k, w.plan.NT, w.plan.NTp, w.plan.Qp, w.plan.nwg * (BF3_WAVES / w.plan.xw), w.cand, w.eps, w.ovf_list, w.ovf_cnt, w.ovf,
+                    excl ? w.exclW : nullptr, idx_base, out_scores, out_idx, sp.abl, g_bf3_dbg, g_bf3_stamps};
+        const unsigned fgrid = (unsigned)((Q + BF3_FQ - 1) / BF3_FQ);
+        MF_DISPATCH_BF3_FINAL(64) else MF_DISPATCH_BF3_FINAL(128) else MF_DISPATCH_BF3_FINAL(256)
     });
     return mf_check_launch("mf_topk_bf3");
 }

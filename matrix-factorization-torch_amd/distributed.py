@@ -11,7 +11,8 @@ below is the north-star's and our design:
   (example-sharded data, like the reference's loader): every id is routed to its owner and back (``RowExchange``).
   ``user_mode="partitioned"`` keeps the round-2 fast path -- the user table in contiguous blocks and the training pairs
   partitioned by user shard, so user rows never travel -- and a batch that breaks that promise RAISES (it used to gather
-  a silent zero row);
+  a silent zero row); ``user_mode="replicated"`` is the split the north-star words: item corpus sharded, user table
+  replicated, user-row gradients combined by a sparse all-gather of (row, gradient) and applied by every rank;
 * **hash / bloom towers** (BASELINE config 5: 10 M users x 100 M items do not get a row each): both
   BUCKET tables are dealt round-robin and every id's ``num_hashes`` bucket rows go through the same
   exchange (an id's buckets live on arbitrary ranks);
@@ -80,6 +81,10 @@ class TorchComm:
         dist.all_to_all_single(out, x.contiguous())
         return out
 
+    def for_second_stream(self):
+        """torch's process group orders its collectives itself (its own stream and events): one object serves every stream."""
+        return self
+
 
 class RcclComm:
     """Exchanges by RCCL called from ``libmf_hip.so`` on the CURRENT stream (``mf_comm_*``): no second stream, no
@@ -106,6 +111,14 @@ class RcclComm:
         with torch.cuda.device(device):
             _lib.check(lib.mf_comm_create(self.world, self.rank, ctypes.create_string_buffer(box[0], 128), ctypes.byref(handle)))
         self.handle = handle
+        self.device = device
+
+    def for_second_stream(self):
+        """A SECOND communicator (its own ``ncclCommInitRank``, collective: every rank calls this at the same point).  One
+        ``ncclComm`` must not be driven from two streams at once -- RCCL serialises a communicator's operations only within
+        a stream -- and ``ShardedTrainer.prefetch`` builds the next plan on a side stream while the step's own exchanges run
+        on the compute stream."""
+        return RcclComm(self.device)
 
     @property
     def rccl_ranks(self) -> int:
@@ -365,6 +378,8 @@ class RowExchange:
     C >= len(ids)) -- the exchange is then incomplete and the caller must treat the step as invalid."""
 
     def __init__(self, ids: torch.Tensor, comm, ops=None, capacity: int | None = None, payload: torch.Tensor | None = None) -> None:
+        # ``comm`` serves the plan's own exchanges (counts, requests); ``fetch`` / ``push`` use ``self.comm``, which the trainer
+        # re-points at the compute stream's communicator when a plan built on the side stream is consumed
         self.comm, world = comm, comm.world
         self.ids = ids                                               # keeps the routed ids (and their storage) alive
         n = ids.numel()
@@ -460,7 +475,7 @@ class _LazyCheck:
         return bool(int(self.host[0]))
 
 
-USER_MODES = ("routed", "partitioned")
+USER_MODES = ("routed", "partitioned", "replicated")
 
 
 class ShardedTrainer:
@@ -472,6 +487,12 @@ class ShardedTrainer:
     item rows travel in ONE fused exchange each way.  "partitioned" -- contiguous user blocks, every rank's batch holds
     only users of its own block (``data.DeviceInteractionSampler(user_range=...)``), user rows never travel; a user id
     outside the block raises (at the plan's host read when the plan is exact, one or two steps later otherwise).
+    "replicated" -- the split ``north_star`` words: the ITEM corpus row-sharded, the USER table replicated on every rank
+    (83 MB at ML-25M / d = 128); a rank's batch may hold any users, their rows are read locally (the user half of the forward
+    exchange disappears), and the user-row gradients are combined by a sparse all-gather of ``(row, gradient)`` -- B x (8 + 4 d)
+    bytes per rank, the row-sparse form of the all-reduce of user gradients -- after which EVERY rank applies the
+    same deterministic update (duplicates summed in (rank, batch) order), so the replicas stay bit-identical.  Not for hashed
+    towers (their bucket tables are sharded like the items).
     ``capacity_factor``: per-peer slots of an un-prefetched (capacity-padded) exchange as a multiple of the even share
     ``len(ids) / world``; ``None`` = ``len(ids)`` slots per peer, which can never overflow.  An overflow raises (late, like
     the id check) and leaves the step's updates incomplete -- prefetch plans, or keep ``None``."""
@@ -485,11 +506,15 @@ class ShardedTrainer:
             raise ValueError(msg)
         self.ops = ops if ops is not None else HipOps(mf)
         self.comm = comm if comm is not None else default_comm(device)
+        # the plan stream's own communicator (RcclComm: a second ncclComm; torch's group: the same object)
+        self.plan_comm = self.comm.for_second_stream() if hasattr(self.comm, "for_second_stream") else self.comm
         self.rank, self.world = self.comm.rank, self.comm.world
         self.optimizer, self.num_negatives, self.kind = optimizer, num_negatives, kind
         self.hyper = optimizer_hyper(optimizer, lr)
         self.num_users, self.num_items, self.dim = num_users, num_items, dim
         self.num_hashes, self.hash_seed = int(num_hashes), int(hash_seed)
+        if self.num_hashes and user_mode == "replicated":
+            raise ValueError("user_mode='replicated' is for plain tables (hashed towers shard their bucket tables)")
         self.user_mode = "routed" if self.num_hashes else user_mode
         self.capacity_factor = capacity_factor
         std = 1.0 / (dim * max(self.num_hashes, 1)) ** 0.5
@@ -498,6 +523,9 @@ class ShardedTrainer:
             self.user_lo, self.user_hi = 0, num_users
             self.user_table = self.ops.init_rows(cyclic_rows(num_users, self.world, self.rank), dim, self.rank, self.world, seed,
                                                  std, device)
+        elif self.user_mode == "replicated":                      # every rank generates the WHOLE user table (same counter-based values)
+            self.user_lo, self.user_hi = 0, num_users
+            self.user_table = self.ops.init_rows(num_users, dim, 0, 1, seed, std, device)
         else:                                                     # contiguous user blocks: user rows never travel
             self.user_lo, self.user_hi = shard_bounds(num_users, self.world, self.rank)
             self.user_table = self.ops.init_rows(self.user_hi - self.user_lo, dim, self.user_lo, 1, seed, std, device)
@@ -560,20 +588,21 @@ class ShardedTrainer:
             return n
         return min(n, -(-int(math.ceil(self.capacity_factor * n / self.world)) // 8) * 8)       # (whole 64-byte id lines)
 
-    def _build(self, b, padded: bool) -> tuple:
+    def _build(self, b, padded: bool, comm=None) -> tuple:
         """(item exchange, user exchange or None, bucket rows or None, out-of-shard flag or None)"""
+        comm = comm if comm is not None else self.comm
         cap = (lambda n: self._capacity(n)) if padded else (lambda n: None)   # noqa: E731
         if self.num_hashes:
             ib = self.ops.hash_buckets(b["item"], self.num_hashes, self.hash_seed + 1, self.num_items)
             ub = self.ops.hash_buckets(b["user"], self.num_hashes, self.hash_seed, self.num_users)
-            return (RowExchange(ib, self.comm, self.ops, cap(ib.numel())), RowExchange(ub, self.comm, self.ops, cap(ub.numel())),
+            return (RowExchange(ib, comm, self.ops, cap(ib.numel())), RowExchange(ub, comm, self.ops, cap(ub.numel())),
                     (ub, ib), None)
         if self.user_mode == "routed":
             # ONE exchange for both tables: the users' ids then the items', the table in the payload's lowest bit
             ids = torch.cat([b["user"], b["item"]])
             tag = torch.zeros_like(ids)
             tag[b["user"].numel():] = 1
-            ex = RowExchange(ids, self.comm, self.ops, cap(ids.numel()), payload=ids * 2 + tag)
+            ex = RowExchange(ids, comm, self.ops, cap(ids.numel()), payload=ids * 2 + tag)
             # what this rank has to gather / update for the requests it received, per table (rows of the other table are
             # asked for as -1: a zero row for the gather, skipped by the update) -- part of the PLAN: a dozen tiny
             # launches that used to sit on the step's own stream between the updates and the next forward
@@ -585,17 +614,18 @@ class ShardedTrainer:
             return ex, None, None, None
         user = b["user"]
         bad = ((user < self.user_lo) | (user >= self.user_hi)).any()
-        return RowExchange(b["item"], self.comm, self.ops, cap(b["item"].numel())), None, None, bad
+        return RowExchange(b["item"], comm, self.ops, cap(b["item"].numel())), None, None, bad
 
-    def _new_plan(self, key, b, padded: bool, ready=None) -> _Plan:
-        item, user, buckets, bad = self._build(b, padded)
+    def _new_plan(self, key, b, padded: bool, ready=None, comm=None) -> _Plan:
+        item, user, buckets, bad = self._build(b, padded, comm)
         if bad is not None and not padded:
             # an exact plan has just read its split sizes on the host: one more flag, on the same (plan) stream, costs
             # nothing -- and the error surfaces before the step that would have gathered zero rows
             if bool(bad):
                 msg = (f"user ids outside this rank's shard [{self.user_lo}, {self.user_hi}) in a user-partitioned batch "
                        "(user_mode='partitioned' needs per-rank batches of its own users; use user_mode='routed' for "
-                       "example-sharded data)")
+                       "example-sharded data)" if self.user_mode == "partitioned" else
+                       f"user ids outside the user table [0, {self.num_users})")
                 raise _lib.MfHipError(msg)
             bad = None
         return _Plan(key, item, user, ready, self.steps, buckets, bad)
@@ -613,6 +643,9 @@ class ShardedTrainer:
         if hit is None:
             self.padded_steps += 1
             return self._new_plan(key, b, padded=True)
+        for ex in (hit.item, hit.user):            # built with the plan stream's communicator: the step's exchanges use its own
+            if ex is not None:
+                ex.comm = self.comm
         if hit.ready is not None:                  # built on the side stream: order it before our use
             cur = torch.cuda.current_stream()
             cur.wait_event(hit.ready)
@@ -635,7 +668,7 @@ class ShardedTrainer:
             return
         ids = next_b["item"]
         if not ids.is_cuda:
-            self._plans[key] = self._new_plan(key, next_b, padded=False)
+            self._plans[key] = self._new_plan(key, next_b, padded=False, comm=self.plan_comm)
             return
         cur = torch.cuda.current_stream()
         if self._plan_stream is None:
@@ -646,7 +679,7 @@ class ShardedTrainer:
         else:
             self._plan_stream.wait_stream(cur)      # conservative: everything queued so far
         with torch.cuda.stream(self._plan_stream):
-            plan = self._new_plan(key, next_b, padded=False)
+            plan = self._new_plan(key, next_b, padded=False, comm=self.plan_comm)
             plan.ready = torch.cuda.Event()
             plan.ready.record(self._plan_stream)
         for t in (next_b["item"], next_b["user"]):
@@ -672,8 +705,9 @@ class ShardedTrainer:
                 self._checks.append(_LazyCheck(self.steps, f"exchange capacity exceeded (capacity_factor = {self.capacity_factor}); "
                                                "this step's updates are incomplete", ex.overflow))
         if plan.bad_users is not None:            # (padded plan: nothing is read back now; an exact plan checked at build time)
-            self._checks.append(_LazyCheck(self.steps, f"user ids outside this rank's shard [{self.user_lo}, {self.user_hi}) in a "
-                                           "user-partitioned batch (use user_mode='routed' for example-sharded data); the rows "
+            self._checks.append(_LazyCheck(self.steps, (f"user ids outside this rank's shard [{self.user_lo}, {self.user_hi}) in a "
+                                           "user-partitioned batch (use user_mode='routed' for example-sharded data)" if self.user_mode == "partitioned"
+                                           else f"user ids outside the user table [0, {self.num_users})") + "; the rows "
                                            "were gathered as zeros and not updated", plan.bad_users))
         nb = b["user"].numel()
         if H:
@@ -685,7 +719,7 @@ class ShardedTrainer:
             uid, iid = plan.item.table_ids
             rows = plan.item.fetch(ops.gather(self.user_table, uid, True) + ops.gather(self.item_table, iid, True))
             u, v = rows[:nb], rows[nb:]
-        else:
+        else:                                     # "partitioned" / "replicated": the users' rows are here
             user_local = b["user"] - self.user_lo
             v = plan.item.fetch(ops.gather(self.item_table, plan.item.local_ids, True))
             u = ops.gather(self.user_table, user_local, True)
@@ -702,6 +736,13 @@ class ShardedTrainer:
             owned = plan.item.push(torch.cat([du, dv]))
             ops.update(self.optimizer, self.item_table, self.state["item"], iid, owned, True, self.steps, self.hyper)
             ops.update(self.optimizer, self.user_table, self.state["user"], uid, owned, True, self.steps, self.hyper)
+        elif self.user_mode == "replicated":
+            dv_owned = plan.item.push(dv)
+            ops.update(self.optimizer, self.item_table, self.state["item"], plan.item.local_ids, dv_owned, True, self.steps, self.hyper)
+            # the sparse form of "all-reduce of user gradients": every rank receives every rank's (row, gradient) pairs, in rank
+            # order, and applies ONE update to its replica -- the same list, the same deterministic kernel: identical replicas
+            ids_all, du_all = self.comm.gather(b["user"]), self.comm.gather(du)
+            ops.update(self.optimizer, self.user_table, self.state["user"], ids_all, du_all, True, self.steps, self.hyper)
         else:
             dv_owned = plan.item.push(dv)
             ops.update(self.optimizer, self.item_table, self.state["item"], plan.item.local_ids, dv_owned, True, self.steps, self.hyper)
@@ -735,15 +776,36 @@ class ShardedIndex:
         ours = (d >= 0) & (torch.remainder(d, self.stride) == 0)
         return torch.where(ours, torch.div(d, self.stride, rounding_mode="floor"), torch.full_like(d, -1))
 
-    def search(self, queries: torch.Tensor, top_k: int, *, exclude_csr=None):
+    def search(self, queries: torch.Tensor, top_k: int, *, exclude_csr=None, exclude_capacity: int | None = None):
+        """``exclude_csr = (off [q + 1], ids)``: this rank's queries' exclusion lists (global item rows).  Every rank needs every
+        rank's lists (it scans its shard for ALL queries).  Default: the lists travel at their exact lengths, which costs one
+        host read of the other ranks' lengths per NEW set of lists.  ``exclude_capacity = C`` (a bound on ``ids.numel()`` the
+        caller knows on the host, the same on every rank): every rank sends a block of C entries padded with -1 and the
+        offsets are rebased onto the blocks on the device -- no host sync at all (the padding lands in the last query of each
+        block as ids no shard owns, which the scan ignores)."""
         comm = self.comm
         world = comm.world
         q, d = queries.shape
         all_q = comm.gather(queries)
         csr = None
-        key = None if exclude_csr is None else (exclude_csr[0].data_ptr(), exclude_csr[1].data_ptr(), exclude_csr[1].numel(), q)
+        key = None if exclude_csr is None else (exclude_csr[0].data_ptr(), exclude_csr[1].data_ptr(), exclude_csr[1].numel(), q, exclude_capacity)
         if key is not None and getattr(self, "_csr_key", None) == key:
             csr = self._csr_all                       # same exclusion lists as the last call: gathered once
+        elif exclude_csr is not None and exclude_capacity is not None:
+            off, ids = exclude_csr
+            cap = int(exclude_capacity)
+            if ids.numel() > cap or cap < 1:
+                msg = f"exclude_capacity = {cap} but this rank's lists hold {ids.numel()} entries"
+                raise ValueError(msg)
+            padded = torch.full((cap,), -1, dtype=torch.int64, device=queries.device)
+            padded[: ids.numel()] = ids
+            all_ids = comm.gather(padded)                                        # [world * cap]
+            all_off = comm.gather(off.contiguous()).reshape(world, q + 1)        # every rank's offsets, from 0
+            base = torch.arange(world, device=queries.device, dtype=torch.int64)[:, None] * cap
+            starts = (all_off[:, :q] + base).reshape(-1)                         # query (r, i) starts inside block r ...
+            end = torch.full((1,), world * cap, dtype=torch.int64, device=queries.device)
+            csr = (torch.cat([starts, end]), self._localise(all_ids))            # ... and a block's padding rides with its last query: -1, ignored
+            self._csr_key, self._csr_all, self._csr_src = key, csr, exclude_csr
         elif exclude_csr is not None:
             off, ids = exclude_csr
             n_loc = torch.tensor([ids.numel()], dtype=torch.int64, device=queries.device)

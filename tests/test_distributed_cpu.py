@@ -107,13 +107,13 @@ def _batch(rank: int, world: int, mfd, mode: str = "routed", salt: int = 0):
     """"routed": example-sharded, as the reference's loader deals examples (data/lightning.py:109) -- any user on any rank,
     the same user on several ranks; "partitioned": every rank draws from its own user block."""
     g = torch.Generator().manual_seed(100 + rank + 1000 * salt)
-    lo, hi = mfd.shard_bounds(N_USERS, world, rank) if mode == "partitioned" else (0, N_USERS)
+    lo, hi = mfd.shard_bounds(N_USERS, world, rank) if mode == "partitioned" else (0, N_USERS)      # ("replicated": any user, like "routed")
     item = torch.randint(0, N_ITEMS, (2 * B,), generator=g)
     item[:4] = 3                                       # duplicates, all owned by one rank
     pos = torch.randint(0, N_ITEMS, (B, P), generator=g)
     pos[:, 0] = item[:B]
     user = torch.randint(lo, hi, (B,), generator=g)
-    if mode == "routed":
+    if mode in ("routed", "replicated"):
         user[:3] = 5                                   # one user three times here -- and on every other rank too
     return {"user": user, "item": item, "target": torch.randint(1, 6, (B,), generator=g), "pos": pos}
 
@@ -164,6 +164,10 @@ def _train_case_partitioned(rank: int, world: int, out_dir: str) -> None:
     _train_case(rank, world, out_dir, mode="partitioned")
 
 
+def _train_case_replicated(rank: int, world: int, out_dir: str) -> None:
+    _train_case(rank, world, out_dir, mode="replicated")
+
+
 def _check_train(tmp_path, world: int, mode: str = "routed", tags=("exact", "padded", "cap2"), batch_fn=None, rtol=1e-5, atol=1e-6) -> None:
     """The shards of every rank, put back together, against ONE process applying every rank's gradients (computed from the
     same pre-step tables) in a single sparse update per table."""
@@ -190,7 +194,11 @@ def _check_train(tmp_path, world: int, mode: str = "routed", tags=("exact", "pad
         ops.update(opt, it, st, torch.cat(i_ids), torch.cat(i_g), True, 1, hyper)
         for tag in tags:
             got = [torch.load(f"{tmp_path}/{opt}_{tag}_{r}.pt") for r in range(world)]
-            if mode == "partitioned":                         # contiguous user blocks
+            if mode == "replicated":                          # every rank holds the whole user table: identical replicas
+                users = got[0]["user"]
+                for r in range(1, world):
+                    assert torch.equal(got[r]["user"], users), (opt, tag, r)
+            elif mode == "partitioned":                       # contiguous user blocks
                 users = torch.cat([x["user"] for x in got])
             else:                                             # user rows dealt round-robin, like the items
                 users = torch.empty_like(ut)
@@ -224,6 +232,57 @@ def test_sharded_training_step_user_partitioned(tmp_path):
     _check_train(tmp_path, 2, mode="partitioned")
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_training_step_user_replicated(tmp_path, world):
+    """The split ``north_star`` words: item corpus row-sharded, user table REPLICATED, user-row gradients combined by a
+    sparse all-gather of (row, gradient) that every rank applies -- equal to one process applying every rank's gradients,
+    and the replicas bit-identical to each other (example-sharded batches; exact, padded and tight-capacity item plans)."""
+    _run("_train_case_replicated", tmp_path, world=world)
+    _check_train(tmp_path, world, mode="replicated")
+
+
+class _TaggedComm:
+    """Wraps a communicator and logs which instance served which call."""
+
+    def __init__(self, inner, tag, log):
+        self.inner, self.tag, self.log = inner, tag, log
+        self.world, self.rank, self.transport, self.rccl_ranks = inner.world, inner.rank, inner.transport, None
+
+    def for_second_stream(self):
+        return _TaggedComm(self.inner, "plan", self.log)
+
+    def __getattr__(self, name):
+        fn = getattr(self.inner, name)
+
+        def call(*a, **k):
+            self.log.append((self.tag, name))
+            return fn(*a, **k)
+
+        return call
+
+
+def _two_comm_case(rank: int, world: int, out_dir: str) -> None:
+    mf = importlib.import_module("matrix-factorization-torch_amd")
+    mfd = mf.distributed
+    log = []
+    tr = mfd.ShardedTrainer(mf, "cpu", "sgd", 0, num_users=N_USERS, num_items=N_ITEMS, dim=DIM, ops=OracleOps(), lr=0.05,
+                            kind="PairwiseLogisticLoss", comm=_TaggedComm(mfd.TorchComm(), "step", log))
+    assert tr.plan_comm is not tr.comm and tr.plan_comm.tag == "plan"
+    b = _batch(rank, world, mfd)
+    tr.prefetch(b)
+    assert log and all(tag == "plan" for tag, _ in log), log          # the plan's exchanges: the second communicator only
+    n_plan = len(log)
+    tr.step(b)
+    assert len(log) > n_plan and all(tag == "step" for tag, _ in log[n_plan:]), log[n_plan:]      # fetch / push: the step's own
+    tr.finish()
+
+
+def test_prefetched_plans_use_their_own_communicator(tmp_path):
+    """One ncclComm must not be driven from two streams: a plan prefetched on the side stream exchanges through
+    ``comm.for_second_stream()`` (RcclComm: a second communicator), the step's fetch / push through the step's."""
+    _run("_two_comm_case", tmp_path)
+
+
 def _guard_case(rank: int, world: int, out_dir: str) -> None:
     """Errors instead of silent zero rows / silently dropped rows."""
     mf = importlib.import_module("matrix-factorization-torch_amd")
@@ -249,7 +308,9 @@ def _guard_case(rank: int, world: int, out_dir: str) -> None:
     with pytest.raises(mf.MfHipError, match="capacity exceeded"):
         tr.finish()
     with pytest.raises(ValueError, match="user_mode"):
-        mfd.ShardedTrainer(mf, "cpu", "sgd", 0, user_mode="replicated", **kw)
+        mfd.ShardedTrainer(mf, "cpu", "sgd", 0, user_mode="mirrored", **kw)
+    with pytest.raises(ValueError, match="replicated"):
+        mfd.ShardedTrainer(mf, "cpu", "sgd", 0, user_mode="replicated", num_hashes=2, **kw)
 
 
 def test_sharded_trainer_raises_instead_of_zero_rows(tmp_path):

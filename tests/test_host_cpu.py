@@ -288,6 +288,16 @@ def test_bench_starts_its_own_ranks_and_reports_them():
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert {"metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "rccl_ranks",
             "transport"} <= set(line)
+    # a failed RCCL self-test: every rank hands over to a FRESH child of itself on torch's collectives (new rendezvous port,
+    # MF_COMM=torch) and exits with its code -- no continuation in the process whose RCCL is in an unknown state; one JSON
+    # line, carrying the note (simulated on the CPU plumbing)
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=dict(env, MF_BENCH_FAKE_COMM_FAILURE="1"), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    assert json.loads(lines[0])["n_gpus"] == 2 and "self-test failed" in json.loads(lines[0])["comm_note"]
+    assert res.stderr.count("restarting this rank in a fresh process") == 2
     # under a launcher whose world differs from --gpus: exit 2, nothing printed
     bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"),
                          capture_output=True, text=True, timeout=120)

@@ -21,7 +21,7 @@ items = torch.nn.functional.normalize(torch.randn(N, d, generator=g), dim=-1).to
 index = mf.retrieval.ItemIndex(items)
 import ctypes
 lib = mf._lib.lib()
-cnt = (ctypes.c_ulonglong * 2)()
+cnt = (ctypes.c_ulonglong * 3)()
 lib.mf_probe_bf3_candidates.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for Q in qs:
     q = torch.nn.functional.normalize(torch.randn(Q, d, generator=g), dim=-1).to(dev)
@@ -46,5 +46,5 @@ for Q in qs:
             lib.mf_probe_bf3_candidates(None, 1)
             index.search(q, 20, path=path, exclude_csr=csr)
             lib.mf_probe_bf3_candidates(cnt, 0)
-            extra = f"  candidates / query {cnt[0] / max(cnt[1], 1):7.1f}"
+            extra = f"  candidates / query {cnt[0] / max(cnt[1], 1):7.1f} (rescored {cnt[2] / max(cnt[1], 1):6.1f})"
         print(f"path {path:6s} excl {'yes' if csr else 'no ':3s} Q {Q:5d} N {N} d {d}: {us:8.1f} us / call  {Q / us:8.2f} M queries/s{extra}", flush=True)
