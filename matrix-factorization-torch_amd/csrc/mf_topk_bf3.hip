@@ -217,17 +217,14 @@ struct Bf3Lds {
     static constexpr int PPW = (PIECES + BF3_WAVES - 1) / BF3_WAVES;    // DMA instructions per wave and tile (1, 1, 2)
     static constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row
     static __device__ __forceinline__ int swz(int row) { return CPR >= 16 ? (row & 15) : ((row >> 1) & 7); }
-    static constexpr int NS = D <= 128 ? 10 : 6;              // ring slots (one 32-row tile each); NS - 1 tiles in flight
+    static constexpr int NS = 2 * BF3_BLOCK;                  // ring slots (one 32-row tile each): the block being scored and the block landing behind it
     static constexpr int RING = NS * TILEB;
     static constexpr int EX0 = RING;
     static constexpr int EXW = XT * 512;                      // exclusion words of one block: per query tile 32 queries x 4 tiles
-    static constexpr int EXS = (NS - 2) / BF3_BLOCK + 2;      // blocks in rotation per wave: in use, in flight behind it, being staged
+    static constexpr int EXS = 2;                             // blocks in rotation per wave, like the tiles
     static constexpr int EXB = BF3_WAVES * EXS * EXW;
     static constexpr int DUMP0 = EX0 + EXB;                   // where the (zero) pieces of waves without a share of a short tile land
     static constexpr int BYTES = DUMP0 + 1024;
-    // vector-memory instructions per wave behind the stage of a tile, among the NS - 2 = BLOCK stages that follow it: their
-    // tile pieces, and the XT exclusion DMAs of the one block start among them
-    static_assert((NS - 2) % BF3_BLOCK == 0, "a fixed number of block starts among the stages in flight behind a tile");
 };
 
 // PASS 0: block maxima of the sample; PASS 1: candidate lists of the whole catalog
@@ -237,7 +234,6 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
     using L = Bf3Lds<D, XT>;
     constexpr int KS = D / 16;                               // MFMA steps per tile
     constexpr int NS = L::NS;
-    constexpr int INFLIGHT = (NS - 2) * L::PPW + (EXCL ? XT * ((NS - 2) / BF3_BLOCK) : 0);
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int wave = mf_wave_id();
 #ifdef MF_BF3_LAB
@@ -295,7 +291,7 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
     }
     (void)aoff;
     char* exl = smem + L::EX0 + wave * L::EXS * L::EXW;
-    auto stage = [&](int v) {                                // every wave issues the same instructions for every tile, live or not
+    auto stage = [&](int v) {                                // (a tile past the chunk or the catalog: a dead scalar offset, zeros arrive)
         const int t = real_tile(v < nv ? v : 0);
         const bool live = v < nv && t < p.NT;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -317,8 +313,13 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
         (void)live;
 #endif
     };
+    // Round 4: ONE meeting point per BLOCK of four tiles, not per tile.  The block's four tiles (and its exclusion words) were
+    // staged while the previous block was scored; at the block's start every wave waits for its own DMA pieces, all meet, the
+    // next block is staged into the slots just vacated, and the four tiles are scored WITHOUT a barrier between them: the waves
+    // drift apart instead of arriving at the LDS port and the matrix pipe in lockstep eight times as often (per-tile barriers:
+    // scan loop 19.8 us, seed 8.1; none at all, in the lab: 16.1 / 6.6).
 #pragma unroll
-    for (int j = 0; j < NS - 1; ++j) stage(j);
+    for (int j = 0; j < BF3_BLOCK; ++j) stage(j);
 
     // the queries' bf16 fragments (written once, in operand order, by the prep launch): coalesced 1 KiB loads
     bf16x8 xb[XT][KS];
@@ -356,12 +357,17 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
 
 #ifdef MF_BF3_LAB
     if (st && threadIdx.x == 0) { asm volatile("" : : "v"(xb[0][0]) : "memory"); st[1] = __builtin_amdgcn_s_memrealtime(); }
+    if (st && threadIdx.x == 0 && p.stamps[(size_t)(2 * 4096 * 4 + 4096 * 8)] == 1ull) st[3] = __builtin_amdgcn_s_memtime();       // (... and at loop start, in slots 3 / 0)
 #endif
     for (int v = 0; v < nv; ++v) {
-        // tile v (and, at a block start, the block's exclusion words) is older than what the BLOCK stages behind it issued
-        mf_wait_vmcnt<INFLIGHT>();
-        mf_block_barrier();                                  // ... for every wave; and tile v - 1's slot is free
-        stage(v + NS - 1);
+        if ((v & (BF3_BLOCK - 1)) == 0) {
+            mf_wait_vmcnt<0>();                              // this wave's pieces of block v / 4 have landed ...
+            mf_block_barrier();                              // ... every wave's have; and everybody is done with block v / 4 - 1
+            if (v + BF3_BLOCK < nv) {
+#pragma unroll
+                for (int j = 0; j < BF3_BLOCK; ++j) stage(v + BF3_BLOCK + j);
+            }
+        }
         const int t = real_tile(v);
         const bool mine = (v % nsub) == sub && t < p.NT && !(p.abl & 1);
         if (mine) {
@@ -535,6 +541,7 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
     mf_wait_vmcnt<0>();                                      // nothing of this workgroup may still be on its way into LDS when it ends
 #ifdef MF_BF3_LAB
     if (st && threadIdx.x == 0) st[2] = __builtin_amdgcn_s_memrealtime();
+    if (st && threadIdx.x == 0 && p.stamps[(size_t)(2 * 4096 * 4 + 4096 * 8)] == 1ull) st[0] = __builtin_amdgcn_s_memtime();       // (clock probe: shader cycles at loop end ...)
 #endif
     if (PASS == 1) {
         // this lane's slots of every query tile: 16 bytes each, a wave's 32 queries x 2 halves contiguous (no counters, no atomics)
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(64 * BF3_WAVES, 2) void bf3_scan_kernel(Bf3Scan p) 
         }
     }
 #ifdef MF_BF3_LAB
-    if (st && threadIdx.x == 0) { mf_wait_vmcnt<0>(); st[3] = __builtin_amdgcn_s_memrealtime(); }
+    if (st && threadIdx.x == 0 && p.stamps[(size_t)(2 * 4096 * 4 + 4096 * 8)] != 1ull) { mf_wait_vmcnt<0>(); st[3] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 }
 
@@ -1018,7 +1025,8 @@ static unsigned long long* g_bf3_dbg = nullptr;
 static unsigned long long* g_bf3_stamps = nullptr;       // lab: [2 passes][4096 workgroups][4], then [4096 queries][8] of the final kernel
 // lab: out = host buffer of (2 x 4096 x 4 + 4096 x 8) stamps of the LAST search (100 MHz ticks); enable = 1 allocates and switches them on
 extern "C" int mf_probe_bf3_stamps(unsigned long long* out, int enable) {
-    const size_t bytes = ((size_t)2 * 4096 * 4 + (size_t)4096 * 8) * 8;
+    const size_t bytes = ((size_t)2 * 4096 * 4 + (size_t)4096 * 8 + 8) * 8;       // (+ a mode word: 1 = clock probe)
+    if (g_bf3_stamps && enable >= 1) { const unsigned long long mode = enable == 2 ? 1ull : 0ull; (void)hipMemcpy(g_bf3_stamps + (bytes / 8 - 8), &mode, 8, hipMemcpyHostToDevice); }
     if (!g_bf3_stamps && enable) {
         if (hipMalloc(reinterpret_cast<void**>(&g_bf3_stamps), bytes) != hipSuccess) return -1;
         (void)hipMemset(g_bf3_stamps, 0, bytes);

@@ -97,9 +97,16 @@ __device__ __forceinline__ void apply_row_update(bool active, int64_t row, int c
 // memory by the same workgroup (slow, O(m^2 / 1024), but correct).
 static constexpr int FUSED_MAX_N = 65536;
 static constexpr int FUSED_CAP = 8192;          // keys per bucket in LDS (64 KiB)
-static constexpr int FUSED_RANK_MAX = 512;      // all-pairs rank sort up to here (the sorted copy goes to the list's upper half)
+#ifndef MF_FUSED_RANK_MAX
+#define MF_FUSED_RANK_MAX 512
+#endif
+#ifndef MF_FUSED_MAX_BITS
+#define MF_FUSED_MAX_BITS 8     // 256 buckets = one workgroup per CU.  Every workgroup scans ALL n ids (L2): with 512 buckets that scan was
+#endif                          // 64 MB of L2 reads per 16,384-id update -- 41.0 -> 35.7 us (Zipf ids), 25.2 -> 19.6 (uniform); 128: 38.7 / 25.4
+
+static constexpr int FUSED_RANK_MAX = MF_FUSED_RANK_MAX; // all-pairs rank sort up to here (the sorted copy goes to the list's upper half)
 static constexpr int FUSED_THREADS = 1024;
-static constexpr int FUSED_MAX_BITS = 9;
+static constexpr int FUSED_MAX_BITS = MF_FUSED_MAX_BITS;
 static constexpr int FUSED_SCAN_UNROLL = 8;
 #ifndef FUSED_NF_ADAM
 #define FUSED_NF_ADAM 12
@@ -314,7 +321,7 @@ __device__ __forceinline__ void fused_update_body(const FusedUpdateParams& p, co
     if (m <= FUSED_RANK_MAX) {
         // short list: every key counts the keys below it (LDS broadcast reads) and drops into its place
         unsigned long long* sorted = lk + FUSED_CAP / 2;
-        if (tid < m) {
+        if (tid < m) {                  // (m <= FUSED_THREADS)
             const unsigned long long mine = lk[tid];
             int rank = 0;
             for (int j0 = 0; j0 < m; j0 += 8) {                      // (eight broadcast reads in flight)

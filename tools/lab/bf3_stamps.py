@@ -31,10 +31,10 @@ for _ in range(30):
 lib.mf_probe_bf3_stamps(None, 1)
 for _ in range(5):
     index.search(q, 20, path="bf16", exclude_csr=(off, ids))
-raw = np.zeros(2 * 4096 * 4 + 4096 * 8, dtype=np.uint64)
+raw = np.zeros(2 * 4096 * 4 + 4096 * 8 + 8, dtype=np.uint64)
 lib.mf_probe_bf3_stamps(raw.ctypes.data_as(ctypes.c_void_p), 1)
 buf = raw[: 2 * 4096 * 4].reshape(2, 4096, 4)
-fin = raw[2 * 4096 * 4:].reshape(4096, 8)[:Q].astype(np.int64)
+fin = raw[2 * 4096 * 4: 2 * 4096 * 4 + 4096 * 8].reshape(4096, 8)[:Q].astype(np.int64)
 for ps, name in enumerate(("seed", "scan")):
     st = buf[ps]
     st = st[st[:, 0] > 0].astype(np.int64)
@@ -57,3 +57,16 @@ if len(fin):
           f"; first entry -> last exit {us[:, 5].max():.2f} us; median wave {np.median(us[:, 5] - us[:, 0]):.2f} us")
     scan0 = buf[1][buf[1][:, 0] > 0][:, 0].astype(np.int64)
     print(f"scan start -> final start {(t0 - scan0.min()) / 100.0:.2f} us")
+
+# clock probe: shader cycles (s_memtime) across the tile loop against the 100 MHz counter
+lib.mf_probe_bf3_stamps(None, 2)
+for _ in range(3):
+    index.search(q, 20, path="bf16", exclude_csr=(off, ids))
+lib.mf_probe_bf3_stamps(raw.ctypes.data_as(ctypes.c_void_p), 1)
+buf = raw[: 2 * 4096 * 4].reshape(2, 4096, 4)
+for ps, name in enumerate(("seed", "scan")):
+    st = buf[ps]
+    st = st[st[:, 1] > 0].astype(np.int64)
+    us = (st[:, 2] - st[:, 1]) / 100.0
+    cyc = st[:, 0] - st[:, 3]
+    print(f"{name}: loop {np.median(us):.2f} us = {np.median(cyc):.0f} shader cycles -> {np.median(cyc / us) / 1e3:.2f} GHz")
