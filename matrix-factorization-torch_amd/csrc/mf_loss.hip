@@ -1014,7 +1014,14 @@ struct BwdLds {
     static constexpr int NSLOT = SPREAD ? 2 : (((G::NW == 8 ? 1 : 2) * (3 * SLOT + EXTRA) <= 160 * 1024) ? 3 : 2);
     static constexpr int TR = NSLOT * SLOT;
     static constexpr int BYTES = TR + EXTRA;
-    static constexpr int NDMA = G::PPW + 4;              // memory instructions per wave per stage (4 = the stash block)
+    // d = 64 (config C2): the sweeps are HBM-bound on the 4 KiB stash blocks, not MFMA-bound (a block costs 4 KiB at every width, a tile's
+    // MFMAs shrink with d).  There the dV sweep derives G' from the LOGIT stash itself -- the per-element map dU applies, with
+    // the users' coefficients loaded per tile (lanes are users BEFORE the block is transposed) -- and dU no longer writes a
+    // G' stash: dU moves 0.57 GB instead of 1.07 at C2's shape (round 4; same bits: the same map on the same logits).
+    static constexpr bool RECOMP = D == 64;              // (d = 32 stages two tiles ahead: the coefficients would need a ring of their own)
+    static constexpr int NCOEF = (RECOMP && !XU) ? 4 : 0;   // a, b, coefG, gdiag of the tile's users
+    static constexpr int NDMA = G::PPW + 4 + NCOEF;      // memory instructions per wave per stage (4 = the stash block)
+    static constexpr int NSTORE = (XU && !RECOMP) ? 4 : 0;  // G' stores per tile
 };
 
 // XU = true : lanes hold users, item tiles stream, result d loss / d u   (reads L, writes G' back)
@@ -1032,13 +1039,15 @@ __global__ __launch_bounds__(64 * mf_nw(D), (D == 128 || D == 64) ? BWD_MIN_WG :
     const int64_t Xp = XU ? p.Bp : p.Np;
     const float* Y = XU ? p.v : p.u;
     const int t0 = blockIdx.x * p.tps, t1 = min(p.YT, t0 + p.tps);
+    constexpr bool RECOMP = L::RECOMP;
     float xa = 0.f, xb = 0.f, xc = 0.f, xd = 0.f;
+    const float gout = p.grad_out[0];
     if (XU) {
-        const float g = p.grad_out[0];
-        xa = p.rowc[x]; xb = p.rowc[p.Bp + x]; xc = g * p.rowc[2 * p.Bp + x]; xd = g * p.rowc[3 * p.Bp + x];
+        xa = p.rowc[x]; xb = p.rowc[p.Bp + x]; xc = gout * p.rowc[2 * p.Bp + x]; xd = gout * p.rowc[3 * p.Bp + x];
     }
-    const float xb2 = xb * 1.44269504088896341f;       // exp((L - a) + b) = exp2((L - a) log2e + b log2e): a is the row's largest logit
+    float xb2 = xb * 1.44269504088896341f;             // exp((L - a) + b) = exp2((L - a) log2e + b log2e): a is the row's largest logit
                                                        // (L - a: exact where it matters), b = -log(sum) is small -- rowc_row
+    float cn[4] = {0.f, 0.f, 0.f, 0.f};                // dV, RECOMP: the coefficients of the NEXT tile's user (lane = user c of the tile)
     f32x16 dacc[D / 32];
 #pragma unroll
     for (int mb = 0; mb < D / 32; ++mb)
@@ -1057,8 +1066,10 @@ __global__ __launch_bounds__(64 * mf_nw(D), (D == 128 || D == 64) ? BWD_MIN_WG :
     for (int q = 0; q < 4; ++q) Gn[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto stage_piece = [&](int t, int slot_idx, int j) {
         char* slot = smem + slot_idx * L::SLOT;
-        if (j < 4) {
-            const char* lsrc = reinterpret_cast<const char*>((XU ? p.stash : p.gstash) + block_of(t) * 1024) + lane * 16;
+        if (L::NCOEF && j >= L::NDMA - L::NCOEF) {
+            cn[j - (L::NDMA - L::NCOEF)] = p.rowc[(int64_t)(j - (L::NDMA - L::NCOEF)) * p.Bp + (int64_t)t * 32 + c];
+        } else if (j < 4) {
+            const char* lsrc = reinterpret_cast<const char*>(((XU || RECOMP) ? p.stash : p.gstash) + block_of(t) * 1024) + lane * 16;
             if (SPREAD) Gn[j] = *reinterpret_cast<const f32x4*>(lsrc + j * 1024);
             else __builtin_amdgcn_global_load_lds((mf_glb_ptr)(lsrc + j * 1024), (mf_lds_ptr)(slot + L::LT + wave * 4096 + j * 1024), 16, 0, 0);
         } else {
@@ -1081,8 +1092,8 @@ __global__ __launch_bounds__(64 * mf_nw(D), (D == 128 || D == 64) ? BWD_MIN_WG :
         } else {
             // queue, oldest first: [DMA(ty)] [G stores(ty-2)] [DMA(ty+1)] [G stores(ty-1)]   (stores: dU only)
             if (ty + 1 >= t1) mf_wait_vmcnt<0>();
-            else if (!XU || ty == t0) mf_wait_vmcnt<L::NDMA>();
-            else mf_wait_vmcnt<L::NDMA + 4>();
+            else if (L::NSTORE == 0 || ty == t0) mf_wait_vmcnt<L::NDMA>();
+            else mf_wait_vmcnt<L::NDMA + L::NSTORE>();
         }
         mf_block_barrier();
         if (!SPREAD && L::NSLOT == 3 && ty + 2 < t1) stage(ty + 2, cur >= 1 ? cur - 1 : 2);
@@ -1095,7 +1106,11 @@ __global__ __launch_bounds__(64 * mf_nw(D), (D == 128 || D == 64) ? BWD_MIN_WG :
 #pragma unroll
             for (int t = 0; t < 4; ++t) Gv[4 * q + t] = t4[t];
         }
-        if (XU) {
+        if (!XU && RECOMP) {            // this tile's users' coefficients (asked for one tile ago)
+            xa = cn[0]; xb = cn[1]; xc = gout * cn[2]; xd = gout * cn[3];
+            xb2 = xb * 1.44269504088896341f;
+        }
+        if (XU || RECOMP) {
             // masked logits -> G' (masked entries are -inf: exp / step / sigmoid give exactly 0)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -1107,11 +1122,14 @@ __global__ __launch_bounds__(64 * mf_nw(D), (D == 128 || D == 64) ? BWD_MIN_WG :
                 for (int e = 0; e < 16; ++e)
                     if (mf_acc_row(e, h) == c) Gv[e] = xd;
             }
+        }
+        if (XU && !RECOMP) {
             float* blk = p.gstash + block_of(ty) * 1024 + lane * 4;     // hand G' to the dV sweep
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *reinterpret_cast<f32x4*>(blk + q * 256) = f32x4{Gv[4 * q], Gv[4 * q + 1], Gv[4 * q + 2], Gv[4 * q + 3]};
-        } else {
+        }
+        if (!XU) {
             // block layout is (lane = user, register = item row): transpose to (lane = item, register = user row)
             float* tr = reinterpret_cast<float*>(smem + L::TR) + wave * (32 * 32);
 #pragma unroll
@@ -1547,7 +1565,7 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
             bp.YT = w.NT; bp.tps = w.tps_u;
             MF_TIMED("loss_bwd_du", s, (launch_bwd<D, true>(gmode, dim3((unsigned)w.nsplit_u, (unsigned)(w.BT / w.NW)), bp, s)));
             bp.YT = w.BT; bp.tps = w.tps_v; bp.dpart = w.dpart_v; bp.rpart = w.rpart_v;
-            MF_TIMED("loss_bwd_dv", s, (launch_bwd<D, false>(G_EXP, dim3((unsigned)w.nsplit_v, (unsigned)(w.NT / w.NW)), bp, s)));
+            MF_TIMED("loss_bwd_dv", s, (launch_bwd<D, false>(D == 64 ? gmode : G_EXP, dim3((unsigned)w.nsplit_v, (unsigned)(w.NT / w.NW)), bp, s)));
             const SumJob ja{w.dpart, w.rpart, u, w.nsplit_u, B, w.Bp, du}, jb{w.dpart_v, w.rpart_v, v, w.nsplit_v, N, w.Np, dv};
             const int nb_a = (int)((B * (D / 4) + 255) / 256), nb_b = (int)((N * (D / 4) + 255) / 256);
             sum_parts_kernel<<<dim3((unsigned)(nb_a + nb_b)), 256, 0, s>>>(ja, jb, D, nb_a);
