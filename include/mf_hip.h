@@ -204,6 +204,17 @@ int mf_update_adam(float* table, float* exp_avg, float* exp_avg_sq, int64_t n_ro
                    const int64_t* step_dev, float lr, float beta1, float beta2, float eps,
                    float weight_decay, void* ws, size_t ws_bytes, mf_stream_t stream);
 
+/* Both tables of a training step -- the user rows and the item rows touched by one batch (xfmr_rec/lightning.py:189-192: one
+ * optimizer.step() per step covers every parameter) -- in ONE launch: the two sparse updates are independent, so their
+ * workgroups run side by side.  Same arithmetic, same results as two mf_update_sgd / mf_update_adam calls (adam = 0 / 1), the same
+ * hyper-parameters for both tables, one workspace each (mf_update_ws_bytes).  MF_ENOTSUP for lists longer than 65,536 ids or empty
+ * ones: callers then update the tables one by one. */
+int mf_update_pair(int adam, int d, float* table_a, float* exp_avg_a, float* exp_avg_sq_a, int64_t n_rows_a, const int64_t* idx_a,
+                   int64_t n_a, const float* grad_a, int normalized_a, void* ws_a, size_t ws_a_bytes, float* table_b,
+                   float* exp_avg_b, float* exp_avg_sq_b, int64_t n_rows_b, const int64_t* idx_b, int64_t n_b, const float* grad_b,
+                   int normalized_b, void* ws_b, size_t ws_b_bytes, int64_t step, const int64_t* step_dev, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, mf_stream_t stream);
+
 /* -------------------------------------------------- the default step in one launch ---
  * The reference trains with BATCH_SIZE = 32 pairs (xfmr_rec/params.py:18), PairwiseHingeLoss and 4 mined negatives
  * (xfmr_rec/lightning.py:38-39): a step of ~0.5 MFLOP that the multi-kernel path spends in launch latency.  mf_step_small

@@ -49,6 +49,8 @@ SIGNATURES = {
     "mf_update_sgd": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_f32, c_f32, c_vp, c_sz, c_vp]),
     "mf_update_adam": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_f32, c_f32,
                                c_f32, c_f32, c_f32, c_vp, c_sz, c_vp]),
+    "mf_update_pair": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_vp, c_sz, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,
+                               c_vp, c_int, c_vp, c_sz, c_i64, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "mf_step_small_ws_bytes": (c_sz, [c_int]),
     "mf_step_small": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp,
                               c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_vp, c_i64, c_int, c_i64, c_vp, c_f32, c_f32,

@@ -561,6 +561,56 @@ extern "C" int mf_update_adam(float* table, float* exp_avg, float* exp_avg_sq, i
                                ws_bytes, stream, "mf_update_adam");
 }
 
+template <bool ADAM>
+static int update_pair_common(int d, float* ta, float* ma, float* va, int64_t rows_a, const int64_t* idx_a, int64_t n_a, const float* grad_a,
+                              int norm_a, void* ws_a, size_t ws_a_bytes, float* tb, float* mb, float* vb, int64_t rows_b,
+                              const int64_t* idx_b, int64_t n_b, const float* grad_b, int norm_b, void* ws_b, size_t ws_b_bytes,
+                              AdamHyper hp, mf_stream_t stream) {
+    if (!ta || !tb || !idx_a || !idx_b || !grad_a || !grad_b || !ws_a || !ws_b || rows_a <= 0 || rows_b <= 0 ||
+        (ADAM && (!ma || !va || !mb || !vb)))
+        return mf_set_error(MF_EINVAL, "mf_update_pair: bad argument");
+    if (!mf_width_ok(d)) return mf_set_error(MF_EINVAL, "mf_update_pair: embedding width %d not in {32,64,128,256}", d);
+    if (rows_a >= (1ll << 39) || rows_b >= (1ll << 39)) return mf_set_error(MF_ENOTSUP, "mf_update_pair: table too large");
+    if (n_a <= 0 || n_b <= 0 || n_a > FUSED_MAX_N || n_b > FUSED_MAX_N)
+        return mf_set_error(MF_ENOTSUP, "mf_update_pair: list lengths outside 1..%d (update the tables one by one)", FUSED_MAX_N);
+    if (ws_a_bytes < mf_update_ws_bytes(n_a, d) || ws_b_bytes < mf_update_ws_bytes(n_b, d))
+        return mf_set_error(MF_ENOSPC, "mf_update_pair: workspace too small");
+    UpdateWs wa = update_ws(ws_a, n_a, d), wb = update_ws(ws_b, n_b, d);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int bits_a = fused_bucket_bits(n_a), bits_b = fused_bucket_bits(n_b);
+    FusedUpdateParams fa{ta, ma, va, (long long)rows_a, reinterpret_cast<const long long*>(idx_a), (int)n_a, bits_a, grad_a,
+                         wa.partial, wa.gk0, wa.gk1, norm_a, hp};
+    FusedUpdateParams fb{tb, mb, vb, (long long)rows_b, reinterpret_cast<const long long*>(idx_b), (int)n_b, bits_b, grad_b,
+                         wb.partial, wb.gk0, wb.gk1, norm_b, hp};
+    MF_DISPATCH_D(d, {
+        auto fn = update_fused_pair_kernel<D, ADAM>;
+        static bool attr_set = false;           // (per instantiation)
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_CAP * 8);
+            attr_set = true;
+        }
+        MF_TIMED("update_rows", s, (fn<<<dim3((1u << bits_a) + (1u << bits_b)), FUSED_THREADS, FUSED_CAP * 8, s>>>(fa, fb, 1 << bits_a)));
+    });
+    return mf_check_launch("mf_update_pair");
+}
+
+extern "C" int mf_update_pair(int adam, int d, float* table_a, float* exp_avg_a, float* exp_avg_sq_a, int64_t n_rows_a, const int64_t* idx_a,
+                              int64_t n_a, const float* grad_a, int normalized_a, void* ws_a, size_t ws_a_bytes, float* table_b,
+                              float* exp_avg_b, float* exp_avg_sq_b, int64_t n_rows_b, const int64_t* idx_b, int64_t n_b, const float* grad_b,
+                              int normalized_b, void* ws_b, size_t ws_b_bytes, int64_t step, const int64_t* step_dev, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, mf_stream_t stream) {
+    if (adam) {
+        if (!step_dev && step < 1) return mf_set_error(MF_EINVAL, "mf_update_pair: step must be >= 1");
+        AdamHyper hp{lr, beta1, beta2, eps, weight_decay, (long long)step, reinterpret_cast<const long long*>(step_dev),
+                     log((double)beta1), log((double)beta2)};
+        return update_pair_common<true>(d, table_a, exp_avg_a, exp_avg_sq_a, n_rows_a, idx_a, n_a, grad_a, normalized_a, ws_a, ws_a_bytes, table_b,
+                                        exp_avg_b, exp_avg_sq_b, n_rows_b, idx_b, n_b, grad_b, normalized_b, ws_b, ws_b_bytes, hp, stream);
+    }
+    AdamHyper hp{lr, 0.f, 0.f, 0.f, weight_decay, 1, nullptr, 0.0, 0.0};
+    return update_pair_common<false>(d, table_a, nullptr, nullptr, n_rows_a, idx_a, n_a, grad_a, normalized_a, ws_a, ws_a_bytes, table_b, nullptr,
+                                     nullptr, n_rows_b, idx_b, n_b, grad_b, normalized_b, ws_b, ws_b_bytes, hp, stream);
+}
+
 // ---- lab: the DPP / permlane lane exchanges of mf_common.h against the `__shfl_xor` they replace ----------------------
 // (tests/test_gpu_parity.py: every butterfly sum, the 64-bit wave maximum and every single exchange, bit for bit)
 __global__ __launch_bounds__(64) void lane_ops_probe_kernel(const uint32_t* __restrict__ in, unsigned* __restrict__ bad) {

@@ -567,6 +567,9 @@ __global__ __launch_bounds__(64) void bf3_bound_kernel(const float* __restrict__
     const int64_t r = blockIdx.x;
     const int lane = mf_lane();
     const unsigned ninf = mf_orderable(-__builtin_inff());
+    float ss = 0.f;                                          // (the query's row and the largest norm are asked for with the maxima: one round trip)
+    for (int i = lane; i < d; i += 64) ss = __builtin_fmaf(q[r * d + i], q[r * d + i], ss);
+    const float ym2 = ymax2[0];
     unsigned m1 = 0u, m2 = 0u;                               // 0: "no value" (ranks below -inf)
     for (int i0 = 0; i0 < nvals; i0 += 64 * 8) {
         float f[8];
@@ -588,12 +591,10 @@ __global__ __launch_bounds__(64) void bf3_bound_kernel(const float* __restrict__
         const int cge = __popcll(__ballot(m1 >= cnd)) + __popcll(__ballot(m2 >= cnd));
         if (cge >= k) th = cnd;
     }
-    float ss = 0.f;
-    for (int i = lane; i < d; i += 64) ss = __builtin_fmaf(q[r * d + i], q[r * d + i], ss);
     ss = mf_wave_sum(ss);
     if (lane == 0) {
         const float c = 1.01f * (0x1p-7f + 0x1p-16f + (float)d * 0x1p-22f);
-        const float eps = c * sqrtf(ss) * sqrtf(ymax2[0]);
+        const float eps = c * sqrtf(ss) * sqrtf(ym2);
         // fewer than k rows in sight (or a NaN bound): everything is a candidate
         // the scan tests "score > thr": thr sits strictly below the bound (one part in 2^22, and past zero)
         float t = (th <= ninf) ? -__builtin_inff() : mf_unorderable(th) - 2.f * eps;
@@ -746,6 +747,14 @@ __global__ __launch_bounds__(64 * BF3_FQ) void bf3_final_kernel(Bf3Final p) {
 #define BF3_STAMP(i) do { } while (0)
 #endif
     BF3_STAMP(0);
+    // (the wave's scalars are asked for before the slot records: they travel under the same round trip)
+    const float* xq_g = p.q + (real ? r : 0) * D;
+    const int novf = real ? p.ovf_cnt[r] : 0;
+    const float eps = real ? p.eps[r] : 0.f;
+    const int ovf_g = real ? p.ovf[r] : 0;
+    float xv[(D + 63) / 64];
+#pragma unroll
+    for (int j = 0; j < (D + 63) / 64; ++j) xv[j] = (real && lane + 64 * j < D) ? xq_g[lane + 64 * j] : 0.f;
     if (threadIdx.x < BF3_FQ) lcnt[threadIdx.x] = 0;
     __syncthreads();
     static_assert(BF3_SLOTS == 2 && BF3_FQ == 4, "a block's share of the workgroup = 4 queries x 2 lane halves x 16 bytes = 128 bytes");
@@ -782,10 +791,10 @@ __global__ __launch_bounds__(64 * BF3_FQ) void bf3_final_kernel(Bf3Final p) {
             }
         }
     }
-    if (real) for (int i = lane; i < D; i += 64) xq[i] = p.q[r * D + i];
-    const int novf = real ? p.ovf_cnt[r] : 0;
-    const float eps = real ? p.eps[r] : 0.f;
-    bool overflow = real && (p.ovf[r] != 0 || novf > BF3_OVF);
+#pragma unroll
+    for (int j = 0; j < (D + 63) / 64; ++j)
+        if (lane + 64 * j < D) xq[lane + 64 * j] = xv[j];
+    bool overflow = real && (ovf_g != 0 || novf > BF3_OVF);
     __syncthreads();                                         // the four lists are complete; from here on every wave is on its own
     if (!real) return;
     n = lcnt[wave];

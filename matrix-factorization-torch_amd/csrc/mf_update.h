@@ -474,6 +474,17 @@ __global__ __launch_bounds__(FUSED_THREADS) void update_fused_kernel(FusedUpdate
     fused_update_body<D, ADAM>(p, blockIdx.x, reinterpret_cast<unsigned long long*>(fused_smem));
 }
 
+// BOTH tables of a step in one launch: workgroups [0, nb_a) take table A's buckets, the rest table B's.  The two updates are
+// independent; side by side the long pole of one (a popular item's run of 700 duplicates: one workgroup busy for 35 us) no
+// longer delays the other's launch, and one launch's fixed cost goes (round 4: 13.8 + 35.7 us in sequence -> one launch).
+template <int D, bool ADAM>
+__global__ __launch_bounds__(FUSED_THREADS) void update_fused_pair_kernel(FusedUpdateParams pa, FusedUpdateParams pb, int nb_a) {
+    extern __shared__ __attribute__((aligned(16))) char fused_smem[];
+    // (two calls, not one call on a selected parameter set: the selection moved the set out of scalar registers and spilled)
+    if ((int)blockIdx.x < nb_a) fused_update_body<D, ADAM>(pa, blockIdx.x, reinterpret_cast<unsigned long long*>(fused_smem));
+    else fused_update_body<D, ADAM>(pb, blockIdx.x - nb_a, reinterpret_cast<unsigned long long*>(fused_smem));
+}
+
 // buckets (= workgroups) of a list of n ids: ~32 ids each, at most 2^FUSED_MAX_BITS
 __host__ __device__ static inline int fused_bucket_bits(int64_t n) {
     int bits = 0;

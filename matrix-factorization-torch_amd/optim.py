@@ -67,6 +67,30 @@ def run_table_jobs(jobs) -> None:
         cur.wait_event(done)
 
 
+def _pair_update(adam: bool, jobs, step: int, step_dev, hyper: dict) -> bool:
+    """Both tables of the step in ONE launch (``mf_update_pair``) when there are exactly two pending tables of one width and one
+    parameter group -- the usual step: user rows and item rows.  ``jobs``: (table, state or None, ids, grad, normalized).
+    False: not that shape (or lists beyond the one-launch range): the caller updates the tables one by one."""
+    if len(jobs) != 2 or os.environ.get("MF_UPDATE_PAIR", "1") != "1":
+        return False
+    (pa, sa, ia, ga, na), (pb, sb, ib, gb, nb) = jobs
+    d = pa.shape[1]
+    if pb.shape[1] != d or not (0 < ia.numel() <= 65536 and 0 < ib.numel() <= 65536):
+        return False
+    lib = _lib.lib()
+    wa = _lib.workspace(lib.mf_update_ws_bytes(ia.numel(), d), pa.device)
+    wb = _lib.workspace(lib.mf_update_ws_bytes(ib.numel(), d), pb.device)
+    b1, b2 = hyper.get("betas", (0.0, 0.0))
+    _lib.check(lib.mf_update_pair(
+        int(adam), d,
+        pa.data_ptr(), sa["exp_avg"].data_ptr() if adam else None, sa["exp_avg_sq"].data_ptr() if adam else None, pa.shape[0],
+        ia.data_ptr(), ia.numel(), ga.data_ptr(), int(na), wa.data_ptr(), wa.numel(),
+        pb.data_ptr(), sb["exp_avg"].data_ptr() if adam else None, sb["exp_avg_sq"].data_ptr() if adam else None, pb.shape[0],
+        ib.data_ptr(), ib.numel(), gb.data_ptr(), int(nb), wb.data_ptr(), wb.numel(),
+        step, step_dev, hyper["lr"], b1, b2, hyper.get("eps", 0.0), hyper["weight_decay"], _lib.stream_ptr()))
+    return True
+
+
 class _SparseRowOptimizer(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = True) -> None:
         super().zero_grad(set_to_none=set_to_none)
@@ -96,13 +120,14 @@ class SparseSGD(_SparseRowOptimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.lib()
-        jobs, done = [], []
+        jobs, done, pairs = [], [], []
         for group in self.param_groups:
             for p in group["params"]:
                 self._check(p)
                 pend = _pending(p)
                 if pend is None:
                     continue
+                pairs.append((p, None, pend[0], pend[1], pend[2], group))
 
                 def job(p=p, pend=pend, group=group):
                     ids, g, norm = pend
@@ -114,7 +139,9 @@ class SparseSGD(_SparseRowOptimizer):
 
                 jobs.append(job)
                 done.append(p)
-        run_table_jobs(jobs)
+        one_group = len({id(x[5]) for x in pairs}) == 1
+        if not (one_group and _pair_update(False, [x[:5] for x in pairs], 1, None, pairs[0][5] if pairs else {})):
+            run_table_jobs(jobs)
         for p in done:
             p._mf_pending.clear()
         return loss
@@ -157,7 +184,7 @@ class RowAdam(_SparseRowOptimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.lib()
-        jobs, done = [], []
+        jobs, done, pairs = [], [], []
         for group in self.param_groups:
             for p in group["params"]:
                 self._check(p)
@@ -177,6 +204,7 @@ class RowAdam(_SparseRowOptimizer):
                     step_dev = state["step_t"].data_ptr()
                 if not (self.capturable and torch.cuda.is_current_stream_capturing()):
                     state["step"] += 1                     # (a capture runs no kernel: the replays count, via on_replay)
+                pairs.append((p, state, pend[0], pend[1], pend[2], group, step_dev))
 
                 def job(p=p, pend=pend, group=group, state=state, step_dev=step_dev):
                     ids, g, norm = pend
@@ -190,7 +218,11 @@ class RowAdam(_SparseRowOptimizer):
 
                 jobs.append(job)
                 done.append(p)
-        run_table_jobs(jobs)
+        # the usual step -- user rows and item rows, one parameter group, the same global step -- is ONE launch
+        same = (len(pairs) == 2 and pairs[0][5] is pairs[1][5] and pairs[0][1]["step"] == pairs[1][1]["step"]
+                and (pairs[0][6] is None) == (pairs[1][6] is None))
+        if not (same and _pair_update(True, [x[:5] for x in pairs], pairs[0][1]["step"], pairs[0][6], pairs[0][5])):
+            run_table_jobs(jobs)
         for p in done:
             p._mf_pending.clear()
         return loss

@@ -1019,3 +1019,40 @@ def test_group_keys_is_a_stable_counting_sort(mf, n, nk):
     assert torch.equal(sk, keys[want])
     assert torch.equal(bounds, torch.cat([torch.zeros(1, dtype=torch.int64), torch.bincount(keys, minlength=nk).cumsum(0)]))
     assert mf.distributed.HipOps(mf).group_by_key(torch.zeros(40000, dtype=torch.int64, device=DEV), 8) is None      # beyond the limits
+
+
+@pytest.mark.parametrize("adam", [True, False])
+def test_update_pair_equals_two_updates(mf, adam):
+    """``mf_update_pair`` -- both tables of a step in ONE launch -- against the two ``mf_update_adam`` / ``mf_update_sgd`` calls it
+    replaces: torch.equal on tables and moments (Zipf ids with a run of hundreds of duplicates, out-of-range ids, two steps)."""
+    lib = mf._lib.lib()
+    g = torch.Generator().manual_seed(3)
+    d, rows_a, rows_b, n_a, n_b = 128, 5000, 700, 4096, 8192
+    w = 1.0 / torch.arange(1, rows_b + 1, dtype=torch.float64)
+    ia = torch.randint(-2, rows_a + 2, (n_a,), generator=g).to(DEV)
+    ib = torch.multinomial(w, n_b, replacement=True, generator=g).to(DEV)
+    ga, gb = torch.randn(n_a, d, generator=g).to(DEV), torch.randn(n_b, d, generator=g).to(DEV)
+
+    def tables():
+        t = torch.Generator().manual_seed(9)
+        ta, tb = torch.randn(rows_a, d, generator=t).to(DEV), torch.randn(rows_b, d, generator=t).to(DEV)
+        return ta, tb, [torch.zeros_like(ta), torch.zeros_like(ta)], [torch.zeros_like(tb), torch.zeros_like(tb)]
+
+    (ta1, tb1, sa1, sb1), (ta2, tb2, sa2, sb2) = tables(), tables()
+    wa = mf._lib.workspace(lib.mf_update_ws_bytes(n_a, d), DEV)
+    wb = mf._lib.workspace(lib.mf_update_ws_bytes(n_b, d), DEV)
+    for step in (1, 2):
+        for t, s, i, gr, ws in ((ta1, sa1, ia, ga, wa), (tb1, sb1, ib, gb, wb)):
+            if adam:
+                mf._lib.check(lib.mf_update_adam(t.data_ptr(), s[0].data_ptr(), s[1].data_ptr(), t.shape[0], d, i.data_ptr(), i.numel(), gr.data_ptr(), 1,
+                                                 step, None, 0.05, 0.9, 0.999, 1e-8, 0.01, ws.data_ptr(), ws.numel(), None))
+            else:
+                mf._lib.check(lib.mf_update_sgd(t.data_ptr(), t.shape[0], d, i.data_ptr(), i.numel(), gr.data_ptr(), 1, 0.05, 0.01, ws.data_ptr(),
+                                                ws.numel(), None))
+        mf._lib.check(lib.mf_update_pair(int(adam), d, ta2.data_ptr(), sa2[0].data_ptr() if adam else None, sa2[1].data_ptr() if adam else None, rows_a,
+                                         ia.data_ptr(), n_a, ga.data_ptr(), 1, wa.data_ptr(), wa.numel(), tb2.data_ptr(),
+                                         sb2[0].data_ptr() if adam else None, sb2[1].data_ptr() if adam else None, rows_b, ib.data_ptr(), n_b,
+                                         gb.data_ptr(), 1, wb.data_ptr(), wb.numel(), step, None, 0.05, 0.9, 0.999, 1e-8, 0.01, None))
+        assert torch.equal(ta1, ta2) and torch.equal(tb1, tb2), step
+        if adam:
+            assert all(torch.equal(x, y) for x, y in zip(sa1 + sb1, sa2 + sb2)), step

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round profiles on the GPU box (run through gpurun from the repository root):
-#   bash tools/collect_profiles.sh r03
+#   bash tools/collect_profiles.sh r04
 # kernel trace + stats of the default bench.py run, then three PMC passes (SQ counters, FETCH_SIZE, WRITE_SIZE; counters in
 # their own runs, no trace domains beside them), summarised into gpurun_out/profiles_<round>/ -- copy into profiles/.
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
@@ -25,6 +25,10 @@ python3 tools/pmc_sq.py $(ls gpurun_out/pmcS_$R/*.db gpurun_out/pmcS_$R/*/*.db 2
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmcF_$R -o r -- python3 bench.py --steps 3 --warmup 1 --no-extras > $OUT/pmcF_stdout.log 2>&1 || exit 1
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmcW_$R -o r -- python3 bench.py --steps 3 --warmup 1 --no-extras > $OUT/pmcW_stdout.log 2>&1 || exit 1
 python3 tools/pmc_traffic.py $(ls gpurun_out/pmcF_$R/*.db gpurun_out/pmcF_$R/*/*.db 2>/dev/null | head -1) $(ls gpurun_out/pmcW_$R/*.db gpurun_out/pmcW_$R/*/*.db 2>/dev/null | head -1) > $OUT/${R}_traffic.json || exit 1
+# kernel timeline of one steady training step (rocpd database of a short headline run)
+timeout -k 10 600 rocprofv3 --kernel-trace -d gpurun_out/tl_$R -o tl -- python3 bench.py --no-extras --no-cpu-baseline > $OUT/tl_stdout.log 2>&1 || exit 1
+python3 tools/step_timeline.py $(ls gpurun_out/tl_$R/*.db gpurun_out/tl_$R/*/*.db 2>/dev/null | head -1) > $OUT/${R}_step_timeline.txt || exit 1
+rm -rf gpurun_out/tl_$R
 # the raw rocprof databases are far beyond what travels back
 rm -rf gpurun_out/prof_$R gpurun_out/pmcS_$R gpurun_out/pmcF_$R gpurun_out/pmcW_$R
 ls -la $OUT

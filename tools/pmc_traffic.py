@@ -19,11 +19,11 @@ sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 
 GROUPS = {
     "loss_fwd_dense": ["loss_fwd_dense_kernel"],
-    "loss_bwd_du": ["loss_bwd_dense_kernel<128, true"],
+    "loss_bwd_du": ["loss_bwd_dense_kernel<128, true"],       # (the headline width: --no-extras runs launch no other)
     "loss_bwd_dv": ["loss_bwd_dense_kernel<128, false"],
     "topk_select": ["select_kernel<", "select_seed_kernel<", "select_bound_kernel<"],
     "gather_rows": ["gather_rows_kernel"],
-    "topk_bf3": ["bf3_scan_kernel<", "bf3_bound_kernel", "bf3_final_kernel<", "bf3_excl_rows_kernel"],
+    "topk_bf3": ["bf3_scan_kernel<", "bf3_bound_kernel", "bf3_final_kernel<", "bf3_prep_kernel"],
     "update_rows": ["update_fused_kernel", "update_rows_kernel"],
     "mask_sweep": ["mask_sweep_kernel"],
     "sum_parts": ["sum_parts_kernel"],
