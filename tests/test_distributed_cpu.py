@@ -387,6 +387,12 @@ def _topk_case(rank: int, world: int, out_dir: str) -> None:
     ids = torch.tensor([i for e in excl for i in e] or [0], dtype=torch.int64)
     index = mfd.ShardedIndex(items[rank::world].contiguous(), rank, N_ITEMS, stride=world, ops=OracleOps())
     s, i = index.search(q, K, exclude_csr=(off, ids))
+    # the same search with capacity-padded exclusion blocks (no host read of the other ranks' list lengths): same bits
+    index2 = mfd.ShardedIndex(items[rank::world].contiguous(), rank, N_ITEMS, stride=world, ops=OracleOps())
+    s2, i2 = index2.search(q, K, exclude_csr=(off, ids.clone()), exclude_capacity=40)
+    assert torch.equal(i, i2) and torch.equal(s, s2)
+    with pytest.raises(ValueError, match="exclude_capacity"):
+        index2.search(q, K, exclude_csr=(off, ids.clone()), exclude_capacity=8)
     torch.save({"q": q, "excl": excl, "s": s, "i": i}, f"{out_dir}/topk_{rank}.pt")
 
 

@@ -214,6 +214,35 @@ def test_oracle_retrieval_metrics_hand_example():
     assert not oretr.retrieval_metrics(np.array([[1, 2, 3, 4]]), [{}], 4).any()          # no target: all 0
 
 
+def test_metric_convention_for_unretrieved_targets_and_where_it_differs_from_the_reference():
+    """The reference scores a target the search did NOT retrieve with -U(0, 1) (xfmr_rec/lightning.py:170-175) and lets
+    torchmetrics rank everything by score; here (oracle.retrieval.retrieval_metrics, mf_retrieval_metrics) an unretrieved target
+    ranks below every retrieved item.  The two agree for ANY draw whenever every retrieved score is >= 0 (cosine scores of the
+    top k of a trained model); they can differ when a retrieved score is negative -- a tiny catalog, or untrained towers --
+    because the reference may then lift a missed target above a retrieved item.  Pinned here so that nobody reads the numbers
+    of such a run as the reference's ("deviations")."""
+    from oracle import retrieval as oretr
+
+    def reference_convention(scores, idx, tgt, k, draws):
+        """HitRate@k and Recall@k under the reference's scoring: retrieved items keep their scores, missed targets get -draw."""
+        pred = {int(i): float(s) for i, s in zip(idx, scores)}
+        missed = [i for i in tgt if i not in pred]
+        for i, u in zip(missed, draws):
+            pred[i] = -float(u)
+        order = sorted(pred, key=lambda i: -pred[i])[:k]
+        hits = sum(1 for i in order if tgt.get(i, 0) > 0)
+        return float(hits > 0), hits / sum(1 for v in tgt.values() if v > 0)
+
+    k, idx, tgt = 4, np.array([7, 3, 9, 5]), {3: 5.0, 8: 4.0}          # 8 was missed
+    ours = oretr.retrieval_metrics(idx[None, :], [tgt], k)[0]
+    for draws in ([0.01], [0.5], [0.99]):                                # every retrieved score >= 0: the same for any draw
+        hr, rec = reference_convention([0.9, 0.5, 0.2, 0.0], idx, tgt, k, draws)
+        assert hr == ours[4] and rec == ours[1]
+    # negative retrieved scores: a draw of 0.05 puts the missed target 8 above the retrieved item 5 (score -0.3)
+    hr, rec = reference_convention([0.9, 0.5, -0.1, -0.3], idx, tgt, k, [0.05])
+    assert rec == 1.0 and ours[1] == 0.5                                 # the documented deviation: ours never promotes a missed target
+
+
 def test_oracle_epoch_permutation_is_a_bijection():
     from oracle import data as odata
 
