@@ -772,10 +772,17 @@ __global__ __launch_bounds__(64 * BF3_FQ) void bf3_final_kernel(Bf3Final p) {
                 v[j] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
                 if (idx < nrec) v[j] = *reinterpret_cast<const uint4*>(p.cand + (((int64_t)(idx >> 3) * p.Qp + q0) * 2) * (2 * BF3_SLOTS) + (idx & 7) * 4);
             }
+            // (a thread's records all belong to ONE of the four queries -- record index mod 8 is thread index mod 8 --: it counts its
+            // occupied slots, reserves them with ONE LDS atomic and writes them; sixteen conditional atomics in a row, each waited
+            // for, were a microsecond of dependent LDS round trips)
+            const int qq = ((int)threadIdx.x >> 1) & 3;
+            int mine_n = 0;
+#pragma unroll
+            for (int j = 0; j < PF; ++j) mine_n += (v[j].x != 0xFFFFFFFFu ? 1 : 0) + (v[j].y != 0xFFFFFFFFu ? 1 : 0);
+            int at = mine_n ? atomicAdd(&lcnt[qq], mine_n) : 0;
+            unsigned long long* kq = keys_of(qq);
 #pragma unroll
             for (int j = 0; j < PF; ++j) {
-                const int idx = i0 + j * 64 * BF3_FQ + (int)threadIdx.x;
-                const int qq = (idx >> 1) & 3;
                 const uint32_t rw[2] = {v[j].x, v[j].y}, vl[2] = {v[j].z, v[j].w};
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -784,8 +791,8 @@ __global__ __launch_bounds__(64 * BF3_FQ) void bf3_final_kernel(Bf3Final p) {
                         // in sight of the seed -- counts as unknown)
                         const float a = __builtin_bit_cast(float, vl[t]);
                         const unsigned oa = (a - a == 0.f) ? mf_orderable(a) : ORD_INF;
-                        const int at = atomicAdd(&lcnt[qq], 1);
-                        if (at < BF3_CAND) keys_of(qq)[at] = ((unsigned long long)oa << 32) | (unsigned long long)rw[t];
+                        if (at < BF3_CAND) kq[at] = ((unsigned long long)oa << 32) | (unsigned long long)rw[t];
+                        ++at;
                     }
                 }
             }
