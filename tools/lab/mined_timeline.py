@@ -1,0 +1,32 @@
+"""Kernel timeline of one steady step of the reference's DEFAULT loss (PairwiseHinge, 4 mined negatives) at the C3 shape.
+    rocprofv3 --kernel-trace -d out -o m -- python3 tools/lab/mined_timeline.py ; python tools/lab/mined_timeline.py out/...db"""
+import sys
+
+if len(sys.argv) > 1:
+    import sqlite3
+    db = sqlite3.connect(sys.argv[1])
+    rows = db.execute("select name,start,end from kernels order by start").fetchall()
+    idx = [i for i, r in enumerate(rows) if "select_kernel<" in r[0]]
+    a, b = idx[60], idx[61]
+    prev = None
+    for r in rows[a:b]:
+        gap = (r[1] - prev) / 1e3 if prev else 0.0
+        print(f"{r[0][:70]:70s} dur {(r[2] - r[1]) / 1e3:7.1f} gap {gap:6.1f}")
+        prev = r[2]
+    print(f"step {(rows[b][1] - rows[a][1]) / 1e3:.1f} us")
+    sys.exit(0)
+import importlib
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+
+mf = importlib.import_module("matrix-factorization-torch_amd")
+dev = torch.device("cuda:0")
+batches, _ = bench.make_batches(8, 8192, seed=1000, device=dev)
+tr = bench.Trainer(mf, dev, "adam", 4, loss="PairwiseHingeLoss")
+for i in range(120):
+    tr.step(batches[i % 8])
+torch.cuda.synchronize()
