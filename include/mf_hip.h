@@ -171,6 +171,13 @@ int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sig
                 int kind, const float* u, const float* v, int flags, void* ws, size_t ws_bytes,
                 const float* grad_out, float* du, float* dv, mf_stream_t stream);
 
+/* The candidate search of the mined losses (0 < num_negatives < N) has two implementations with IDENTICAL results: the fp32
+ * streaming selection, and -- for d in {64, 128}, B >= 256, N >= 2048, num_negatives <= 32 -- a split-bf16 prefilter on the
+ * bf16 matrix cores with exact fp32 rescoring of the few columns that pass (csrc/mf_mine_bf.h).  The prefilter is the default
+ * where it applies; mf_set_mining_prefilter(0) (or MF_MINE_BF=0 in the environment) selects the fp32 search everywhere --
+ * what the parity tests use to compare the two.  Process-wide; not a per-stream setting. */
+void mf_set_mining_prefilter(int on);
+
 /* API parity with the public helper methods of EmbeddingLoss, on caller-provided tensors (not the
  * hot path): negative_masks (losses.py:92-110) -> out_mask[B,N] bytes, 1 = valid negative;
  * hard_mining (losses.py:112-132, semi_hard = 0: keep the k highest logits among the valid

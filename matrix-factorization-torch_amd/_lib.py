@@ -44,6 +44,7 @@ SIGNATURES = {
                             c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
     "mf_negative_masks_ws_bytes": (c_sz, [c_i64, c_i64, c_int]),
     "mf_negative_masks": (c_int, [c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "mf_set_mining_prefilter": (None, [c_int]),
     "mf_mine_logits": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp]),
     "mf_update_ws_bytes": (c_sz, [c_i64, c_int]),
     "mf_update_sgd": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_f32, c_f32, c_vp, c_sz, c_vp]),

@@ -19,6 +19,7 @@
 
 #include "mf_common.h"
 #include "mf_loss_math.h"
+#include "mf_mine_bf.h"
 #include "mf_select.h"
 #include "mf_stream.h"
 
@@ -57,6 +58,15 @@ struct LossWs {
     int32_t *cand_cnt, *sel, *sel_cnt;
     unsigned* gtau;
     float* sel_L;
+    MineBfPlan mbf;              // the split-bf16 candidate search (mf_mine_bf.h); its arrays exist whenever the shape is eligible
+    unsigned short* mbf_plane;
+    void* mbf_ufrag;
+    void* mbf_rowk;
+    int32_t* mbf_flag;
+    unsigned* mbf_max;
+    int32_t *mbf_ncopy, *mbf_lastcopy, *mbf_rep;
+    unsigned long long* mbf_plist;
+    uint32_t* mbf_pcnt;
     long long* dvfix;            // mined backward: exact fixed-point accumulator of dv [N][d]
     float* dvsc;                 // its unit for this batch: {2^E, clamp, 2^-E} (dv_fix_of, mf_loss_math.h)
     size_t total;
@@ -127,6 +137,19 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
         w.dvfix = a.take<long long>((size_t)w.N * d);
         w.gtau = a.take<unsigned>((size_t)w.Bp);
         w.cand_cnt = a.take<int32_t>((size_t)w.Bp);      // right behind gtau: one memset clears both
+        w.mbf_max = a.take<unsigned>(4);                 // ... and these maxima
+        w.mbf = mine_bf_plan(B, N, d, k);
+        if (w.mbf.ok) {
+            w.mbf_ncopy = a.take<int32_t>((size_t)w.mbf.Nq);        // (cleared with the maxima)
+            w.mbf_lastcopy = a.take<int32_t>((size_t)w.mbf.Nq);
+            w.mbf_rep = a.take<int32_t>((size_t)w.mbf.Nq);
+            w.mbf_plane = a.take<unsigned short>((size_t)w.mbf.Nq * (2 * d + 16) + 64);
+            w.mbf_ufrag = a.take<char>((size_t)w.mbf.Xq * d * 4);
+            w.mbf_rowk = a.take<char>((size_t)w.mbf.Xq * 16);
+            w.mbf_flag = a.take<int32_t>((size_t)w.mbf.Xq);
+            w.mbf_plist = a.take<unsigned long long>((size_t)w.mbf.nchunk * w.mbf.Xq * 2 * MBF_CAPL);
+            w.mbf_pcnt = a.take<uint32_t>((size_t)w.mbf.nchunk * w.mbf.Xq * 2);
+        }
         w.dpart = nullptr;
     } else {
         // the two backward sweeps keep their split partials apart: ONE launch adds up both after the second sweep
@@ -1405,6 +1428,63 @@ static int loss_masks_impl(const char* what, int64_t B, int64_t N, int d, int nu
     return mf_check_launch(what);
 }
 
+// The candidate search of the mined losses through the split-bf16 prefilter: the fp32 seeding pass and its bound as before,
+// then item plane / user fragments + intervals / ONE scan on the bf16 cores / exact rescoring into the row lists.
+static unsigned long long* g_mine_dbg = nullptr;
+template <int D>
+static void mine_bf_launch(const LossWs& w, const float* u, const float* v, int64_t B, int64_t N, int k, float sigma, hipStream_t s) {
+    const MineBfPlan& m = w.mbf;
+    {
+        const int64_t threads = m.Nq * (D / 8);
+        mine_items_kernel<D><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(v, w.nv, w.logq, w.colfirst, N, m.Nq, sigma, w.mbf_plane, w.mbf_max,
+                                                                               w.mbf_rep, w.mbf_ncopy, w.mbf_lastcopy);
+    }
+    {
+        MineUsers mu{u, w.nu, w.lii, w.sgn, w.gtau, w.mbf_max, B, m.Xq, sigma, static_cast<mbf16x8*>(w.mbf_ufrag),
+                     static_cast<f32x4*>(w.mbf_rowk), w.mbf_flag, g_mine_dbg};
+        const int64_t threads = m.Xq * (D / 8);
+        mine_users_kernel<D, MiningPolicy><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(mu);
+    }
+    {
+        MineScan ms{w.mbf_plane, m.Nq, m.NT, m.tpc, static_cast<const mbf16x8*>(w.mbf_ufrag), static_cast<const f32x4*>(w.mbf_rowk), m.Xq,
+                    w.mbf_plist, w.mbf_pcnt, w.mbf_flag, g_mine_dbg};
+        auto fn = mine_scan_kernel<D>;
+        const int bytes = MineLds<D>::BYTES;
+        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        fn<<<dim3((unsigned)m.nchunk, (unsigned)m.gy), 64 * MBF_WAVES, bytes, s>>>(ms);
+    }
+    {
+        MineRescore mr{u, v, w.nu, w.nv, w.lii, w.sgn, w.logq, w.maskW, B, w.Bp, N, m.Xq, sigma, m.nlists, k,
+                       w.mbf_plist, w.mbf_pcnt, w.mbf_flag, w.mbf_rep, w.mbf_ncopy, w.mbf_lastcopy, w.cand, w.cand_cnt, w.plan.rowcap, g_mine_dbg};
+        auto fn = mine_rescore_kernel<D>;
+        const int bytes = MBF_RW * MineRescoreGeom<D>::PER_WAVE;
+        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        fn<<<dim3((unsigned)((B + MBF_RW - 1) / MBF_RW)), 64 * MBF_RW, bytes, s>>>(mr);
+    }
+}
+static int mine_bf_run(const LossWs& w, const MiningPolicy::Params& mp, const SelectCommon& sc, const float* u, const float* v, int64_t B,
+                       int64_t N, int d, int k, float sigma, hipStream_t s) {
+    MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s, true))); });
+    if (d == 64) { MF_TIMED("mining_scan", s, (mine_bf_launch<64>(w, u, v, B, N, k, sigma, s))); }
+    else { MF_TIMED("mining_scan", s, (mine_bf_launch<128>(w, u, v, B, N, k, sigma, s))); }
+    return MF_OK;
+}
+// tools/lab/mined_timeline.py: [0] candidates rescored, [1] users, [2] users walked exactly, since the last call
+extern "C" int mf_probe_mining_prefilter(unsigned long long* out3, int enable) {
+    static unsigned long long* buf = nullptr;
+    if (!buf) {
+        if (hipMalloc(reinterpret_cast<void**>(&buf), 64) != hipSuccess) return -1;
+        (void)hipMemset(buf, 0, 64);
+    }
+    (void)hipDeviceSynchronize();
+    if (out3) (void)hipMemcpy(out3, buf, 64, hipMemcpyDeviceToHost);      // (eight counters)
+    (void)hipMemset(buf, 0, 64);
+    g_mine_dbg = enable ? buf : nullptr;
+    return 0;
+}
+// tests / tools: 1 = prefilter on (default), 0 = select_kernel only
+extern "C" void mf_set_mining_prefilter(int on) { g_mine_bf_mode = on ? 1 : 0; }
+
 static int pos_src_check(const char* what, const PosSrc& src) {
     if (src.pos_off) {
         if (!src.user_ids || !src.pos_items || src.num_users <= 0) return mf_set_error(MF_EINVAL, "%s: CSR positives need user_ids, pos_off, pos_items, num_users > 0", what);
@@ -1490,8 +1570,12 @@ static int loss_fwd_impl(const char* what, int64_t B, int64_t N, int d, const Po
     } else if (scores_needed) {
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
         SelectCommon sc{u, B, v, N, 0, (int)((N + 31) / 32), w.plan.tpc, w.Bp, num_negatives, w.plan.xw, w.gtau, w.priv, w.cand, w.cand_cnt, w.plan.rowcap};
-        mf_zero_async(w.gtau, (size_t)((char*)(w.cand_cnt + w.Bp) - (char*)w.gtau), s);
-        MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s))); });
+        mf_zero_async(w.gtau, (size_t)((char*)(w.mbf.ok ? (void*)(w.mbf_lastcopy + w.mbf.Nq) : (void*)(w.mbf_max + 4)) - (char*)w.gtau), s);
+        if (w.mbf.ok && mine_bf_enabled() && w.plan.YTa > 0 && w.plan.rowcap >= num_negatives) {
+            if (int rc2 = mine_bf_run(w, mp, sc, u, v, B, N, d, num_negatives, sigma, s)) return rc2;
+        } else {
+            MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s))); });
+        }
         MinedRowParams mr{w.cand, w.cand_cnt, w.plan.rowcap, num_negatives, u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, B, w.Bp, d,
                           sigma, margin, need, w.sel, w.sel_cnt, w.sel_L, w.stats};
         mined_rows_kernel<<<dim3((unsigned)w.Bp), 64, 0, s>>>(mr);

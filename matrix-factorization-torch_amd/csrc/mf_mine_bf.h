@@ -1,0 +1,668 @@
+// mf_mine_bf.h -- the mined losses' candidate search through a SPLIT-bf16 prefilter (gfx950).
+//
+// Semi-hard mining (xfmr_rec/losses.py:134-162) needs, per user, the k best columns of the B x N matrix of
+// Dm = L_ij - L_ii by the mining order (mf_numerics.h), bit-exact.  select_kernel (mf_select.h) streams that matrix on the
+// fp32 matrix cores -- 1/16 of the bf16 rate -- although all but a few dozen columns per user are nowhere near the cut.
+// Here the matrix is streamed ONCE on the bf16 cores with every fp32 operand split in two bf16 numbers,
+//
+//     x = xh + xl + r,  xh = bf16(x),  xl = bf16(x - xh),  |r| <= 2^-18 |x|
+//     x y ~ xh yh + xl yh + xh yl            (three products, each exact in fp32; what is dropped: <= 3.03 2^-18 |x||y|)
+//
+// and the O(1) terms of Dm ride in one extra k-step of the hi x hi product (16 more k slots):
+//
+//     Dm_ij = as_i (u_i . v_j)  -  s_i w_j  +  lqn_j  +  rho_i          as = sigma s_i, w_j = sigma |v_j|^2 / 2 (= -hs nv_j),
+//     item side  [ v_j | w1 w2 w3 | q1 q2 q3 | 1 1 1 | 0.. ]            lqn_j = -logq_j, rho_i = hs |u_i|^2 - L_ii - mid_i
+//     user side  [ as u_i | -s -s -s | 1 1 1 | r1 r2 r3 | 0.. ]         (w, lqn, rho: three bf16 pieces each -- 24 bits)
+//
+// so the accumulator of an element IS Dm_ij - mid_i, and "may this column be among the k best" is ONE compare per element:
+// |acc| <= half_i, where [mid - half, mid + half] is the interval of Dm the user's bound admits (MiningPolicy::make_thr of the
+// seeding pass's bound) widened by a RIGOROUS bound eps_i of |acc + mid - Dm as select_kernel would compute it| (below).
+// The few columns that pass (tens per user) are rescored with the canonical fp32 chain and keyed exactly as
+// MiningPolicy::key does; the row lists that come out feed mined_rows_kernel unchanged.  A user whose lists overflow (all
+// scores equal, a zero target, non-finite inputs) is answered by its rescoring wave walking the whole row exactly.
+//
+// Error bound (mine_users_kernel).  With P = |as| |u_i| max|v|, W = sigma max|v|^2 / 2, Q = max |lqn|, and
+// S = 1.01 P + W + Q + |rho| >= the sum of the absolute values of everything one accumulator adds up (nt = 3 d + 16 terms):
+//   * the matrix core's fp32 accumulation, any order, any grouping: <= nt 2^-23 S (twice the round-to-nearest bound);
+//   * the dropped products and the rounding of as u:                 <= 3.1 2^-18 P;
+//   * w's rounding, the three-piece splits, rho's rounding:          <= 2^-23 (W + Q + |rho|);
+//   * the exact side's own rounding (chain, two fma, one subtraction), M = P + (|hs| |u|^2 + W) + Q + |L_ii|:
+//                                                                    <= d 2^-23 P + 2^-21 M;
+// eps = 1.01 x their sum (the norms are themselves fp32 chains).
+#pragma once
+
+#include <cstdlib>
+
+#include "mf_common.h"
+#include "mf_select.h"
+#include "mf_stream.h"
+
+typedef __bf16 mbf16x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int MBF_WAVES = 8;                     // waves per scan workgroup, two per SIMD
+static constexpr int MBF_XT = 2;                        // user tiles (32 users) a wave keeps in registers
+static constexpr int MBF_BLOCK = 2;                     // item tiles between two meeting points of the workgroup
+static constexpr int MBF_CAPL = 16;                     // entries of a lane's list (one chunk, one lane half of a user)
+static constexpr int MBF_ROWS_WG = 32 * MBF_XT * MBF_WAVES;      // 512 users per workgroup
+static constexpr int MBF_MAXLISTS = 32;                 // lists per user the rescoring wave gathers (one per lane; 32 x 16 keys of LDS)
+
+struct MineBfPlan {
+    bool ok;                // the shape is served by this path
+    int NT;                 // 32-row item tiles
+    int64_t Xq, Nq;         // users padded to a workgroup's 512, items to a tile's 32
+    int gy;                 // user blocks
+    int nchunk, tpc;        // item chunks (grid.x) and tiles per chunk
+    int nlists;             // 2 nchunk lists per user
+    int rowb;               // bytes of an item's row in the plane: (2 d + 16) bf16
+};
+static inline MineBfPlan mine_bf_plan(int64_t B, int64_t N, int d, int k) {
+    MineBfPlan p{};
+    p.NT = (int)((N + 31) / 32);
+    p.Nq = (int64_t)p.NT * 32;
+    p.Xq = (B + MBF_ROWS_WG - 1) / MBF_ROWS_WG * MBF_ROWS_WG;
+    p.gy = (int)(p.Xq / MBF_ROWS_WG);
+    p.rowb = (2 * d + 16) * 2;
+    int want = (256 + p.gy - 1) / p.gy;                  // one workgroup per CU
+    if (want > MBF_MAXLISTS / 2) want = MBF_MAXLISTS / 2;
+    if (want < 1) want = 1;
+    p.tpc = (p.NT + want - 1) / want;
+    p.tpc = (p.tpc + MBF_BLOCK - 1) / MBF_BLOCK * MBF_BLOCK;
+    p.nchunk = (p.NT + p.tpc - 1) / p.tpc;
+    p.nlists = 2 * p.nchunk;
+    // (the seeding pass of mf_select_plan exists from 64 tiles on; below that, and for short batches, select_kernel is fast anyway)
+    p.ok = (d == 64 || d == 128) && B >= 256 && N >= 2048 && k >= 1 && k <= 32 && (int64_t)p.tpc * 32 * p.rowb <= (int64_t)MF_SRD_MAX_BYTES;
+    return p;
+}
+
+// run-time switch (tests compare the two candidate searches; MF_MINE_BF=0 in the environment turns the prefilter off)
+static int g_mine_bf_mode = -1;
+static inline bool mine_bf_enabled() {
+    if (g_mine_bf_mode < 0) {
+        const char* e = getenv("MF_MINE_BF");
+        g_mine_bf_mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_mine_bf_mode != 0;
+}
+
+#ifdef __HIPCC__
+
+__device__ __forceinline__ unsigned short mbf_round(float x) {
+    const __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float mbf_float(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+// x -> three bf16 pieces whose sum is x to 2^-26 |x| (the subtractions are exact)
+__device__ __forceinline__ void mbf_split3(float x, unsigned short (&o)[3]) {
+    o[0] = mbf_round(x);
+    const float r1 = x - mbf_float(o[0]);
+    o[1] = mbf_round(r1);
+    const float r2 = r1 - mbf_float(o[1]);
+    o[2] = mbf_round(r2);
+}
+
+// ------------------------------------------------------------- item plane ----
+// One d/8-lane group per item: [hi d | lo d | aug 16] bf16, plus the maxima the error bound needs.
+//
+// Duplicate columns.  A batch drawn by popularity repeats its popular items hundreds of times (Zipf(1) over 62,423 items, 8192
+// draws: ~700 copies of the first), and copies tie EXACTLY: whenever one is near a user's cut all are, and no list is long
+// enough.  But copies need no search: with rep(j) = the first column whose row is bit for bit column j's (found through the
+// mask builder's colfirst -- first column with j's item id -- and verified on the rows themselves), the copies of a column
+// rank directly behind it, in column order.  So only representatives are scanned (a copy's plane row is made unreachable like a
+// row past N), and the rescoring wave lists the copies of the few winners that have any (ncopy, lastcopy; mine_rescore_kernel).
+template <int D>
+__global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict__ v, const float* __restrict__ nv,
+                                                         const float* __restrict__ lqn, const int32_t* __restrict__ colfirst,
+                                                         int64_t N, int64_t Nq, float sigma, unsigned short* __restrict__ plane,
+                                                         unsigned* __restrict__ maxima, int32_t* __restrict__ rep,
+                                                         int32_t* __restrict__ ncopy, int32_t* __restrict__ lastcopy) {
+    constexpr int LPR = D / 8, RW = 2 * D + 16;
+    const int lane = mf_lane();
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = t / LPR;
+    const int c = (int)(t % LPR);
+    const bool live = r < Nq;                                 // (whole groups: Nq LPR is a multiple of 64)
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    u16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
+    bool same = false;
+    int64_t f = r;
+    if (live && r < N) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(v + r * D)[2 * c], b = reinterpret_cast<const f32x4*>(v + r * D)[2 * c + 1];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = i < 4 ? a[i] : b[i - 4];
+            hi[i] = mbf_round(x);
+            lo[i] = mbf_round(x - mbf_float(hi[i]));
+        }
+        const int64_t cf = colfirst ? (int64_t)colfirst[r] : r;
+        if (cf >= 0 && cf < r) {                              // an earlier column carries the same item id: the same row?
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 fa = reinterpret_cast<const u32x4*>(v + cf * D)[2 * c], fb = reinterpret_cast<const u32x4*>(v + cf * D)[2 * c + 1];
+            const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
+            same = ua[0] == fa[0] && ua[1] == fa[1] && ua[2] == fa[2] && ua[3] == fa[3] && ub[0] == fb[0] && ub[1] == fb[1] && ub[2] == fb[2] && ub[3] == fb[3];
+            f = cf;
+        }
+    }
+    const unsigned long long gm = (LPR >= 64 ? ~0ull : ((1ull << LPR) - 1ull)) << (lane & ~(LPR - 1));
+    const bool dup = (__ballot(same) & gm) == gm;             // every chunk of the row equals the first copy's
+    float mx_nv = 0.f, mx_q = 0.f;
+    if (live) {
+        unsigned short* row = plane + r * RW;
+        *reinterpret_cast<u16x8*>(row + 8 * c) = hi;
+        *reinterpret_cast<u16x8*>(row + D + 8 * c) = lo;
+        if (c == 0) {
+            u16x8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
+            if (r < N && !dup) {
+                const float w = (0.5f * sigma) * nv[r], q = lqn[r];
+                unsigned short ws[3], qs[3];
+                mbf_split3(w, ws);
+                mbf_split3(q, qs);
+                const unsigned short one = 0x3F80;
+                a0 = u16x8{ws[0], ws[1], ws[2], qs[0], qs[1], qs[2], one, one};
+                a1[0] = one;
+                mx_nv = nv[r];
+                mx_q = fabsf(q);
+            } else {
+                a0[3] = 0x7E00;      // rows past N and copies: 2^125 in the first logQ slot -- their accumulators never pass |acc| <= half
+            }
+            *reinterpret_cast<u16x8*>(row + 2 * D) = a0;
+            *reinterpret_cast<u16x8*>(row + 2 * D + 8) = a1;
+            rep[r] = (int32_t)(dup ? f : r);
+            if (dup) {
+                atomicAdd(ncopy + f, 1);
+                atomicMax(lastcopy + f, (int32_t)r);
+            }
+        }
+    }
+    // one atomic per wave and maximum (non-negative floats order like their bits; NaN ranks above everything: it reaches the bound)
+    unsigned bn = __builtin_bit_cast(unsigned, mx_nv), bq = __builtin_bit_cast(unsigned, mx_q);
+    bn = mf_wave_max_u32(bn);
+    bq = mf_wave_max_u32(bq);
+    if (lane == 0) {
+        atomicMax(maxima + 0, bn);
+        atomicMax(maxima + 1, bq);
+    }
+}
+
+// ------------------------------------------------------- user fragments ----
+// as u in MFMA operand order (hi steps, then lo steps), and per user {half, rho, s}: the interval test of the scan
+struct MineUsers {
+    const float *u, *nu, *lii, *sgn;
+    const unsigned* gtau;
+    const unsigned* maxima;
+    int64_t B, Xq;
+    float sigma;
+    mbf16x8* ufrag;          // [Xq / 32][2 KS][64]
+    f32x4* rowk;             // [Xq]: {half, rho, s, eps}
+    int32_t* rowflag;        // [Xq]: 1 = the rescoring wave walks the whole row
+    unsigned long long* dbg; // lab: [3] += no bound, [4] += non-finite, [5] += zero targets (NULL: off)
+};
+template <int D, class Policy>
+__global__ __launch_bounds__(256) void mine_users_kernel(MineUsers p) {
+    constexpr int LPR = D / 8, KS = D / 16;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t x = t / LPR;
+    const int j = (int)(t % LPR);
+    if (x >= p.Xq) return;
+    const bool real = x < p.B;
+    const float s = real ? p.sgn[x] : 0.f;
+    const float as = p.sigma * s;
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    u16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
+    if (real) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(p.u + x * D)[2 * j], b = reinterpret_cast<const f32x4*>(p.u + x * D)[2 * j + 1];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float y = as * (i < 4 ? a[i] : b[i - 4]);
+            hi[i] = mbf_round(y);
+            lo[i] = mbf_round(y - mbf_float(hi[i]));
+        }
+    }
+    const int step = j >> 1, h = j & 1;
+    mbf16x8* f = p.ufrag + ((x >> 5) * (2 * KS)) * 64 + (x & 31) + 32 * h;
+    f[step * 64] = __builtin_bit_cast(mbf16x8, hi);
+    f[(KS + step) * 64] = __builtin_bit_cast(mbf16x8, lo);
+    if (j != 0) return;
+    float half = -1.f, rho = 0.f, eps = 0.f;
+    int flag = 0;
+    if (real) {
+        const double nvmax = (double)__builtin_bit_cast(float, p.maxima[0]), Q = (double)__builtin_bit_cast(float, p.maxima[1]);
+        const double nu = (double)p.nu[x], li = (double)p.lii[x], sg = (double)p.sigma, aas = fabs((double)as);
+        const double P = aas * sqrt(nu * nvmax), W = 0.5 * fabs(sg) * nvmax, Hn = 0.5 * aas * nu;
+        const double M = P + Hn + W + Q + fabs(li);
+        const typename Policy::Thr th = Policy::make_thr(p.gtau[x]);
+        const bool none = th.lo > th.hi;                                   // (thr_none: cannot happen for a real row; nothing passes)
+        double lo_ = (double)th.lo, hi_ = (double)th.hi;
+        const double big = 1.01 * M + 1e-30;
+        if (!(lo_ > -big)) lo_ = -big;                                     // an open end: no Dm of this row lies beyond +-M
+        if (!(hi_ < big)) hi_ = big;
+        const double mid = 0.5 * (lo_ + hi_);
+        const double hs = -0.5 * (double)as;
+        const double rd = hs * nu - li - mid;
+        rho = (float)rd;
+        const double ar = fabs((double)rho);
+        const double S = 1.01 * P + W + Q + ar;
+        const double nt = 3.0 * D + 16.0;
+        const double e = 1.01 * (nt * 0x1p-23 * S + 3.1 * 0x1p-18 * P + 0x1p-23 * (W + Q + ar) + D * 0x1p-23 * P + 0x1p-21 * M);
+        eps = (float)e;
+        double hf = (0.5 * (hi_ - lo_) + e) * (1.0 + 0x1p-20) + 1e-37;
+        half = (float)hf;
+        if ((double)half < hf) half = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, half) + 1u);     // (positive, finite: the next float up)
+        if (none) half = -1.f;
+        if ((p.gtau[x] >> 30) == 0u) { half = -1.f; flag = 1; if (p.dbg) atomicAdd(p.dbg + 3, 1ull); }            // no bound (fewer than k seeds in sight): every column would pass
+        if (!(hf < 1e37) || !(M < 1e37)) { half = -1.f; flag = 1; if (p.dbg) atomicAdd(p.dbg + 4, 1ull); }        // non-finite inputs: the exact walk decides
+        if (s == 0.f) { half = -1.f; flag = 1; if (p.dbg) atomicAdd(p.dbg + 5, 1ull); }                           // a zero target: Dm does not depend on the embeddings -- the exact walk is cheap
+    }
+    p.rowk[x] = f32x4{half, rho, s, eps};
+    p.rowflag[x] = flag;
+}
+
+// ------------------------------------------------------------------ scan ----
+struct MineScan {
+    const unsigned short* plane;     // [Nq][2 d + 16]
+    int64_t Nq;
+    int NT, tpc;
+    const mbf16x8* ufrag;
+    const f32x4* rowk;
+    int64_t Xq;
+    unsigned long long* plist;       // [nchunk][Xq][2][MBF_CAPL]: {acc bits << 32 | column}
+    uint32_t* pcnt;                  // [nchunk][Xq][2]
+    int32_t* rowflag;
+    unsigned long long* dbg;         // lab: [6] += entries of overflowing lane lists, [7] = max half (bits) of overflowing rows
+};
+template <int D>
+struct MineLds {
+    static constexpr int ROWB = 2 * D;                        // bytes of a bf16 row of one part
+    static constexpr int SUB = 32 * ROWB;                     // hi (and lo) sub-tile
+    static constexpr int TILEB = 2 * SUB + 1024;              // + the 16 augmented slots of the 32 rows
+    static constexpr int PIECES = TILEB / 1024;               // 17 (d = 128), 9
+    static constexpr int HP = SUB / 1024;                     // pieces of a sub-tile
+    static constexpr int PPW = (PIECES + MBF_WAVES - 1) / MBF_WAVES;
+    static constexpr int CPR = ROWB / 16;
+    static __device__ __forceinline__ int swz(int row) { return CPR >= 16 ? (row & 15) : ((row >> 1) & 7); }
+    static constexpr int NS = 2 * MBF_BLOCK;
+    static constexpr int RING = NS * TILEB;
+    static constexpr int DUMP0 = RING;
+    static constexpr int BYTES = RING + 1024;
+};
+
+template <int D>
+__global__ __launch_bounds__(64 * MBF_WAVES, 2) void mine_scan_kernel(MineScan p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using L = MineLds<D>;
+    constexpr int KS = D / 16, NS = L::NS, RW = (2 * D + 16) * 2;
+    const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
+    const int wave = mf_wave_id();
+    const int64_t x0 = (int64_t)blockIdx.y * MBF_ROWS_WG + (int64_t)wave * (32 * MBF_XT);
+    const int chunk = blockIdx.x;
+    const int t0 = chunk * p.tpc, t1 = min(p.NT, t0 + p.tpc);
+    const int nv = t1 - t0;
+
+    const int64_t row0 = (int64_t)t0 * 32;
+    mf_rsrc_t trsrc;
+    unsigned toff[L::PPW];
+    {
+        int64_t bytes = (p.Nq - row0) * (int64_t)RW;
+        bytes = bytes < 0 ? 0 : (bytes > (int64_t)MF_SRD_MAX_BYTES ? (int64_t)MF_SRD_MAX_BYTES : bytes);
+#if defined(__HIP_DEVICE_COMPILE__)
+        trsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.plane + row0 * (2 * D + 16)), 0, (int)(unsigned)bytes, 0x00020000);
+#else
+        (void)trsrc;
+#endif
+#pragma unroll
+        for (int q = 0; q < L::PPW; ++q) {
+            const int piece = wave + q * MBF_WAVES;
+            unsigned o = MF_SRD_DEAD;
+            if (piece < 2 * L::HP) {
+                const int part = piece / L::HP;                               // 0 hi, 1 lo
+                const int off = (piece - part * L::HP) * 1024 + lane * 16;
+                const int row = off / L::ROWB;
+                const int ch = ((off % L::ROWB) >> 4) ^ L::swz(row);
+                o = (unsigned)(row * RW + part * L::ROWB + ch * 16);
+            } else if (piece == 2 * L::HP) {
+                o = (unsigned)((lane >> 1) * RW + 2 * L::ROWB + (lane & 1) * 16);
+            }
+            toff[q] = o;
+            asm volatile("" : "+v"(toff[q]));
+        }
+    }
+    auto stage = [&](int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        char* slot = smem + (v % NS) * L::TILEB;
+        const int soff = v < nv ? (int)((int64_t)v * 32 * RW) : (int)MF_SRD_DEAD;
+#pragma unroll
+        for (int q = 0; q < L::PPW; ++q) {
+            const int piece = wave + q * MBF_WAVES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(trsrc, (mf_lds_ptr)(piece < L::PIECES ? slot + piece * 1024 : smem + L::DUMP0), 16, (int)toff[q], soff, 0, 0);
+        }
+#else
+        (void)v;
+#endif
+    };
+#pragma unroll
+    for (int j = 0; j < MBF_BLOCK; ++j) stage(j);
+
+    mbf16x8 ubh[MBF_XT][KS], ubl[MBF_XT][KS], uaug[MBF_XT];
+    float half[MBF_XT];
+    unsigned long long* list[MBF_XT];
+    int cnt[MBF_XT];
+#pragma unroll
+    for (int xt = 0; xt < MBF_XT; ++xt) {
+        const int64_t x = x0 + 32 * xt + c;
+        const mbf16x8* xf = p.ufrag + ((x0 / 32 + xt) * (2 * KS)) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { ubh[xt][s] = xf[s * 64]; ubl[xt][s] = xf[(KS + s) * 64]; }
+        const f32x4 rk = p.rowk[x];
+        half[xt] = rk[0];
+        unsigned short r3[3];
+        mbf_split3(rk[1], r3);
+        const unsigned short one = 0x3F80, ms = mbf_round(-rk[2]);
+        typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+        const u16x8 a = h == 0 ? u16x8{ms, ms, ms, one, one, one, r3[0], r3[1]} : u16x8{r3[2], 0, 0, 0, 0, 0, 0, 0};
+        uaug[xt] = __builtin_bit_cast(mbf16x8, a);
+        list[xt] = p.plist + (((int64_t)chunk * p.Xq + x) * 2 + h) * MBF_CAPL;
+        cnt[xt] = 0;
+    }
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (int v = 0; v < nv; ++v) {
+        if ((v & (MBF_BLOCK - 1)) == 0) {
+            mf_wait_vmcnt<0>();
+            mf_block_barrier();
+            if (v + MBF_BLOCK < nv) {
+#pragma unroll
+                for (int j = 0; j < MBF_BLOCK; ++j) stage(v + MBF_BLOCK + j);
+            }
+        }
+        const char* slot = smem + (v % NS) * L::TILEB;
+        const char* rowp = slot + c * L::ROWB;
+        const int sw = L::swz(c);
+        mbf16x8 ahi[KS], alo[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            ahi[s] = *reinterpret_cast<const mbf16x8*>(rowp + (((2 * s + h) ^ sw) << 4));
+            alo[s] = *reinterpret_cast<const mbf16x8*>(rowp + L::SUB + (((2 * s + h) ^ sw) << 4));
+        }
+        const mbf16x8 aaug = *reinterpret_cast<const mbf16x8*>(slot + 2 * L::SUB + c * 32 + h * 16);
+        const unsigned col0 = (unsigned)(t0 + v) * 32u + 4u * (unsigned)h;
+#pragma unroll
+        for (int xt = 0; xt < MBF_XT; ++xt) {
+            f32x16 acc = zero16;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[s], ubh[xt][s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[s], ubh[xt][s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[s], ubl[xt][s], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aaug, uaug[xt], acc, 0, 0, 0);
+            // one compare per element into a wave mask; the masks are OR-ed on the scalar unit, and only a tile with a hit
+            // (tens of columns per user in all) looks at them one by one
+            unsigned long long m[16], any = 0ull;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                m[e] = __ballot(fabsf(acc[e]) <= half[xt]);
+                any |= m[e];
+            }
+            if (any) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (m[e]) {
+                        if (fabsf(acc[e]) <= half[xt]) {
+                            if (cnt[xt] < MBF_CAPL)
+                                mf_cand_store(list[xt] + cnt[xt], col0 + (unsigned)((e & 3) + 8 * (e >> 2)), __builtin_bit_cast(unsigned, acc[e]));
+                            ++cnt[xt];
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int xt = 0; xt < MBF_XT; ++xt) {
+        const int64_t x = x0 + 32 * xt + c;
+        p.pcnt[((int64_t)chunk * p.Xq + x) * 2 + h] = (uint32_t)min(cnt[xt], MBF_CAPL);
+        if (cnt[xt] > MBF_CAPL) {
+            p.rowflag[x] = 1;
+            if (p.dbg) { atomicAdd(p.dbg + 6, (unsigned long long)cnt[xt]); atomicMax(p.dbg + 7, (unsigned long long)__builtin_bit_cast(unsigned, half[xt])); }
+        }
+    }
+}
+
+// --------------------------------------------------------------- rescore ----
+struct MineRescore {
+    const float *u, *v, *nu, *nv, *lii, *sgn, *lqn;
+    const uint32_t* maskW;
+    int64_t B, Bp, N, Xq;
+    float sigma;
+    int nlists, k;
+    const unsigned long long* plist;
+    const uint32_t* pcnt;
+    const int32_t* rowflag;
+    const int32_t *rep, *ncopy, *lastcopy;
+    unsigned long long* cand;
+    int32_t* cand_cnt;
+    int rowcap;
+    unsigned long long* dbg;         // lab: [0] += candidates rescored, [1] += rows, [2] += rows walked exactly (NULL: off)
+};
+static constexpr int MBF_RW = 4;                         // users (waves) per rescoring workgroup
+template <int D>
+struct MineRescoreGeom {
+    static constexpr int CPR = D / 4;                   // 16-byte chunks of an fp32 row
+    static constexpr int RPI = 64 / CPR;                // rows per DMA instruction
+    static constexpr int RB = 64;                       // candidates per round
+    static constexpr int NI = RB / RPI;
+    static constexpr int LMAX = MBF_MAXLISTS * MBF_CAPL;
+    static constexpr int PER_WAVE = RB * D * 4 + LMAX * 8 + 2 * 64 * 8 + D * 4;      // rows | keys | win, sorted | the user's row
+};
+
+// the exact key of (user, column) from the chain product -- MiningPolicy::key, word for word
+__device__ __forceinline__ unsigned long long mine_exact_key(float nu, float nvj, float dot, float s, float sigma, float lqnj, float lii, unsigned col) {
+    const float Lg = mf_logit(nu, nvj, dot, s, sigma, -lqnj);
+    return mf_key_mining(Lg - lii, col);
+}
+template <int D>
+__device__ __forceinline__ float mine_chain_global(const float* xq, const float* __restrict__ row) {
+    constexpr int BL = D < 128 ? D : 128;
+    float acc = 0.f;
+#pragma unroll
+    for (int g0 = 0; g0 < D; g0 += BL) {
+        f32x4 y[BL / 4];
+#pragma unroll
+        for (int j = 0; j < BL / 4; ++j) y[j] = *reinterpret_cast<const f32x4*>(row + g0 + 4 * j);
+#pragma unroll
+        for (int g = 0; g < BL; g += 8)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc = __builtin_fmaf(xq[g0 + g + t], y[g / 4][t], acc);
+                acc = __builtin_fmaf(xq[g0 + g + 4 + t], y[g / 4 + 1][t], acc);
+            }
+    }
+    return acc;
+}
+// The copies of representative column f behind column `from`, in column order, by the whole wave: emit(col) for each one that
+// is a valid negative of user x, until `want` were emitted or the `left` copies behind `from` are all seen.  Returns the number emitted.
+template <class Emit>
+__device__ __forceinline__ int mine_copies(const MineRescore& p, int64_t x, unsigned f, unsigned from, int left, int want, Emit emit) {
+    const int lane = mf_lane();
+    int got = 0;
+    for (int64_t base = (int64_t)(from + 1) & ~63ll; base < p.N && left > 0 && got < want; base += 256) {
+        unsigned long long hit[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t col = base + 64 * j + lane;
+            hit[j] = __ballot(col < p.N && col > (int64_t)from && (unsigned)p.rep[col] == f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned long long m = hit[j];
+            while (m && got < want) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                --left;
+                const unsigned col = (unsigned)(base + 64 * j + b);
+                if (!((p.maskW[(int64_t)(col >> 5) * p.Bp + x] >> (col & 31)) & 1u)) { emit(col, got); ++got; }     // (the user's own diagonal may be a copy)
+            }
+        }
+    }
+    return got;
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * MBF_RW) void mine_rescore_kernel(MineRescore p) {
+    using G = MineRescoreGeom<D>;
+    extern __shared__ __attribute__((aligned(1024))) char fsm[];
+    const int lane = mf_lane(), wave = mf_wave_id();
+    char* mine_ = fsm + wave * G::PER_WAVE;
+    float* rows_lds = reinterpret_cast<float*>(mine_);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(mine_ + G::RB * D * 4);      // columns first, their keys later
+    unsigned long long* win = keys + G::LMAX;
+    unsigned long long* sorted = win + 64;
+    float* xq = reinterpret_cast<float*>(sorted + 64);
+    const int64_t x = (int64_t)blockIdx.x * MBF_RW + wave;
+    if (x >= p.B) return;                                   // (the waves never meet)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const float nu = p.nu[x], lii = p.lii[x], s = p.sgn[x];
+    const int flag = p.rowflag[x];
+#pragma unroll
+    for (int j = 0; j < (D + 63) / 64; ++j)
+        if (lane + 64 * j < D) xq[lane + 64 * j] = p.u[x * D + lane + 64 * j];
+    unsigned long long* out = p.cand + x * (int64_t)p.rowcap;
+    int n_out = 0;
+    if (!flag) {
+        // the lists: lane l owns list l = 2 chunk + lane half
+        const int nl = lane < p.nlists ? (int)p.pcnt[((int64_t)(lane >> 1) * p.Xq + x) * 2 + (lane & 1)] : 0;
+        const unsigned long long* src = p.plist + (((int64_t)(lane >> 1) * p.Xq + x) * 2 + (lane & 1)) * MBF_CAPL;
+        int n = 0;
+        for (int t = 0; __any(t < nl); ++t) {
+            bool keep = false, orph = false;
+            unsigned col = 0u;
+            if (t < nl) {
+                col = (unsigned)src[t];
+                if ((int64_t)col < p.N) {
+                    keep = !((p.maskW[(int64_t)(col >> 5) * p.Bp + x] >> (col & 31)) & 1u);    // hit, diagonal, padding
+                    // A masked representative with copies.  Masked through its item id: every copy is.  Masked only as this user's
+                    // own diagonal (a positive that is not on the user's list): its copies are valid negatives -- the last one
+                    // tells which -- and the first valid one stands in for it.
+                    if (!keep && (int64_t)col == x && p.ncopy[col] > 0) {
+                        const unsigned lc = (unsigned)p.lastcopy[col];
+                        orph = !((p.maskW[(int64_t)(lc >> 5) * p.Bp + x] >> (lc & 31)) & 1u);
+                    }
+                }
+            }
+            const unsigned long long bal = __ballot(keep);
+            if (keep) keys[n + __popcll(bal & below)] = (unsigned long long)col;
+            n += __popcll(bal);
+            const unsigned long long ob = __ballot(orph);
+            if (ob) {                                        // (at most one lane: the diagonal is one column)
+                const unsigned fc = (unsigned)__shfl((int)col, __builtin_ctzll(ob), 64);
+                n += mine_copies(p, x, fc, fc, p.ncopy[fc], 1, [&](unsigned cc, int) { if (lane == 0) keys[n] = (unsigned long long)cc; });
+            }
+        }
+        mf_row_topk_sync<true>();
+        if (p.dbg && lane == 0) { atomicAdd(p.dbg, (unsigned long long)n); atomicAdd(p.dbg + 1, 1ull); }
+        const int pz = lane % G::CPR, sub = lane / G::CPR;
+        const float* row_l = rows_lds + lane * D;
+        const int sw = lane & 15;
+        for (int base = 0; base < n; base += G::RB) {
+            const int nr = min(G::RB, n - base);
+            const bool have = lane < nr;
+            const unsigned col = have ? (unsigned)keys[base + lane] : 0u;
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the columns have arrived
+#pragma unroll
+            for (int t = 0; t < G::NI; ++t) {
+                if (t * G::RPI < nr) {                       // (wave-uniform)
+                    unsigned rr = (unsigned)__builtin_amdgcn_readlane((int)col, G::RPI * t);
+#pragma unroll
+                    for (int j = 1; j < G::RPI; ++j) {
+                        const unsigned rj = (unsigned)__builtin_amdgcn_readlane((int)col, G::RPI * t + j);
+                        rr = sub == j ? rj : rr;
+                    }
+                    const int ch = pz ^ ((G::RPI * t + sub) & 15);
+                    const float* srcp = p.v + (int64_t)rr * D + 4 * ch;
+                    __builtin_amdgcn_global_load_lds((mf_glb_ptr)srcp, (mf_lds_ptr)(rows_lds + t * 256), 16, 0, 0);
+                }
+            }
+            const float nvj = have ? p.nv[col] : 0.f, lqj = have ? p.lqn[col] : 0.f;
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+            asm volatile("" ::: "memory");
+            float acc = 0.f;
+#pragma unroll 4
+            for (int g = 0; g < D / 8; ++g) {                // k order of mf_dot_chain
+                const f32x4 a = *reinterpret_cast<const f32x4*>(row_l + (((2 * g) ^ sw) << 2));
+                const f32x4 b = *reinterpret_cast<const f32x4*>(row_l + (((2 * g + 1) ^ sw) << 2));
+                const f32x4 xa = *reinterpret_cast<const f32x4*>(xq + 8 * g), xb = *reinterpret_cast<const f32x4*>(xq + 8 * g + 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc = __builtin_fmaf(xa[t], a[t], acc);
+                    acc = __builtin_fmaf(xb[t], b[t], acc);
+                }
+            }
+            if (have) keys[base + lane] = mine_exact_key(nu, nvj, acc, s, p.sigma, lqj, lii, col);
+            mf_row_topk_sync<true>();                        // the rows are consumed before the next round's DMA lands
+        }
+        // the k best representatives; then, behind each winner that has copies, the copies a cut at k could still reach
+        int m;
+        if (n <= 64) m = mf_row_topk<1, true>(keys, n, p.k, win, sorted);
+        else if (n <= 256) m = mf_row_topk<4, true>(keys, n, p.k, win, sorted);
+        else m = mf_row_topk<G::LMAX / 64, true>(keys, n, p.k, win, sorted);
+        if (lane < m && lane < p.rowcap) out[lane] = sorted[lane];
+        n_out = m;
+        for (int t = 0; t < m; ++t) {
+            const unsigned long long kt = sorted[t];
+            const unsigned cf = mf_key_mining_col(kt);
+            const unsigned fr = (unsigned)p.rep[cf];         // (cf itself, or -- a stand-in for a masked diagonal -- its representative)
+            const int nc = p.ncopy[fr];
+            const int want = p.k - 1 - t;                    // a copy of the winner at position t sits at position t + 1 or later
+            if (nc > 0 && want > 0) {
+                const int at = n_out;
+                n_out += mine_copies(p, x, fr, cf, nc, want, [&](unsigned cc, int i) {
+                    if (lane == 0 && at + i < p.rowcap) out[at + i] = (kt & ~0x3FFFFFFFull) | (unsigned long long)(0x3FFFFFFFu - cc);
+                });
+            }
+        }
+        n_out = min(n_out, p.rowcap);
+    } else {
+        // the whole row by the exact formulas, 64 columns a round; the k best keys so far ride along in win[]
+        if (p.dbg && lane == 0) atomicAdd(p.dbg + 2, 1ull);
+        mf_row_topk_sync<true>();
+        int carry = 0;
+        for (int64_t base = 0; base < p.N; base += 64) {
+            const int64_t col = base + lane;
+            unsigned long long v0 = 0ull;
+            if (col < p.N && !((p.maskW[(col >> 5) * p.Bp + x] >> (col & 31)) & 1u)) {
+                const float dot = s == 0.f ? 0.f : mine_chain_global<D>(xq, p.v + col * D);      // (s = 0: fma(0, dot, c) = c)
+                v0 = mine_exact_key(nu, p.nv[col], dot, s, p.sigma, p.lqn[col], lii, (unsigned)col);
+            }
+            const unsigned long long v1 = lane < carry ? win[lane] : 0ull;
+            mf_row_topk_sync<true>();
+            const int have = __popcll(__ballot(v0 != 0ull)) + carry;
+            unsigned long long tau = 1ull;
+            if (have > p.k) {
+                unsigned long long th = 0ull;
+                for (int b = 63; b >= 0; --b) {
+                    const unsigned long long cnd = th | (1ull << b);
+                    const int cge = __popcll(__ballot(v0 >= cnd)) + __popcll(__ballot(v1 >= cnd));
+                    if (cge >= p.k) th = cnd;
+                }
+                tau = th;
+            }
+            int pos = 0;
+            {
+                const bool w0 = v0 != 0ull && v0 >= tau;
+                const unsigned long long m0 = __ballot(w0);
+                if (w0) win[__popcll(m0 & below)] = v0;
+                pos = __popcll(m0);
+                const bool w1 = v1 != 0ull && v1 >= tau;
+                const unsigned long long m1 = __ballot(w1);
+                if (w1) win[pos + __popcll(m1 & below)] = v1;
+                pos += __popcll(m1);
+            }
+            carry = pos;
+            mf_row_topk_sync<true>();
+        }
+        if (lane < carry && lane < p.rowcap) out[lane] = win[lane];
+        n_out = min(carry, p.rowcap);
+    }
+    if (lane == 0) p.cand_cnt[x] = n_out;
+}
+
+#endif  // __HIPCC__

@@ -57,6 +57,7 @@ struct SelectCommon {
     unsigned long long* cand;   // [Xp][rowcap]: every X row's surviving keys of ALL chunks, contiguous
     int32_t* cand_cnt;          // [Xp], zeroed by the host: fill count of the row's list (atomic cursor)
     int rowcap;                 // nsets * 2 CAPH
+    int tstride;                // seeding pass: virtual tile t of [t_begin, t_end) is real tile t * tstride (0 or 1: contiguous)
 };
 
 #ifdef MF_PROBE
@@ -414,12 +415,15 @@ __global__ __launch_bounds__(64 * mf_nw(D), T >= 32 ? 1 : mf_wg_per_cu(D)) void 
 #pragma unroll
     for (int i = 0; i < T; ++i) tl[i] = 0u;
 
+    // A STRIDED sample (round 4): the first eighth of a batch's columns are the positives of its first users -- popular items --
+    // while the uniform negatives sit at the end: a bound from the head alone missed the cut of ~4 % of the users by a wide margin.
+    const int ts = sc.tstride > 1 ? sc.tstride : 1;
     TileSrc<D> tsrc;
-    mf_tile_src_init<D>(tsrc, sc.Y, sc.nY, (int64_t)t0 * 32);
+    mf_tile_src_init<D>(tsrc, sc.Y, sc.nY, (int64_t)t0 * ts * 32);
     auto stage = [&](int t) {
         const int kk = t - t0;
-        mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, t * 32, tsrc);
-        Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t, x0, L::W0);
+        mf_stage_tile<D>(smem + (kk % L::NSLOT) * G::TILEB, t * ts * 32, tsrc);
+        Policy::stage_aux(pp, smem + L::AUX0 + (kk & 3) * L::AUXB, wave, t * ts, x0, L::W0);
     };
     auto mine_tile = [&](int t) { return (t - t0) % nsub == sub; };
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), T >= 32 ? 1 : mf_wg_per_cu(D)) void 
             }
             if (cur) {
                 tile = Policy::tile_init(pp, row, smem + L::AUX0 + ((ty - t0) & 3) * L::AUXB, wave, c, h, L::W0);
-                y0 = (unsigned)ty * 32u;
+                y0 = (unsigned)(ty * ts) * 32u;
             }
             const char* next_tile = smem + ((ty + 1 - t0) % L::NSLOT) * G::TILEB;
             if (cur && nxt) {
@@ -675,9 +679,10 @@ static void mf_select_seed_t(const typename Policy::Params& pp, const SelectComm
 // cand_cnt zeroed; `seeds`: [Xp][plan.seeds_per_row] scratch
 template <int D, class Policy>
 static void mf_select_run(const SelectPlan& plan, const typename Policy::Params& pp, SelectCommon sc,
-                          unsigned long long* seeds, int64_t nX, hipStream_t s) {
+                          unsigned long long* seeds, int64_t nX, hipStream_t s, bool seed_only = false) {
     if (plan.YTa > 0) {
         sc.t_begin = 0; sc.t_end = plan.YTa; sc.tiles_per_chunk = plan.tpcA;
+        sc.tstride = MF_SEED_DIV;                       // tile t of the sample is tile MF_SEED_DIV t (YTa = YT / MF_SEED_DIV)
         switch (plan.T) {
             case 2: mf_select_seed_t<D, 2, Policy>(pp, sc, seeds, plan.seeds_per_row, plan.nchunkA, plan.gx, s); break;
             case 4: mf_select_seed_t<D, 4, Policy>(pp, sc, seeds, plan.seeds_per_row, plan.nchunkA, plan.gx, s); break;
@@ -689,6 +694,8 @@ static void mf_select_run(const SelectPlan& plan, const typename Policy::Params&
         }
         select_bound_kernel<0><<<dim3((unsigned)((nX + 3) / 4)), 256, 0, s>>>(seeds, plan.seeds_per_row, sc.k, nX, sc.gtau);
     }
+    if (seed_only) return;          // (mf_mine_bf.h: the bound is all the prefilter wants from here)
+    sc.tstride = 1;
     sc.t_begin = 0; sc.t_end = plan.YT; sc.tiles_per_chunk = plan.tpc;
     mf_select_launch<D, Policy>(plan.T, pp, sc, plan.nchunk, plan.gx, s);
 }

@@ -1056,3 +1056,48 @@ def test_update_pair_equals_two_updates(mf, adam):
         assert torch.equal(ta1, ta2) and torch.equal(tb1, tb2), step
         if adam:
             assert all(torch.equal(x, y) for x, y in zip(sa1 + sb1, sa2 + sb2)), step
+
+
+def _mined_mask(mf, t, k, sigma, logq=None):
+    kw = dict(item_idx=t["item_idx"].to(DEV), pos_idx=t["pos_idx"].to(DEV), num_negatives=k, sigma=sigma)
+    return mf.losses.negative_mask(t["u"].to(DEV), t["v"].to(DEV), t["target"].to(DEV), **kw).cpu()
+
+
+@pytest.mark.parametrize("tied", [False, True], ids=["distinct", "zipf-copies"])
+@pytest.mark.parametrize("cfg", [(512, 2048, 64, 4, 1.0), (300, 2500, 128, 4, 1.0), (1024, 4096, 128, 32, 30.0), (700, 3000, 64, 9, 1000.0)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_mined_masks_through_the_bf16_prefilter_are_bit_exact(mf, cfg, tied):
+    """The split-bf16 candidate search (csrc/mf_mine_bf.h) against the oracle's semi-hard mining AND against the fp32
+    streaming selection it replaces at these shapes: all three masks are the same bits -- zero-target users, duplicate
+    item rows (exact ties), accidental hits and a ragged last tile included.  `tied`: the item rows are looked up by id in a
+    table, as the module does, with a popularity skew -- hundreds of bit-identical columns, which the prefilter scans once
+    and expands behind the winners; every fifth user's positive is missing from its own list (its copies are then valid
+    negatives at Dm = 0 exactly)."""
+    b, n, d, k, sigma = cfg
+    t = _random_case(b, n, d, 6, seed=sum(map(int, cfg[:4])), n_items=n // 3)
+    if tied:
+        g = torch.Generator().manual_seed(7)
+        ids = torch.randint(1, n // 8, (n,), generator=g)
+        ids[40:40 + n // 4] = 3                              # one item a quarter of the batch
+        ids[n - 300:n - 100] = 5
+        table = _unit(n // 8 + 1, d, g)
+        t["item_idx"] = ids
+        t["v"] = table[ids].clone()
+        t["pos_idx"] = torch.randint(0, n // 8, t["pos_idx"].shape, generator=g)
+        t["pos_idx"][:, 0] = ids[:b]
+        t["pos_idx"][::5, 0] = 0                             # (0 = padding: these users do not list their own positive)
+    else:
+        t["v"][n // 2:n // 2 + 40] = t["v"][:40]             # duplicate rows under different ids: equal scores, the column decides
+    t["u"][5] = t["u"][4]
+    lg = torch.from_numpy(chain.logits(t["u"].numpy(), t["v"].numpy(), t["target"].numpy(), sigma))
+    want = ol.semi_hard_mining(lg, ol.negative_masks(t["item_idx"], t["pos_idx"], b), k)
+    lib = mf._lib.lib()
+    try:
+        lib.mf_set_mining_prefilter(0)
+        plain = _mined_mask(mf, t, k, sigma)
+        lib.mf_set_mining_prefilter(1)
+        got = _mined_mask(mf, t, k, sigma)
+    finally:
+        lib.mf_set_mining_prefilter(1)
+    assert torch.equal(plain, want), int((plain != want).sum())
+    assert torch.equal(got, want), (int((got != want).sum()), (got != want).any(1).nonzero().flatten()[:8].tolist())

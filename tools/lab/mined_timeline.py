@@ -6,7 +6,7 @@ if len(sys.argv) > 1:
     import sqlite3
     db = sqlite3.connect(sys.argv[1])
     rows = db.execute("select name,start,end from kernels order by start").fetchall()
-    idx = [i for i, r in enumerate(rows) if "select_kernel<" in r[0]]
+    idx = [i for i, r in enumerate(rows) if r[0].startswith("mined_rows_kernel")]       # (present with and without the bf16 prefilter)
     a, b = idx[60], idx[61]
     prev = None
     for r in rows[a:b]:
@@ -27,6 +27,22 @@ mf = importlib.import_module("matrix-factorization-torch_amd")
 dev = torch.device("cuda:0")
 batches, _ = bench.make_batches(8, 8192, seed=1000, device=dev)
 tr = bench.Trainer(mf, dev, "adam", 4, loss="PairwiseHingeLoss")
-for i in range(120):
+import time
+for i in range(40):
     tr.step(batches[i % 8])
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(80):
+    tr.step(batches[i % 8])
+torch.cuda.synchronize()
+print(f"mined step (wall clock, 80 steps): {(time.perf_counter() - t0) / 80 * 1e6:.1f} us", flush=True)
+if os.environ.get("MF_MINE_DBG"):
+    import ctypes
+    lib = mf._lib.lib()
+    if hasattr(lib, "mf_probe_mining_prefilter"):
+        buf = (ctypes.c_ulonglong * 8)()
+        lib.mf_probe_mining_prefilter(None, 1)
+        tr.step(batches[0])
+        torch.cuda.synchronize()
+        lib.mf_probe_mining_prefilter(buf, 0)
+        print(f"prefilter: {buf[0] / max(buf[1], 1):.1f} candidates rescored per user over {buf[1]} users, {buf[2]} users walked exactly (no bound {buf[3]}, non-finite {buf[4]}, zero target {buf[5]}; the rest: a list overflowed -- {buf[6]} entries in overflowing lane lists, largest half {__import__('struct').unpack('f', __import__('struct').pack('I', buf[7] & 0xFFFFFFFF))[0]:.4g})", flush=True)
