@@ -64,8 +64,10 @@ struct LossWs {
     void* mbf_rowk;
     int32_t* mbf_flag;
     unsigned* mbf_max;
-    int32_t *mbf_ncopy, *mbf_lastcopy, *mbf_rep;
-    unsigned long long* mbf_plist;
+    unsigned long long* mbf_copybits;
+    int32_t *mbf_lastcopy, *mbf_rep, *mbf_spill_cnt, *mbf_gate;
+    uint32_t* mbf_spill;
+    uint32_t* mbf_plist;
     uint32_t* mbf_pcnt;
     long long* dvfix;            // mined backward: exact fixed-point accumulator of dv [N][d]
     float* dvsc;                 // its unit for this batch: {2^E, clamp, 2^-E} (dv_fix_of, mf_loss_math.h)
@@ -137,18 +139,21 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
         w.dvfix = a.take<long long>((size_t)w.N * d);
         w.gtau = a.take<unsigned>((size_t)w.Bp);
         w.cand_cnt = a.take<int32_t>((size_t)w.Bp);      // right behind gtau: one memset clears both
-        w.mbf_max = a.take<unsigned>(4);                 // ... and these maxima
+        w.mbf_max = a.take<unsigned>(2 * MBF_MAXSLOTS);  // ... and these maxima
         w.mbf = mine_bf_plan(B, N, d, k);
         if (w.mbf.ok) {
-            w.mbf_ncopy = a.take<int32_t>((size_t)w.mbf.Nq);        // (cleared with the maxima)
+            w.mbf_copybits = a.take<unsigned long long>((size_t)w.mbf.Nq);        // (cleared with the maxima, and the next)
             w.mbf_lastcopy = a.take<int32_t>((size_t)w.mbf.Nq);
+            w.mbf_spill_cnt = a.take<int32_t>((size_t)w.mbf.Xq);
+            w.mbf_gate = a.take<int32_t>(4);                             // (the cleared range ends here)
             w.mbf_rep = a.take<int32_t>((size_t)w.mbf.Nq);
+            w.mbf_spill = a.take<uint32_t>((size_t)w.mbf.Xq * MBF_SPILL);
             w.mbf_plane = a.take<unsigned short>((size_t)w.mbf.Nq * (2 * d + 16) + 64);
             w.mbf_ufrag = a.take<char>((size_t)w.mbf.Xq * d * 4);
             w.mbf_rowk = a.take<char>((size_t)w.mbf.Xq * 16);
             w.mbf_flag = a.take<int32_t>((size_t)w.mbf.Xq);
-            w.mbf_plist = a.take<unsigned long long>((size_t)w.mbf.nchunk * w.mbf.Xq * 2 * MBF_CAPL);
-            w.mbf_pcnt = a.take<uint32_t>((size_t)w.mbf.nchunk * w.mbf.Xq * 2);
+            w.mbf_plist = a.take<uint32_t>((size_t)w.mbf.nchunk * w.mbf.Xq * 2 * MBF_CAPL);
+            w.mbf_pcnt = a.take<uint32_t>((size_t)w.mbf.nchunk * w.mbf.Xq);
         }
         w.dpart = nullptr;
     } else {
@@ -1436,37 +1441,48 @@ static void mine_bf_launch(const LossWs& w, const float* u, const float* v, int6
     const MineBfPlan& m = w.mbf;
     {
         const int64_t threads = m.Nq * (D / 8);
-        mine_items_kernel<D><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(v, w.nv, w.logq, w.colfirst, N, m.Nq, sigma, w.mbf_plane, w.mbf_max,
-                                                                               w.mbf_rep, w.mbf_ncopy, w.mbf_lastcopy);
+        MF_TIMED("mining_items", s, (mine_items_kernel<D><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(v, w.nv, w.logq, w.colfirst, N, m.Nq, sigma, w.mbf_plane, w.mbf_max,
+                                                                               w.mbf_rep, w.mbf_copybits, w.mbf_lastcopy, m.blk)));
     }
     {
         MineUsers mu{u, w.nu, w.lii, w.sgn, w.gtau, w.mbf_max, B, m.Xq, sigma, static_cast<mbf16x8*>(w.mbf_ufrag),
-                     static_cast<f32x4*>(w.mbf_rowk), w.mbf_flag, g_mine_dbg};
+                     static_cast<f32x4*>(w.mbf_rowk), w.mbf_flag, w.mbf_gate, g_mine_dbg};
         const int64_t threads = m.Xq * (D / 8);
-        mine_users_kernel<D, MiningPolicy><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(mu);
+        MF_TIMED("mining_users", s, (mine_users_kernel<D, MiningPolicy><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(mu)));
     }
     {
         MineScan ms{w.mbf_plane, m.Nq, m.NT, m.tpc, static_cast<const mbf16x8*>(w.mbf_ufrag), static_cast<const f32x4*>(w.mbf_rowk), m.Xq,
-                    w.mbf_plist, w.mbf_pcnt, w.mbf_flag, g_mine_dbg};
+                    w.mbf_plist, w.mbf_pcnt, w.mbf_spill, w.mbf_spill_cnt, w.mbf_gate, g_mine_dbg, 0};
+#ifdef MF_BF3_LAB
+        if (const char* e = getenv("MF_MBF_ABL")) ms.abl = atoi(e);
+#endif
         auto fn = mine_scan_kernel<D>;
         const int bytes = MineLds<D>::BYTES;
-        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        fn<<<dim3((unsigned)m.nchunk, (unsigned)m.gy), 64 * MBF_WAVES, bytes, s>>>(ms);
+        static bool attr = false;                            // (per instantiation)
+        if (!attr) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); attr = true; }
+        MF_TIMED("mining_scan", s, (fn<<<dim3((unsigned)m.nchunk, (unsigned)m.gy), 64 * MBF_WAVES, bytes, s>>>(ms)));
     }
     {
         MineRescore mr{u, v, w.nu, w.nv, w.lii, w.sgn, w.logq, w.maskW, B, w.Bp, N, m.Xq, sigma, m.nlists, k,
-                       w.mbf_plist, w.mbf_pcnt, w.mbf_flag, w.mbf_rep, w.mbf_ncopy, w.mbf_lastcopy, w.cand, w.cand_cnt, w.plan.rowcap, g_mine_dbg};
+                       w.mbf_plist, w.mbf_pcnt, w.mbf_flag, w.mbf_spill, w.mbf_spill_cnt, w.mbf_gate, w.mbf_rep, w.mbf_copybits, w.mbf_lastcopy, m.blk, w.cand, w.cand_cnt, w.plan.rowcap,
+                       g_mine_dbg};
         auto fn = mine_rescore_kernel<D>;
-        const int bytes = MBF_RW * MineRescoreGeom<D>::PER_WAVE;
-        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        fn<<<dim3((unsigned)((B + MBF_RW - 1) / MBF_RW)), 64 * MBF_RW, bytes, s>>>(mr);
+        const int bytes = MineRescoreGeom<D>::BYTES;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); attr = true; }
+        MF_TIMED("mining_rescore", s, (fn<<<dim3((unsigned)B), 64, bytes, s>>>(mr)));
     }
 }
 static int mine_bf_run(const LossWs& w, const MiningPolicy::Params& mp, const SelectCommon& sc, const float* u, const float* v, int64_t B,
                        int64_t N, int d, int k, float sigma, hipStream_t s) {
     MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s, true))); });
-    if (d == 64) { MF_TIMED("mining_scan", s, (mine_bf_launch<64>(w, u, v, B, N, k, sigma, s))); }
-    else { MF_TIMED("mining_scan", s, (mine_bf_launch<128>(w, u, v, B, N, k, sigma, s))); }
+    if (d == 64) mine_bf_launch<64>(w, u, v, B, N, k, sigma, s);
+    else mine_bf_launch<128>(w, u, v, B, N, k, sigma, s);
+    // behind it, gated on the device: a batch the prefilter gave up on (a spill list overflowed -- thousands of exact ties --,
+    // a user without a bound, non-finite norms) is answered by the fp32 search; otherwise its workgroups leave at once
+    SelectCommon scg = sc;
+    scg.gate = w.mbf_gate;
+    MF_DISPATCH_D(d, { mf_select_run<D, MiningPolicy>(w.plan, mp, scg, w.seeds, B, s, false, true); });
     return MF_OK;
 }
 // tools/lab/mined_timeline.py: [0] candidates rescored, [1] users, [2] users walked exactly, since the last call
@@ -1570,7 +1586,7 @@ static int loss_fwd_impl(const char* what, int64_t B, int64_t N, int d, const Po
     } else if (scores_needed) {
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
         SelectCommon sc{u, B, v, N, 0, (int)((N + 31) / 32), w.plan.tpc, w.Bp, num_negatives, w.plan.xw, w.gtau, w.priv, w.cand, w.cand_cnt, w.plan.rowcap};
-        mf_zero_async(w.gtau, (size_t)((char*)(w.mbf.ok ? (void*)(w.mbf_lastcopy + w.mbf.Nq) : (void*)(w.mbf_max + 4)) - (char*)w.gtau), s);
+        mf_zero_async(w.gtau, (size_t)((char*)(w.mbf.ok ? (void*)(w.mbf_gate + 4) : (void*)(w.mbf_max + 2 * MBF_MAXSLOTS)) - (char*)w.gtau), s);
         if (w.mbf.ok && mine_bf_enabled() && w.plan.YTa > 0 && w.plan.rowcap >= num_negatives) {
             if (int rc2 = mine_bf_run(w, mp, sc, u, v, B, N, d, num_negatives, sigma, s)) return rc2;
         } else {

@@ -42,8 +42,11 @@ typedef __bf16 mbf16x8 __attribute__((ext_vector_type(8)));
 static constexpr int MBF_WAVES = 8;                     // waves per scan workgroup, two per SIMD
 static constexpr int MBF_XT = 2;                        // user tiles (32 users) a wave keeps in registers
 static constexpr int MBF_BLOCK = 2;                     // item tiles between two meeting points of the workgroup
-static constexpr int MBF_CAPL = 16;                     // entries of a lane's list (one chunk, one lane half of a user)
+static constexpr int MBF_CAPL = 16;                     // entries a rescoring lane takes: a user's list of one chunk holds 2 MBF_CAPL
+static constexpr int MBF_HCAP = 512;                    // hits a scan wave buffers in LDS per chunk (64 users; ~80 are usual)
 static constexpr int MBF_ROWS_WG = 32 * MBF_XT * MBF_WAVES;      // 512 users per workgroup
+static constexpr int MBF_MAXSLOTS = 64;                 // pairs of words the item kernel's waves spread their maxima over
+static constexpr int MBF_SPILL = 128;                   // entries of a user's spill list: hits beyond a lane's 16 (more: the fp32 search answers the batch)
 static constexpr int MBF_MAXLISTS = 32;                 // lists per user the rescoring wave gathers (one per lane; 32 x 16 keys of LDS)
 
 struct MineBfPlan {
@@ -54,6 +57,7 @@ struct MineBfPlan {
     int nchunk, tpc;        // item chunks (grid.x) and tiles per chunk
     int nlists;             // 2 nchunk lists per user
     int rowb;               // bytes of an item's row in the plane: (2 d + 16) bf16
+    int blk;                // columns per bit of a representative's copy bitmap (64 bits span the batch; a multiple of 256)
 };
 static inline MineBfPlan mine_bf_plan(int64_t B, int64_t N, int d, int k) {
     MineBfPlan p{};
@@ -62,6 +66,7 @@ static inline MineBfPlan mine_bf_plan(int64_t B, int64_t N, int d, int k) {
     p.Xq = (B + MBF_ROWS_WG - 1) / MBF_ROWS_WG * MBF_ROWS_WG;
     p.gy = (int)(p.Xq / MBF_ROWS_WG);
     p.rowb = (2 * d + 16) * 2;
+    p.blk = (int)(((p.Nq + 63) / 64 + 255) / 256 * 256);
     int want = (256 + p.gy - 1) / p.gy;                  // one workgroup per CU
     if (want > MBF_MAXLISTS / 2) want = MBF_MAXLISTS / 2;
     if (want < 1) want = 1;
@@ -108,13 +113,14 @@ __device__ __forceinline__ void mbf_split3(float x, unsigned short (&o)[3]) {
 // enough.  But copies need no search: with rep(j) = the first column whose row is bit for bit column j's (found through the
 // mask builder's colfirst -- first column with j's item id -- and verified on the rows themselves), the copies of a column
 // rank directly behind it, in column order.  So only representatives are scanned (a copy's plane row is made unreachable like a
-// row past N), and the rescoring wave lists the copies of the few winners that have any (ncopy, lastcopy; mine_rescore_kernel).
+// row past N), and the rescoring wave lists the copies of the few winners that have any: copybits[rep] has bit b set when a
+// copy lies in columns [b blk, (b + 1) blk) -- the wave reads rep[] only there (mine_copies).
 template <int D>
 __global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict__ v, const float* __restrict__ nv,
                                                          const float* __restrict__ lqn, const int32_t* __restrict__ colfirst,
                                                          int64_t N, int64_t Nq, float sigma, unsigned short* __restrict__ plane,
                                                          unsigned* __restrict__ maxima, int32_t* __restrict__ rep,
-                                                         int32_t* __restrict__ ncopy, int32_t* __restrict__ lastcopy) {
+                                                         unsigned long long* __restrict__ copybits, int32_t* __restrict__ lastcopy, int blk) {
     constexpr int LPR = D / 8, RW = 2 * D + 16;
     const int lane = mf_lane();
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -168,8 +174,11 @@ __global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict
             *reinterpret_cast<u16x8*>(row + 2 * D + 8) = a1;
             rep[r] = (int32_t)(dup ? f : r);
             if (dup) {
-                atomicAdd(ncopy + f, 1);
-                atomicMax(lastcopy + f, (int32_t)r);
+                // (a popular item's copies all land on its representative's two words: look first -- after the first few, most
+                // find their bit set and a later copy recorded, and issue no atomic at all)
+                const unsigned long long bit = 1ull << (unsigned)(r / blk);
+                if (!(__hip_atomic_load(copybits + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(copybits + f, bit);
+                if (__hip_atomic_load(lastcopy + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int32_t)r) atomicMax(lastcopy + f, (int32_t)r);
             }
         }
     }
@@ -177,9 +186,10 @@ __global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict
     unsigned bn = __builtin_bit_cast(unsigned, mx_nv), bq = __builtin_bit_cast(unsigned, mx_q);
     bn = mf_wave_max_u32(bn);
     bq = mf_wave_max_u32(bq);
-    if (lane == 0) {
-        atomicMax(maxima + 0, bn);
-        atomicMax(maxima + 1, bq);
+    if (lane == 0) {         // (4096 waves at once: on ONE pair of words their atomics were 95 of this kernel's 100 us; 64 pairs, reduced by the reader)
+        const int slot = (int)((blockIdx.x * 4 + (threadIdx.x >> 6)) & (MBF_MAXSLOTS - 1));
+        atomicMax(maxima + 2 * slot, bn);
+        atomicMax(maxima + 2 * slot + 1, bq);
     }
 }
 
@@ -193,7 +203,8 @@ struct MineUsers {
     float sigma;
     mbf16x8* ufrag;          // [Xq / 32][2 KS][64]
     f32x4* rowk;             // [Xq]: {half, rho, s, eps}
-    int32_t* rowflag;        // [Xq]: 1 = the rescoring wave walks the whole row
+    int32_t* rowflag;        // [Xq]: 1 = a zero target: the rescoring wave walks the row (Dm does not depend on the embeddings)
+    int32_t* gate;           // set: this batch is not for the prefilter (the fp32 search runs behind it)
     unsigned long long* dbg; // lab: [3] += no bound, [4] += non-finite, [5] += zero targets (NULL: off)
 };
 template <int D, class Policy>
@@ -222,10 +233,17 @@ __global__ __launch_bounds__(256) void mine_users_kernel(MineUsers p) {
     f[step * 64] = __builtin_bit_cast(mbf16x8, hi);
     f[(KS + step) * 64] = __builtin_bit_cast(mbf16x8, lo);
     if (j != 0) return;
+    float nvmax_f = 0.f, qmax_f = 0.f;
+    {
+        unsigned a = 0u, b = 0u;                             // (128 words, L2-resident; non-negative floats order like their bits, NaN above all)
+        for (int i = 0; i < MBF_MAXSLOTS; ++i) { a = max(a, p.maxima[2 * i]); b = max(b, p.maxima[2 * i + 1]); }
+        nvmax_f = __builtin_bit_cast(float, a);
+        qmax_f = __builtin_bit_cast(float, b);
+    }
     float half = -1.f, rho = 0.f, eps = 0.f;
     int flag = 0;
     if (real) {
-        const double nvmax = (double)__builtin_bit_cast(float, p.maxima[0]), Q = (double)__builtin_bit_cast(float, p.maxima[1]);
+        const double nvmax = (double)nvmax_f, Q = (double)qmax_f;
         const double nu = (double)p.nu[x], li = (double)p.lii[x], sg = (double)p.sigma, aas = fabs((double)as);
         const double P = aas * sqrt(nu * nvmax), W = 0.5 * fabs(sg) * nvmax, Hn = 0.5 * aas * nu;
         const double M = P + Hn + W + Q + fabs(li);
@@ -248,8 +266,8 @@ __global__ __launch_bounds__(256) void mine_users_kernel(MineUsers p) {
         half = (float)hf;
         if ((double)half < hf) half = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, half) + 1u);     // (positive, finite: the next float up)
         if (none) half = -1.f;
-        if ((p.gtau[x] >> 30) == 0u) { half = -1.f; flag = 1; if (p.dbg) atomicAdd(p.dbg + 3, 1ull); }            // no bound (fewer than k seeds in sight): every column would pass
-        if (!(hf < 1e37) || !(M < 1e37)) { half = -1.f; flag = 1; if (p.dbg) atomicAdd(p.dbg + 4, 1ull); }        // non-finite inputs: the exact walk decides
+        if ((p.gtau[x] >> 30) == 0u) { half = -1.f; *p.gate = 1; if (p.dbg) atomicAdd(p.dbg + 3, 1ull); }            // no bound (fewer than k seeds in sight): every column would pass
+        if (!(hf < 1e37) || !(M < 1e37)) { half = -1.f; *p.gate = 1; if (p.dbg) atomicAdd(p.dbg + 4, 1ull); }        // non-finite inputs
         if (s == 0.f) { half = -1.f; flag = 1; if (p.dbg) atomicAdd(p.dbg + 5, 1ull); }                           // a zero target: Dm does not depend on the embeddings -- the exact walk is cheap
     }
     p.rowk[x] = f32x4{half, rho, s, eps};
@@ -264,10 +282,13 @@ struct MineScan {
     const mbf16x8* ufrag;
     const f32x4* rowk;
     int64_t Xq;
-    unsigned long long* plist;       // [nchunk][Xq][2][MBF_CAPL]: {acc bits << 32 | column}
-    uint32_t* pcnt;                  // [nchunk][Xq][2]
-    int32_t* rowflag;
-    unsigned long long* dbg;         // lab: [6] += entries of overflowing lane lists, [7] = max half (bits) of overflowing rows
+    uint32_t* plist;                 // [nchunk][Xq][2 MBF_CAPL]: columns
+    uint32_t* pcnt;                  // [nchunk][Xq]
+    uint32_t* spill;                 // [Xq][MBF_SPILL]: a user's hits beyond its lists
+    int32_t* spill_cnt;              // [Xq], zeroed by the host
+    int32_t* gate;                   // set when a spill list overflows too
+    unsigned long long* dbg;         // lab: [6] += entries spilled, [7] = max half (bits) of spilling rows
+    int abl;                         // lab (MF_MBF_ABL, -DMF_BF3_LAB builds): 1 = hits are not stored, 2 = no compares, 4 = no MFMAs, 8 = no barriers -- wrong results, timing only
 };
 template <int D>
 struct MineLds {
@@ -282,7 +303,9 @@ struct MineLds {
     static constexpr int NS = 2 * MBF_BLOCK;
     static constexpr int RING = NS * TILEB;
     static constexpr int DUMP0 = RING;
-    static constexpr int BYTES = RING + 1024;
+    static constexpr int HB0 = RING + 1024;                   // per wave: MBF_HCAP hit words, then 64 list cursors
+    static constexpr int HBW = MBF_HCAP * 4 + 64 * 4;
+    static constexpr int BYTES = HB0 + MBF_WAVES * HBW;
 };
 
 template <int D>
@@ -343,8 +366,12 @@ __global__ __launch_bounds__(64 * MBF_WAVES, 2) void mine_scan_kernel(MineScan p
 
     mbf16x8 ubh[MBF_XT][KS], ubl[MBF_XT][KS], uaug[MBF_XT];
     float half[MBF_XT];
-    unsigned long long* list[MBF_XT];
-    int cnt[MBF_XT];
+    // Hits go to a per-wave buffer in LDS ({lane, user tile} << 24 | column: N < 2^24), appended behind a wave-uniform cursor; the
+    // wave deals them to its users' lists after the loop.  (Round 4, first version: one global store per hit from inside the loop --
+    // stores share vmcnt with the tile DMA, so every meeting point also waited for the last store's acknowledgement: 117 us
+    // with them, 79 without.)
+    uint32_t* hbuf = reinterpret_cast<uint32_t*>(smem + L::HB0 + wave * L::HBW);
+    int hn = 0;
 #pragma unroll
     for (int xt = 0; xt < MBF_XT; ++xt) {
         const int64_t x = x0 + 32 * xt + c;
@@ -359,14 +386,15 @@ __global__ __launch_bounds__(64 * MBF_WAVES, 2) void mine_scan_kernel(MineScan p
         typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
         const u16x8 a = h == 0 ? u16x8{ms, ms, ms, one, one, one, r3[0], r3[1]} : u16x8{r3[2], 0, 0, 0, 0, 0, 0, 0};
         uaug[xt] = __builtin_bit_cast(mbf16x8, a);
-        list[xt] = p.plist + (((int64_t)chunk * p.Xq + x) * 2 + h) * MBF_CAPL;
-        cnt[xt] = 0;
     }
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     for (int v = 0; v < nv; ++v) {
         if ((v & (MBF_BLOCK - 1)) == 0) {
             mf_wait_vmcnt<0>();
+#ifdef MF_BF3_LAB
+            if (!(p.abl & 8))
+#endif
             mf_block_barrier();
             if (v + MBF_BLOCK < nv) {
 #pragma unroll
@@ -387,6 +415,9 @@ __global__ __launch_bounds__(64 * MBF_WAVES, 2) void mine_scan_kernel(MineScan p
 #pragma unroll
         for (int xt = 0; xt < MBF_XT; ++xt) {
             f32x16 acc = zero16;
+#ifdef MF_BF3_LAB
+            if (!(p.abl & 4))
+#endif
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[s], ubh[xt][s], acc, 0, 0, 0);
@@ -402,28 +433,63 @@ __global__ __launch_bounds__(64 * MBF_WAVES, 2) void mine_scan_kernel(MineScan p
                 m[e] = __ballot(fabsf(acc[e]) <= half[xt]);
                 any |= m[e];
             }
+#ifdef MF_BF3_LAB
+            if (p.abl & 2) { any = 0ull; asm volatile("" :: "v"(acc)); }
+            if (p.abl & 1) any = 0ull;
+#endif
             if (any) {
+                // (the masks are laundered through the scalar file so that the skips stay SCALAR branches on "some lane hit":
+                // left to itself the compiler re-derives each mask from its compare and emits two vector-side branches per element)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    if (m[e]) {
-                        if (fabsf(acc[e]) <= half[xt]) {
-                            if (cnt[xt] < MBF_CAPL)
-                                mf_cand_store(list[xt] + cnt[xt], col0 + (unsigned)((e & 3) + 8 * (e >> 2)), __builtin_bit_cast(unsigned, acc[e]));
-                            ++cnt[xt];
+                for (int q = 0; q < 4; ++q) {
+                    unsigned long long gq = m[4 * q] | m[4 * q + 1] | m[4 * q + 2] | m[4 * q + 3];
+                    asm volatile("" : "+s"(gq));
+                    if (gq) {
+#pragma unroll
+                        for (int e = 4 * q; e < 4 * q + 4; ++e) {
+                            unsigned long long me = m[e];
+                            asm volatile("" : "+s"(me));
+                            if (me) {
+                                const int pos = hn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(me >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)me, 0u));
+                                if (fabsf(acc[e]) <= half[xt] && pos < MBF_HCAP) {
+                                    const unsigned colv = col0 + (unsigned)((e & 3) + 8 * (e >> 2));
+                                    asm volatile("ds_write_b32 %0, %1" ::"v"(mf_lds_addr(hbuf + pos)), "v"(colv | ((unsigned)(lane | (xt << 6)) << 24)) : "memory");
+                                }
+                                hn += __popcll(me);
+                            }
                         }
                     }
                 }
             }
         }
     }
-#pragma unroll
-    for (int xt = 0; xt < MBF_XT; ++xt) {
-        const int64_t x = x0 + 32 * xt + c;
-        p.pcnt[((int64_t)chunk * p.Xq + x) * 2 + h] = (uint32_t)min(cnt[xt], MBF_CAPL);
-        if (cnt[xt] > MBF_CAPL) {
-            p.rowflag[x] = 1;
-            if (p.dbg) { atomicAdd(p.dbg + 6, (unsigned long long)cnt[xt]); atomicMax(p.dbg + 7, (unsigned long long)__builtin_bit_cast(unsigned, half[xt])); }
+    // deal the buffered hits to the users' lists of this chunk: a user belongs to this wave alone, so the list cursors are LDS
+    // counters (one returning LDS atomic per hit), and the lengths go out as plain stores -- nothing to clear between batches
+    {
+        uint32_t* cur = hbuf + MBF_HCAP;
+        asm volatile("ds_write_b32 %0, %1" ::"v"(mf_lds_addr(cur + lane)), "v"(0u) : "memory");
+        mf_wave_sync();
+        if (hn > MBF_HCAP) { *p.gate = 1; hn = MBF_HCAP; }
+        for (int i0 = 0; i0 < hn; i0 += 64) {
+            if (i0 + lane < hn) {
+                const uint32_t ent = hbuf[i0 + lane];
+                const int who = (int)(ent >> 24);                                  // lane | user tile << 6
+                const int ul = (who & 31) + 32 * (who >> 6);                       // the user among the wave's 64
+                const uint32_t colv = ent & 0xFFFFFFu;
+                const int at = (int)atomicAdd(cur + ul, 1u);
+                const int64_t xr = x0 + ul;
+                if (at < 2 * MBF_CAPL) {
+                    p.plist[((int64_t)chunk * p.Xq + xr) * (2 * MBF_CAPL) + at] = colv;
+                } else {                                                           // (rare: the user's spill list, behind a global cursor)
+                    const int sa = atomicAdd(p.spill_cnt + xr, 1);
+                    if (sa < MBF_SPILL) p.spill[xr * MBF_SPILL + sa] = colv;
+                    else *p.gate = 1;
+                    if (p.dbg) { atomicAdd(p.dbg + 6, 1ull); atomicMax(p.dbg + 7, (unsigned long long)hn); }
+                }
+            }
         }
+        mf_wave_sync();
+        p.pcnt[(int64_t)chunk * p.Xq + x0 + lane] = min(cur[lane], (uint32_t)(2 * MBF_CAPL));
     }
 }
 
@@ -434,24 +500,30 @@ struct MineRescore {
     int64_t B, Bp, N, Xq;
     float sigma;
     int nlists, k;
-    const unsigned long long* plist;
+    const uint32_t* plist;
     const uint32_t* pcnt;
     const int32_t* rowflag;
-    const int32_t *rep, *ncopy, *lastcopy;
+    const uint32_t* spill;
+    const int32_t* spill_cnt;
+    const int32_t* gate;
+    const int32_t* rep;
+    const unsigned long long* copybits;
+    const int32_t* lastcopy;
+    int blk;
     unsigned long long* cand;
     int32_t* cand_cnt;
     int rowcap;
     unsigned long long* dbg;         // lab: [0] += candidates rescored, [1] += rows, [2] += rows walked exactly (NULL: off)
 };
-static constexpr int MBF_RW = 4;                         // users (waves) per rescoring workgroup
 template <int D>
 struct MineRescoreGeom {
     static constexpr int CPR = D / 4;                   // 16-byte chunks of an fp32 row
     static constexpr int RPI = 64 / CPR;                // rows per DMA instruction
-    static constexpr int RB = 64;                       // candidates per round
+    static constexpr int RB = 32;                       // candidates per round (a user has ~20)
     static constexpr int NI = RB / RPI;
-    static constexpr int LMAX = MBF_MAXLISTS * MBF_CAPL;
-    static constexpr int PER_WAVE = RB * D * 4 + LMAX * 8 + 2 * 64 * 8 + D * 4;      // rows | keys | win, sorted | the user's row
+    static constexpr int LMAX = MBF_MAXLISTS * MBF_CAPL + MBF_SPILL;
+    static constexpr int KEYS = LMAX + 8;                // (+ the stand-in of a masked diagonal)
+    static constexpr int BYTES = RB * D * 4 + KEYS * 8 + 2 * 64 * 8 + D * 4;      // rows | keys | win, sorted | the user's row
 };
 
 // the exact key of (user, column) from the chain product -- MiningPolicy::key, word for word
@@ -459,121 +531,158 @@ __device__ __forceinline__ unsigned long long mine_exact_key(float nu, float nvj
     const float Lg = mf_logit(nu, nvj, dot, s, sigma, -lqnj);
     return mf_key_mining(Lg - lii, col);
 }
-template <int D>
-__device__ __forceinline__ float mine_chain_global(const float* xq, const float* __restrict__ row) {
-    constexpr int BL = D < 128 ? D : 128;
-    float acc = 0.f;
-#pragma unroll
-    for (int g0 = 0; g0 < D; g0 += BL) {
-        f32x4 y[BL / 4];
-#pragma unroll
-        for (int j = 0; j < BL / 4; ++j) y[j] = *reinterpret_cast<const f32x4*>(row + g0 + 4 * j);
-#pragma unroll
-        for (int g = 0; g < BL; g += 8)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc = __builtin_fmaf(xq[g0 + g + t], y[g / 4][t], acc);
-                acc = __builtin_fmaf(xq[g0 + g + 4 + t], y[g / 4 + 1][t], acc);
-            }
-    }
-    return acc;
+__device__ __forceinline__ unsigned long long mine_shfl_u64(unsigned long long v, int src) {
+    return ((unsigned long long)(unsigned)__shfl((int)(v >> 32), src, 64) << 32) | (unsigned long long)(unsigned)__shfl((int)(unsigned)v, src, 64);
 }
-// The copies of representative column f behind column `from`, in column order, by the whole wave: emit(col) for each one that
-// is a valid negative of user x, until `want` were emitted or the `left` copies behind `from` are all seen.  Returns the number emitted.
+// The copies of representative column f behind column `from`, in column order, by the whole wave: emit(col, i) for the i-th
+// one that is a valid negative of user x (a copy shares its representative's item id, hence its hits: only the user's own
+// diagonal can differ), i < want.  `bits`: copybits[f].  Returns min(number of valid copies behind `from`, want).
 template <class Emit>
-__device__ __forceinline__ int mine_copies(const MineRescore& p, int64_t x, unsigned f, unsigned from, int left, int want, Emit emit) {
+__device__ __forceinline__ int mine_copies(const MineRescore& p, int64_t x, unsigned f, unsigned from, unsigned long long bits, int want, Emit emit) {
     const int lane = mf_lane();
+    const unsigned long long below = (1ull << lane) - 1ull;
     int got = 0;
-    for (int64_t base = (int64_t)(from + 1) & ~63ll; base < p.N && left > 0 && got < want; base += 256) {
-        unsigned long long hit[4];
+    bits &= ~0ull << (from / (unsigned)p.blk);               // blocks from `from`'s on
+    while (bits && got < want) {
+        const int b = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        for (int64_t base = (int64_t)b * p.blk; base < (int64_t)(b + 1) * p.blk && base < p.N && got < want; base += 256) {
+            const int64_t c0 = base + 4 * lane;
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            i32x4 rv = {-1, -1, -1, -1};
+            if (c0 < (p.N + 31) / 32 * 32) rv = *reinterpret_cast<const i32x4*>(p.rep + c0);      // (rep[] covers the padded last tile)
+            unsigned mm = 0u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t col = base + 64 * j + lane;
-            hit[j] = __ballot(col < p.N && col > (int64_t)from && (unsigned)p.rep[col] == f);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned long long m = hit[j];
-            while (m && got < want) {
-                const int b = __builtin_ctzll(m);
-                m &= m - 1;
-                --left;
-                const unsigned col = (unsigned)(base + 64 * j + b);
-                if (!((p.maskW[(int64_t)(col >> 5) * p.Bp + x] >> (col & 31)) & 1u)) { emit(col, got); ++got; }     // (the user's own diagonal may be a copy)
+            for (int q = 0; q < 4; ++q) {
+                const int64_t col = c0 + q;
+                if (col < p.N && col > (int64_t)from && (unsigned)rv[q] == f && col != x) mm |= 1u << q;
             }
+            int pre = 0, tot = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned long long bal = __ballot((mm >> q) & 1u);
+                pre += __popcll(bal & below);
+                tot += __popcll(bal);
+            }
+            int i = got + pre;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((mm >> q) & 1u) {
+                    if (i < want) emit((unsigned)(c0 + q), i);
+                    ++i;
+                }
+            got = min(want, got + tot);
         }
     }
     return got;
 }
 
+// One wave (= one workgroup) per user.
 template <int D>
-__global__ __launch_bounds__(64 * MBF_RW) void mine_rescore_kernel(MineRescore p) {
+__global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
     using G = MineRescoreGeom<D>;
     extern __shared__ __attribute__((aligned(1024))) char fsm[];
-    const int lane = mf_lane(), wave = mf_wave_id();
-    char* mine_ = fsm + wave * G::PER_WAVE;
-    float* rows_lds = reinterpret_cast<float*>(mine_);
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(mine_ + G::RB * D * 4);      // columns first, their keys later
-    unsigned long long* win = keys + G::LMAX;
+    const int lane = mf_lane();
+    float* rows_lds = reinterpret_cast<float*>(fsm);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(fsm + G::RB * D * 4);      // columns first, their keys later
+    unsigned long long* win = keys + G::KEYS;
     unsigned long long* sorted = win + 64;
     float* xq = reinterpret_cast<float*>(sorted + 64);
-    const int64_t x = (int64_t)blockIdx.x * MBF_RW + wave;
-    if (x >= p.B) return;                                   // (the waves never meet)
+    const int64_t x = blockIdx.x;
+    if (x >= p.B) return;
+    if (__hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {      // the fp32 search behind this kernel fills the lists
+        if (lane == 0) p.cand_cnt[x] = 0;
+        return;
+    }
     const unsigned long long below = (1ull << lane) - 1ull;
+    // round trip 1: the user's scalars and row, the lengths of its lists (lane l owns list l = 2 chunk + lane half)
     const float nu = p.nu[x], lii = p.lii[x], s = p.sgn[x];
     const int flag = p.rowflag[x];
+    // (a user's list of chunk c is taken by lanes 2 c and 2 c + 1, sixteen entries each)
+    const int64_t lbase = ((int64_t)(lane >> 1) * p.Xq + x) * 2 + (lane & 1);
+    int nl = (lane < p.nlists && !flag) ? (int)p.pcnt[(int64_t)(lane >> 1) * p.Xq + x] - MBF_CAPL * (lane & 1) : 0;
+    nl = nl < 0 ? 0 : (nl > MBF_CAPL ? MBF_CAPL : nl);
+    float xv[(D + 63) / 64];
+#pragma unroll
+    for (int j = 0; j < (D + 63) / 64; ++j) xv[j] = lane + 64 * j < D ? p.u[x * D + lane + 64 * j] : 0.f;
 #pragma unroll
     for (int j = 0; j < (D + 63) / 64; ++j)
-        if (lane + 64 * j < D) xq[lane + 64 * j] = p.u[x * D + lane + 64 * j];
+        if (lane + 64 * j < D) xq[lane + 64 * j] = xv[j];
     unsigned long long* out = p.cand + x * (int64_t)p.rowcap;
     int n_out = 0;
     if (!flag) {
-        // the lists: lane l owns list l = 2 chunk + lane half
-        const int nl = lane < p.nlists ? (int)p.pcnt[((int64_t)(lane >> 1) * p.Xq + x) * 2 + (lane & 1)] : 0;
-        const unsigned long long* src = p.plist + (((int64_t)(lane >> 1) * p.Xq + x) * 2 + (lane & 1)) * MBF_CAPL;
-        int n = 0;
-        for (int t = 0; __any(t < nl); ++t) {
-            bool keep = false, orph = false;
-            unsigned col = 0u;
-            if (t < nl) {
-                col = (unsigned)src[t];
-                if ((int64_t)col < p.N) {
-                    keep = !((p.maskW[(int64_t)(col >> 5) * p.Bp + x] >> (col & 31)) & 1u);    // hit, diagonal, padding
-                    // A masked representative with copies.  Masked through its item id: every copy is.  Masked only as this user's
-                    // own diagonal (a positive that is not on the user's list): its copies are valid negatives -- the last one
-                    // tells which -- and the first valid one stands in for it.
-                    if (!keep && (int64_t)col == x && p.ncopy[col] > 0) {
-                        const unsigned lc = (unsigned)p.lastcopy[col];
-                        orph = !((p.maskW[(int64_t)(lc >> 5) * p.Bp + x] >> (lc & 31)) & 1u);
-                    }
-                }
+        // round trip 2: every list whole (a lane's 16 entries = 64 bytes), all loads in flight; 3: their mask words
+        unsigned col[MBF_CAPL];
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(p.plist + lbase * MBF_CAPL);
+#pragma unroll
+            for (int j = 0; j < MBF_CAPL / 4; ++j) {
+                uint4 e = {0u, 0u, 0u, 0u};
+                if (4 * j < nl) e = src[j];
+                col[4 * j] = e.x; col[4 * j + 1] = e.y; col[4 * j + 2] = e.z; col[4 * j + 3] = e.w;
             }
-            const unsigned long long bal = __ballot(keep);
-            if (keep) keys[n + __popcll(bal & below)] = (unsigned long long)col;
-            n += __popcll(bal);
-            const unsigned long long ob = __ballot(orph);
-            if (ob) {                                        // (at most one lane: the diagonal is one column)
-                const unsigned fc = (unsigned)__shfl((int)col, __builtin_ctzll(ob), 64);
-                n += mine_copies(p, x, fc, fc, p.ncopy[fc], 1, [&](unsigned cc, int) { if (lane == 0) keys[n] = (unsigned long long)cc; });
+        }
+        uint32_t mw[MBF_CAPL];
+#pragma unroll
+        for (int j = 0; j < MBF_CAPL; ++j) mw[j] = (j < nl && (int64_t)col[j] < p.N) ? p.maskW[(int64_t)(col[j] >> 5) * p.Bp + x] : ~0u;
+        int n = 0;
+        bool orph_any = false;
+        unsigned orph_col = 0u;
+#pragma unroll
+        for (int j = 0; j < MBF_CAPL; ++j) {
+            if (__any(j < nl)) {                             // (wave-uniform)
+                const bool keep = j < nl && !((mw[j] >> (col[j] & 31)) & 1u);      // not a hit, the diagonal or padding
+                const unsigned long long bal = __ballot(keep);
+                if (keep) keys[n + __popcll(bal & below)] = (unsigned long long)col[j];
+                n += __popcll(bal);
+                if (j < nl && (int64_t)col[j] == x) { orph_any = true; orph_col = col[j]; }
+            }
+        }
+        {   // the spill list (almost always empty)
+            const int ns = min(p.spill_cnt[x], MBF_SPILL);
+            for (int i0 = 0; i0 < ns; i0 += 64) {
+                const bool in = i0 + lane < ns;
+                const unsigned cs = in ? p.spill[x * MBF_SPILL + i0 + lane] : 0u;
+                const bool keep = in && (int64_t)cs < p.N && !((p.maskW[(int64_t)(cs >> 5) * p.Bp + x] >> (cs & 31)) & 1u);
+                const unsigned long long bal = __ballot(keep);
+                if (keep) keys[n + __popcll(bal & below)] = (unsigned long long)cs;
+                n += __popcll(bal);
+                if (in && (int64_t)cs == x) { orph_any = true; orph_col = cs; }
+            }
+        }
+        // The user's own diagonal passed the scan (Dm = 0 is in every semi-hard interval).  If it is a representative with copies
+        // and masked ONLY as the diagonal (a positive that is not on the user's list: its last copy, which shares the item
+        // id, is not masked), the copies are valid negatives and the first of them stands in for it.
+        {
+            const unsigned long long ob = __ballot(orph_any);
+            if (ob) {
+                const unsigned fc = (unsigned)__shfl((int)orph_col, __builtin_ctzll(ob), 64);
+                const unsigned long long bits = p.copybits[fc];
+                if (bits) {
+                    const unsigned lc = (unsigned)p.lastcopy[fc];
+                    if (!((p.maskW[(int64_t)(lc >> 5) * p.Bp + x] >> (lc & 31)) & 1u))
+                        n += mine_copies(p, x, fc, fc, bits, 1, [&](unsigned cc, int) { keys[n] = (unsigned long long)cc; });
+                }
             }
         }
         mf_row_topk_sync<true>();
         if (p.dbg && lane == 0) { atomicAdd(p.dbg, (unsigned long long)n); atomicAdd(p.dbg + 1, 1ull); }
         const int pz = lane % G::CPR, sub = lane / G::CPR;
-        const float* row_l = rows_lds + lane * D;
-        const int sw = lane & 15;
+        const int sl = lane & (G::RB - 1);
+        const float* row_l = rows_lds + sl * D;
+        const int sw = sl & 15;
         for (int base = 0; base < n; base += G::RB) {
             const int nr = min(G::RB, n - base);
             const bool have = lane < nr;
-            const unsigned col = have ? (unsigned)keys[base + lane] : 0u;
+            const unsigned cj = have ? (unsigned)keys[base + lane] : 0u;
             __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the columns have arrived
 #pragma unroll
             for (int t = 0; t < G::NI; ++t) {
                 if (t * G::RPI < nr) {                       // (wave-uniform)
-                    unsigned rr = (unsigned)__builtin_amdgcn_readlane((int)col, G::RPI * t);
+                    unsigned rr = (unsigned)__builtin_amdgcn_readlane((int)cj, G::RPI * t);
 #pragma unroll
                     for (int j = 1; j < G::RPI; ++j) {
-                        const unsigned rj = (unsigned)__builtin_amdgcn_readlane((int)col, G::RPI * t + j);
+                        const unsigned rj = (unsigned)__builtin_amdgcn_readlane((int)cj, G::RPI * t + j);
                         rr = sub == j ? rj : rr;
                     }
                     const int ch = pz ^ ((G::RPI * t + sub) & 15);
@@ -581,7 +690,7 @@ __global__ __launch_bounds__(64 * MBF_RW) void mine_rescore_kernel(MineRescore p
                     __builtin_amdgcn_global_load_lds((mf_glb_ptr)srcp, (mf_lds_ptr)(rows_lds + t * 256), 16, 0, 0);
                 }
             }
-            const float nvj = have ? p.nv[col] : 0.f, lqj = have ? p.lqn[col] : 0.f;
+            const float nvj = have ? p.nv[cj] : 0.f, lqj = have ? p.lqn[cj] : 0.f;
             __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
             asm volatile("" ::: "memory");
             float acc = 0.f;
@@ -596,7 +705,7 @@ __global__ __launch_bounds__(64 * MBF_RW) void mine_rescore_kernel(MineRescore p
                     acc = __builtin_fmaf(xb[t], b[t], acc);
                 }
             }
-            if (have) keys[base + lane] = mine_exact_key(nu, nvj, acc, s, p.sigma, lqj, lii, col);
+            if (have) keys[base + lane] = mine_exact_key(nu, nvj, acc, s, p.sigma, lqj, lii, cj);
             mf_row_topk_sync<true>();                        // the rows are consumed before the next round's DMA lands
         }
         // the k best representatives; then, behind each winner that has copies, the copies a cut at k could still reach
@@ -604,33 +713,37 @@ __global__ __launch_bounds__(64 * MBF_RW) void mine_rescore_kernel(MineRescore p
         if (n <= 64) m = mf_row_topk<1, true>(keys, n, p.k, win, sorted);
         else if (n <= 256) m = mf_row_topk<4, true>(keys, n, p.k, win, sorted);
         else m = mf_row_topk<G::LMAX / 64, true>(keys, n, p.k, win, sorted);
-        if (lane < m && lane < p.rowcap) out[lane] = sorted[lane];
+        unsigned long long kt_l = 0ull, bits_l = 0ull;
+        unsigned fr_l = 0u;
+        if (lane < m) {
+            kt_l = sorted[lane];
+            if (lane < p.rowcap) out[lane] = kt_l;
+            fr_l = (unsigned)p.rep[mf_key_mining_col(kt_l)];  // (the column itself, or -- a stand-in for a masked diagonal -- its representative)
+            bits_l = p.copybits[fr_l];
+        }
         n_out = m;
-        for (int t = 0; t < m; ++t) {
-            const unsigned long long kt = sorted[t];
-            const unsigned cf = mf_key_mining_col(kt);
-            const unsigned fr = (unsigned)p.rep[cf];         // (cf itself, or -- a stand-in for a masked diagonal -- its representative)
-            const int nc = p.ncopy[fr];
-            const int want = p.k - 1 - t;                    // a copy of the winner at position t sits at position t + 1 or later
-            if (nc > 0 && want > 0) {
-                const int at = n_out;
-                n_out += mine_copies(p, x, fr, cf, nc, want, [&](unsigned cc, int i) {
-                    if (lane == 0 && at + i < p.rowcap) out[at + i] = (kt & ~0x3FFFFFFFull) | (unsigned long long)(0x3FFFFFFFu - cc);
-                });
-            }
+        unsigned long long todo = __ballot(bits_l != 0ull && lane < p.k - 1);      // a copy of the winner at position t sits at t + 1 or later
+        while (todo) {
+            const int t = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const unsigned long long kt = mine_shfl_u64(kt_l, t), bits = mine_shfl_u64(bits_l, t);
+            const unsigned fr = (unsigned)__shfl((int)fr_l, t, 64);
+            const int at = n_out;
+            n_out += mine_copies(p, x, fr, mf_key_mining_col(kt), bits, p.k - 1 - t, [&](unsigned cc, int i) {
+                if (at + i < p.rowcap) out[at + i] = (kt & ~0x3FFFFFFFull) | (unsigned long long)(0x3FFFFFFFu - cc);
+            });
         }
         n_out = min(n_out, p.rowcap);
     } else {
-        // the whole row by the exact formulas, 64 columns a round; the k best keys so far ride along in win[]
+        // a zero target: the whole row by the exact formulas (no product needed), 64 columns a round; the k best keys so far ride along in win[]
         if (p.dbg && lane == 0) atomicAdd(p.dbg + 2, 1ull);
         mf_row_topk_sync<true>();
         int carry = 0;
         for (int64_t base = 0; base < p.N; base += 64) {
-            const int64_t col = base + lane;
+            const int64_t cj = base + lane;
             unsigned long long v0 = 0ull;
-            if (col < p.N && !((p.maskW[(col >> 5) * p.Bp + x] >> (col & 31)) & 1u)) {
-                const float dot = s == 0.f ? 0.f : mine_chain_global<D>(xq, p.v + col * D);      // (s = 0: fma(0, dot, c) = c)
-                v0 = mine_exact_key(nu, p.nv[col], dot, s, p.sigma, p.lqn[col], lii, (unsigned)col);
+            if (cj < p.N && !((p.maskW[(cj >> 5) * p.Bp + x] >> (cj & 31)) & 1u)) {
+                v0 = mine_exact_key(nu, p.nv[cj], 0.f, s, p.sigma, p.lqn[cj], lii, (unsigned)cj);      // (s = 0: fma(0, dot, c) = c for every finite dot)
             }
             const unsigned long long v1 = lane < carry ? win[lane] : 0ull;
             mf_row_topk_sync<true>();

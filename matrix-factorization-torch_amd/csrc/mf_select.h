@@ -57,6 +57,7 @@ struct SelectCommon {
     unsigned long long* cand;   // [Xp][rowcap]: every X row's surviving keys of ALL chunks, contiguous
     int32_t* cand_cnt;          // [Xp], zeroed by the host: fill count of the row's list (atomic cursor)
     int rowcap;                 // nsets * 2 CAPH
+    const int32_t* gate;        // not NULL: the launch does nothing unless *gate is set (mf_mine_bf.h: the fallback behind the prefilter)
     int tstride;                // seeding pass: virtual tile t of [t_begin, t_end) is real tile t * tstride (0 or 1: contiguous)
 };
 
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(64 * mf_nw(D), T >= 32 ? 1 : mf_wg_per_cu(D)) void 
     using L = SelectLds<D>;
     constexpr int NWAIT = G::PPW + Policy::AUX_DMA + 1;
     constexpr int CAPH = MF_SELECT_CAPH;
+    if (sc.gate && __hip_atomic_load(sc.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;      // (uniform: every wave of the grid leaves)
 
     const int lane = mf_lane(), c = lane & 31, h = lane >> 5;
     const int wave = mf_wave_id();
@@ -679,8 +681,8 @@ static void mf_select_seed_t(const typename Policy::Params& pp, const SelectComm
 // cand_cnt zeroed; `seeds`: [Xp][plan.seeds_per_row] scratch
 template <int D, class Policy>
 static void mf_select_run(const SelectPlan& plan, const typename Policy::Params& pp, SelectCommon sc,
-                          unsigned long long* seeds, int64_t nX, hipStream_t s, bool seed_only = false) {
-    if (plan.YTa > 0) {
+                          unsigned long long* seeds, int64_t nX, hipStream_t s, bool seed_only = false, bool main_only = false) {
+    if (plan.YTa > 0 && !main_only) {
         sc.t_begin = 0; sc.t_end = plan.YTa; sc.tiles_per_chunk = plan.tpcA;
         sc.tstride = MF_SEED_DIV;                       // tile t of the sample is tile MF_SEED_DIV t (YTa = YT / MF_SEED_DIV)
         switch (plan.T) {

@@ -28,21 +28,41 @@ dev = torch.device("cuda:0")
 batches, _ = bench.make_batches(8, 8192, seed=1000, device=dev)
 tr = bench.Trainer(mf, dev, "adam", 4, loss="PairwiseHingeLoss")
 import time
-for i in range(40):
+lib = mf._lib.lib()
+for mode in (1, 0, 1):
+    lib.mf_set_mining_prefilter(mode)
+    for i in range(60):
+        tr.step(batches[i % 8])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(200):
+        tr.step(batches[i % 8])
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"mined step, prefilter {'on ' if mode else 'off'}: {(t2 - t0) / 200 * 1e6:.1f} us wall clock (200 steps; the host was done after {(t1 - t0) / 200 * 1e6:.1f} us per step)", flush=True)
+import ctypes
+lib.mf_timing_reset()
+lib.mf_timing_enable(1)
+for i in range(100):
     tr.step(batches[i % 8])
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for i in range(80):
-    tr.step(batches[i % 8])
-torch.cuda.synchronize()
-print(f"mined step (wall clock, 80 steps): {(time.perf_counter() - t0) / 80 * 1e6:.1f} us", flush=True)
+lib.mf_timing_enable(0)
+for name in (b"mining_select", b"mining_items", b"mining_users", b"mining_scan", b"mining_rescore", b"update_rows", b"gather_rows"):
+    tot = ctypes.c_double(0.0)
+    n = lib.mf_timing_get(name, ctypes.byref(tot))
+    if n:
+        print(f"  span {name.decode():14s} {tot.value / n * 1e3:8.1f} us (HIP events, {n} spans)", flush=True)
 if os.environ.get("MF_MINE_DBG"):
     import ctypes
-    lib = mf._lib.lib()
     if hasattr(lib, "mf_probe_mining_prefilter"):
+        import struct
         buf = (ctypes.c_ulonglong * 8)()
-        lib.mf_probe_mining_prefilter(None, 1)
-        tr.step(batches[0])
-        torch.cuda.synchronize()
-        lib.mf_probe_mining_prefilter(buf, 0)
-        print(f"prefilter: {buf[0] / max(buf[1], 1):.1f} candidates rescored per user over {buf[1]} users, {buf[2]} users walked exactly (no bound {buf[3]}, non-finite {buf[4]}, zero target {buf[5]}; the rest: a list overflowed -- {buf[6]} entries in overflowing lane lists, largest half {__import__('struct').unpack('f', __import__('struct').pack('I', buf[7] & 0xFFFFFFFF))[0]:.4g})", flush=True)
+        for bi in range(8):
+            lib.mf_probe_mining_prefilter(None, 1)
+            tr.step(batches[bi])
+            torch.cuda.synchronize()
+            lib.mf_probe_mining_prefilter(buf, 0)
+            half = struct.unpack("f", struct.pack("I", buf[7] & 0xFFFFFFFF))[0]
+            print(f"batch {bi}: {buf[0] / max(buf[1], 1):.1f} candidates rescored per user over {buf[1]} users, {buf[2]} users walked exactly "
+                  f"(no bound {buf[3]}, non-finite {buf[4]}, zero target {buf[5]}; {buf[6]} entries in overflowing lane lists, largest half {half:.4g})", flush=True)
