@@ -1436,19 +1436,28 @@ static int loss_masks_impl(const char* what, int64_t B, int64_t N, int d, int nu
 // The candidate search of the mined losses through the split-bf16 prefilter: the fp32 seeding pass and its bound as before,
 // then item plane / user fragments + intervals / ONE scan on the bf16 cores / exact rescoring into the row lists.
 static unsigned long long* g_mine_dbg = nullptr;
+#ifdef MF_BF3_LAB          // per-kernel spans in lab builds; the product records ONE span over the whole search (spans do not nest)
+#define MBF_TIMED(name, s, ...) MF_TIMED(name, s, __VA_ARGS__)
+#else
+#define MBF_TIMED(name, s, ...) do { __VA_ARGS__; } while (0)
+#endif
 template <int D>
 static void mine_bf_launch(const LossWs& w, const float* u, const float* v, int64_t B, int64_t N, int k, float sigma, hipStream_t s) {
     const MineBfPlan& m = w.mbf;
+    int lab_abl = 0;
+#ifdef MF_BF3_LAB
+    if (const char* e = getenv("MF_MBF_ABL")) lab_abl = atoi(e);
+#endif
     {
         const int64_t threads = m.Nq * (D / 8);
-        MF_TIMED("mining_items", s, (mine_items_kernel<D><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(v, w.nv, w.logq, w.colfirst, N, m.Nq, sigma, w.mbf_plane, w.mbf_max,
-                                                                               w.mbf_rep, w.mbf_copybits, w.mbf_lastcopy, m.blk)));
+        MBF_TIMED("mining_items", s, (mine_items_kernel<D><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(v, w.nv, w.logq, w.colfirst, N, m.Nq, sigma, w.mbf_plane, w.mbf_max,
+                                                                               w.mbf_rep, w.mbf_copybits, w.mbf_lastcopy, m.blk, lab_abl)));
     }
     {
         MineUsers mu{u, w.nu, w.lii, w.sgn, w.gtau, w.mbf_max, B, m.Xq, sigma, static_cast<mbf16x8*>(w.mbf_ufrag),
                      static_cast<f32x4*>(w.mbf_rowk), w.mbf_flag, w.mbf_gate, g_mine_dbg};
         const int64_t threads = m.Xq * (D / 8);
-        MF_TIMED("mining_users", s, (mine_users_kernel<D, MiningPolicy><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(mu)));
+        MBF_TIMED("mining_users", s, (mine_users_kernel<D, MiningPolicy><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(mu)));
     }
     {
         MineScan ms{w.mbf_plane, m.Nq, m.NT, m.tpc, static_cast<const mbf16x8*>(w.mbf_ufrag), static_cast<const f32x4*>(w.mbf_rowk), m.Xq,
@@ -1460,7 +1469,7 @@ static void mine_bf_launch(const LossWs& w, const float* u, const float* v, int6
         const int bytes = MineLds<D>::BYTES;
         static bool attr = false;                            // (per instantiation)
         if (!attr) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); attr = true; }
-        MF_TIMED("mining_scan", s, (fn<<<dim3((unsigned)m.nchunk, (unsigned)m.gy), 64 * MBF_WAVES, bytes, s>>>(ms)));
+        MBF_TIMED("mining_scan", s, (fn<<<dim3((unsigned)m.nchunk, (unsigned)m.gy), 64 * MBF_WAVES, bytes, s>>>(ms)));
     }
     {
         MineRescore mr{u, v, w.nu, w.nv, w.lii, w.sgn, w.logq, w.maskW, B, w.Bp, N, m.Xq, sigma, m.nlists, k,
@@ -1470,12 +1479,18 @@ static void mine_bf_launch(const LossWs& w, const float* u, const float* v, int6
         const int bytes = MineRescoreGeom<D>::BYTES;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); attr = true; }
-        MF_TIMED("mining_rescore", s, (fn<<<dim3((unsigned)B), 64, bytes, s>>>(mr)));
+        MBF_TIMED("mining_rescore", s, (fn<<<dim3((unsigned)B), 64, bytes, s>>>(mr)));
     }
 }
 static int mine_bf_run(const LossWs& w, const MiningPolicy::Params& mp, const SelectCommon& sc, const float* u, const float* v, int64_t B,
                        int64_t N, int d, int k, float sigma, hipStream_t s) {
-    MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s, true))); });
+#ifdef MF_BF3_LAB
+    const bool whole = false;
+#else
+    const bool whole = mf_timing_on();
+#endif
+    if (whole) mf_timing_begin("mining_prefilter", s);
+    MF_DISPATCH_D(d, { MBF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s, true))); });
     if (d == 64) mine_bf_launch<64>(w, u, v, B, N, k, sigma, s);
     else mine_bf_launch<128>(w, u, v, B, N, k, sigma, s);
     // behind it, gated on the device: a batch the prefilter gave up on (a spill list overflowed -- thousands of exact ties --,
@@ -1483,6 +1498,7 @@ static int mine_bf_run(const LossWs& w, const MiningPolicy::Params& mp, const Se
     SelectCommon scg = sc;
     scg.gate = w.mbf_gate;
     MF_DISPATCH_D(d, { mf_select_run<D, MiningPolicy>(w.plan, mp, scg, w.seeds, B, s, false, true); });
+    if (whole) mf_timing_end("mining_prefilter", s);
     return MF_OK;
 }
 // tools/lab/mined_timeline.py: [0] candidates rescored, [1] users, [2] users walked exactly, since the last call

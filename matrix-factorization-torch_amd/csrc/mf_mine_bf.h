@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict
                                                          const float* __restrict__ lqn, const int32_t* __restrict__ colfirst,
                                                          int64_t N, int64_t Nq, float sigma, unsigned short* __restrict__ plane,
                                                          unsigned* __restrict__ maxima, int32_t* __restrict__ rep,
-                                                         unsigned long long* __restrict__ copybits, int32_t* __restrict__ lastcopy, int blk) {
+                                                         unsigned long long* __restrict__ copybits, int32_t* __restrict__ lastcopy, int blk, int abl) {
     constexpr int LPR = D / 8, RW = 2 * D + 16;
     const int lane = mf_lane();
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -173,7 +173,11 @@ __global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict
             *reinterpret_cast<u16x8*>(row + 2 * D) = a0;
             *reinterpret_cast<u16x8*>(row + 2 * D + 8) = a1;
             rep[r] = (int32_t)(dup ? f : r);
+#ifdef MF_BF3_LAB
+            if (dup && !(abl & 32)) {
+#else
             if (dup) {
+#endif
                 // (a popular item's copies all land on its representative's two words: look first -- after the first few, most
                 // find their bit set and a later copy recorded, and issue no atomic at all)
                 const unsigned long long bit = 1ull << (unsigned)(r / blk);
@@ -598,6 +602,7 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
     // round trip 1: the user's scalars and row, the lengths of its lists (lane l owns list l = 2 chunk + lane half)
     const float nu = p.nu[x], lii = p.lii[x], s = p.sgn[x];
     const int flag = p.rowflag[x];
+    const int nsp = min(p.spill_cnt[x], MBF_SPILL);
     // (a user's list of chunk c is taken by lanes 2 c and 2 c + 1, sixteen entries each)
     const int64_t lbase = ((int64_t)(lane >> 1) * p.Xq + x) * 2 + (lane & 1);
     int nl = (lane < p.nlists && !flag) ? (int)p.pcnt[(int64_t)(lane >> 1) * p.Xq + x] - MBF_CAPL * (lane & 1) : 0;
@@ -622,55 +627,36 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
                 col[4 * j] = e.x; col[4 * j + 1] = e.y; col[4 * j + 2] = e.z; col[4 * j + 3] = e.w;
             }
         }
-        uint32_t mw[MBF_CAPL];
-#pragma unroll
-        for (int j = 0; j < MBF_CAPL; ++j) mw[j] = (j < nl && (int64_t)col[j] < p.N) ? p.maskW[(int64_t)(col[j] >> 5) * p.Bp + x] : ~0u;
+        // every listed column into keys[] (positions from the list lengths alone: no memory round trip in between)
         int n = 0;
-        bool orph_any = false;
-        unsigned orph_col = 0u;
 #pragma unroll
         for (int j = 0; j < MBF_CAPL; ++j) {
             if (__any(j < nl)) {                             // (wave-uniform)
-                const bool keep = j < nl && !((mw[j] >> (col[j] & 31)) & 1u);      // not a hit, the diagonal or padding
-                const unsigned long long bal = __ballot(keep);
-                if (keep) keys[n + __popcll(bal & below)] = (unsigned long long)col[j];
+                const bool in = j < nl;
+                const unsigned long long bal = __ballot(in);
+                if (in) keys[n + __popcll(bal & below)] = (unsigned long long)col[j];
                 n += __popcll(bal);
-                if (j < nl && (int64_t)col[j] == x) { orph_any = true; orph_col = col[j]; }
             }
         }
         {   // the spill list (almost always empty)
-            const int ns = min(p.spill_cnt[x], MBF_SPILL);
-            for (int i0 = 0; i0 < ns; i0 += 64) {
-                const bool in = i0 + lane < ns;
+            for (int i0 = 0; i0 < nsp; i0 += 64) {
+                const bool in = i0 + lane < nsp;
                 const unsigned cs = in ? p.spill[x * MBF_SPILL + i0 + lane] : 0u;
-                const bool keep = in && (int64_t)cs < p.N && !((p.maskW[(int64_t)(cs >> 5) * p.Bp + x] >> (cs & 31)) & 1u);
-                const unsigned long long bal = __ballot(keep);
-                if (keep) keys[n + __popcll(bal & below)] = (unsigned long long)cs;
+                const unsigned long long bal = __ballot(in);
+                if (in) keys[n + __popcll(bal & below)] = (unsigned long long)cs;
                 n += __popcll(bal);
-                if (in && (int64_t)cs == x) { orph_any = true; orph_col = cs; }
-            }
-        }
-        // The user's own diagonal passed the scan (Dm = 0 is in every semi-hard interval).  If it is a representative with copies
-        // and masked ONLY as the diagonal (a positive that is not on the user's list: its last copy, which shares the item
-        // id, is not masked), the copies are valid negatives and the first of them stands in for it.
-        {
-            const unsigned long long ob = __ballot(orph_any);
-            if (ob) {
-                const unsigned fc = (unsigned)__shfl((int)orph_col, __builtin_ctzll(ob), 64);
-                const unsigned long long bits = p.copybits[fc];
-                if (bits) {
-                    const unsigned lc = (unsigned)p.lastcopy[fc];
-                    if (!((p.maskW[(int64_t)(lc >> 5) * p.Bp + x] >> (lc & 31)) & 1u))
-                        n += mine_copies(p, x, fc, fc, bits, 1, [&](unsigned cc, int) { keys[n] = (unsigned long long)cc; });
-                }
             }
         }
         mf_row_topk_sync<true>();
         if (p.dbg && lane == 0) { atomicAdd(p.dbg, (unsigned long long)n); atomicAdd(p.dbg + 1, 1ull); }
+        // round trip 3, per round of 32 columns, everything in flight together: the fp32 rows (LDS-DMA), and for the lane's own
+        // column its mask word, norm, logQ and copy bitmap.  A masked column (hit, diagonal, padding) gets key 0 = no key.
         const int pz = lane % G::CPR, sub = lane / G::CPR;
         const int sl = lane & (G::RB - 1);
         const float* row_l = rows_lds + sl * D;
         const int sw = sl & 15;
+        unsigned long long kdiag = 0ull, cbdiag = 0ull;       // the user's own diagonal, if it is listed: its key and copy bitmap
+        bool anycb = false;                                  // some valid column has copies (then the winners look theirs up again)
         for (int base = 0; base < n; base += G::RB) {
             const int nr = min(G::RB, n - base);
             const bool have = lane < nr;
@@ -685,12 +671,16 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
                         const unsigned rj = (unsigned)__builtin_amdgcn_readlane((int)cj, G::RPI * t + j);
                         rr = sub == j ? rj : rr;
                     }
+                    if ((int64_t)rr >= p.N) rr = 0u;         // (never listed; a guard for the address only)
                     const int ch = pz ^ ((G::RPI * t + sub) & 15);
                     const float* srcp = p.v + (int64_t)rr * D + 4 * ch;
                     __builtin_amdgcn_global_load_lds((mf_glb_ptr)srcp, (mf_lds_ptr)(rows_lds + t * 256), 16, 0, 0);
                 }
             }
-            const float nvj = have ? p.nv[cj] : 0.f, lqj = have ? p.lqn[cj] : 0.f;
+            const bool inr = have && (int64_t)cj < p.N;
+            const float nvj = inr ? p.nv[cj] : 0.f, lqj = inr ? p.lqn[cj] : 0.f;
+            const uint32_t mwj = inr ? p.maskW[(int64_t)(cj >> 5) * p.Bp + x] : ~0u;
+            const unsigned long long cbj = inr ? p.copybits[cj] : 0ull;
             __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
             asm volatile("" ::: "memory");
             float acc = 0.f;
@@ -705,8 +695,29 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
                     acc = __builtin_fmaf(xb[t], b[t], acc);
                 }
             }
-            if (have) keys[base + lane] = mine_exact_key(nu, nvj, acc, s, p.sigma, lqj, lii, cj);
+            const unsigned long long kj = mine_exact_key(nu, nvj, acc, s, p.sigma, lqj, lii, cj);
+            const bool valid = inr && !((mwj >> (cj & 31)) & 1u);
+            if (have) keys[base + lane] = valid ? kj : 0ull;
+            anycb = anycb || (valid && cbj != 0ull);
+            if (inr && (int64_t)cj == x && !valid && cbj != 0ull) { kdiag = kj; cbdiag = cbj; }
             mf_row_topk_sync<true>();                        // the rows are consumed before the next round's DMA lands
+        }
+        // The user's own diagonal passed the scan (Dm = 0 is in every semi-hard interval).  If it is a representative with copies
+        // and masked ONLY as the diagonal (a positive that is not on the user's list: its last copy, which shares the item id,
+        // is not masked), the copies are valid negatives and the first of them stands in for it -- same row, same Dm.
+        {
+            const unsigned long long ob = __ballot(kdiag != 0ull);
+            if (ob) {
+                const int src_l = __builtin_ctzll(ob);
+                const unsigned long long kd = mine_shfl_u64(kdiag, src_l), cbd = mine_shfl_u64(cbdiag, src_l);
+                const unsigned lc = (unsigned)p.lastcopy[x];
+                if (!((p.maskW[(int64_t)(lc >> 5) * p.Bp + x] >> (lc & 31)) & 1u))
+                    n += mine_copies(p, x, (unsigned)x, (unsigned)x, cbd, 1, [&](unsigned cc, int) {
+                        keys[n] = (kd & ~0x3FFFFFFFull) | (unsigned long long)(0x3FFFFFFFu - cc);
+                        anycb = true;
+                    });
+                mf_row_topk_sync<true>();
+            }
         }
         // the k best representatives; then, behind each winner that has copies, the copies a cut at k could still reach
         int m;
@@ -718,8 +729,14 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
         if (lane < m) {
             kt_l = sorted[lane];
             if (lane < p.rowcap) out[lane] = kt_l;
-            fr_l = (unsigned)p.rep[mf_key_mining_col(kt_l)];  // (the column itself, or -- a stand-in for a masked diagonal -- its representative)
-            bits_l = p.copybits[fr_l];
+        }
+        if (__any(anycb)) {                                  // (LDS is the limit of this kernel's occupancy: no table of bitmaps, one more L2 round trip here)
+            if (lane < m) {
+                const unsigned cw = mf_key_mining_col(kt_l);
+                fr_l = (unsigned)p.rep[cw];                  // (the column itself, or -- a stand-in -- its representative)
+                bits_l = p.copybits[cw];                     // (both loads in flight; a stand-in asks again)
+                if (fr_l != cw) bits_l = p.copybits[fr_l];
+            }
         }
         n_out = m;
         unsigned long long todo = __ballot(bits_l != 0ull && lane < p.k - 1);      // a copy of the winner at position t sits at t + 1 or later

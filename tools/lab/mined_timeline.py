@@ -48,7 +48,7 @@ for i in range(100):
     tr.step(batches[i % 8])
 torch.cuda.synchronize()
 lib.mf_timing_enable(0)
-for name in (b"mining_select", b"mining_items", b"mining_users", b"mining_scan", b"mining_rescore", b"update_rows", b"gather_rows"):
+for name in (b"mining_prefilter", b"mining_select", b"mining_items", b"mining_users", b"mining_scan", b"mining_rescore", b"update_rows", b"gather_rows"):
     tot = ctypes.c_double(0.0)
     n = lib.mf_timing_get(name, ctypes.byref(tot))
     if n:
