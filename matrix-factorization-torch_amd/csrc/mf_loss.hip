@@ -139,7 +139,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
         w.dvfix = a.take<long long>((size_t)w.N * d);
         w.gtau = a.take<unsigned>((size_t)w.Bp);
         w.cand_cnt = a.take<int32_t>((size_t)w.Bp);      // right behind gtau: one memset clears both
-        w.mbf_max = a.take<unsigned>(2 * MBF_MAXSLOTS);  // ... and these maxima
+        w.mbf_max = a.take<unsigned>(MBF_MAXSLOTS * MBF_MAXSTRIDE);  // ... and these maxima
         w.mbf = mine_bf_plan(B, N, d, k);
         if (w.mbf.ok) {
             w.mbf_copybits = a.take<unsigned long long>((size_t)w.mbf.Nq);        // (cleared with the maxima, and the next)
@@ -1451,7 +1451,7 @@ static void mine_bf_launch(const LossWs& w, const float* u, const float* v, int6
     {
         const int64_t threads = m.Nq * (D / 8);
         MBF_TIMED("mining_items", s, (mine_items_kernel<D><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(v, w.nv, w.logq, w.colfirst, N, m.Nq, sigma, w.mbf_plane, w.mbf_max,
-                                                                               w.mbf_rep, w.mbf_copybits, w.mbf_lastcopy, m.blk, lab_abl)));
+                                                                               w.mbf_rep, w.mbf_copybits, w.mbf_lastcopy, __builtin_ctz((unsigned)m.blk), lab_abl)));
     }
     {
         MineUsers mu{u, w.nu, w.lii, w.sgn, w.gtau, w.mbf_max, B, m.Xq, sigma, static_cast<mbf16x8*>(w.mbf_ufrag),
@@ -1602,7 +1602,7 @@ static int loss_fwd_impl(const char* what, int64_t B, int64_t N, int d, const Po
     } else if (scores_needed) {
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
         SelectCommon sc{u, B, v, N, 0, (int)((N + 31) / 32), w.plan.tpc, w.Bp, num_negatives, w.plan.xw, w.gtau, w.priv, w.cand, w.cand_cnt, w.plan.rowcap};
-        mf_zero_async(w.gtau, (size_t)((char*)(w.mbf.ok ? (void*)(w.mbf_gate + 4) : (void*)(w.mbf_max + 2 * MBF_MAXSLOTS)) - (char*)w.gtau), s);
+        mf_zero_async(w.gtau, (size_t)((char*)(w.mbf.ok ? (void*)(w.mbf_gate + 4) : (void*)(w.mbf_max + MBF_MAXSLOTS * MBF_MAXSTRIDE)) - (char*)w.gtau), s);
         if (w.mbf.ok && mine_bf_enabled() && w.plan.YTa > 0 && w.plan.rowcap >= num_negatives) {
             if (int rc2 = mine_bf_run(w, mp, sc, u, v, B, N, d, num_negatives, sigma, s)) return rc2;
         } else {

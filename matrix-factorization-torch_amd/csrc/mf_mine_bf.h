@@ -45,7 +45,8 @@ static constexpr int MBF_BLOCK = 2;                     // item tiles between tw
 static constexpr int MBF_CAPL = 16;                     // entries a rescoring lane takes: a user's list of one chunk holds 2 MBF_CAPL
 static constexpr int MBF_HCAP = 512;                    // hits a scan wave buffers in LDS per chunk (64 users; ~80 are usual)
 static constexpr int MBF_ROWS_WG = 32 * MBF_XT * MBF_WAVES;      // 512 users per workgroup
-static constexpr int MBF_MAXSLOTS = 64;                 // pairs of words the item kernel's waves spread their maxima over
+static constexpr int MBF_MAXSLOTS = 16;                 // pairs of words the item kernel's blocks spread their maxima over ...
+static constexpr int MBF_MAXSTRIDE = 32;                // ... one cache line apart (in words)
 static constexpr int MBF_SPILL = 128;                   // entries of a user's spill list: hits beyond a lane's 16 (more: the fp32 search answers the batch)
 static constexpr int MBF_MAXLISTS = 32;                 // lists per user the rescoring wave gathers (one per lane; 32 x 16 keys of LDS)
 
@@ -57,7 +58,7 @@ struct MineBfPlan {
     int nchunk, tpc;        // item chunks (grid.x) and tiles per chunk
     int nlists;             // 2 nchunk lists per user
     int rowb;               // bytes of an item's row in the plane: (2 d + 16) bf16
-    int blk;                // columns per bit of a representative's copy bitmap (64 bits span the batch; a multiple of 256)
+    int blk;                // columns per bit of a representative's copy bitmap (64 bits span the batch; a power of two >= 256)
 };
 static inline MineBfPlan mine_bf_plan(int64_t B, int64_t N, int d, int k) {
     MineBfPlan p{};
@@ -66,7 +67,8 @@ static inline MineBfPlan mine_bf_plan(int64_t B, int64_t N, int d, int k) {
     p.Xq = (B + MBF_ROWS_WG - 1) / MBF_ROWS_WG * MBF_ROWS_WG;
     p.gy = (int)(p.Xq / MBF_ROWS_WG);
     p.rowb = (2 * d + 16) * 2;
-    p.blk = (int)(((p.Nq + 63) / 64 + 255) / 256 * 256);
+    p.blk = 256;
+    while ((int64_t)p.blk * 64 < p.Nq) p.blk *= 2;
     int want = (256 + p.gy - 1) / p.gy;                  // one workgroup per CU
     if (want > MBF_MAXLISTS / 2) want = MBF_MAXLISTS / 2;
     if (want < 1) want = 1;
@@ -120,28 +122,37 @@ __global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict
                                                          const float* __restrict__ lqn, const int32_t* __restrict__ colfirst,
                                                          int64_t N, int64_t Nq, float sigma, unsigned short* __restrict__ plane,
                                                          unsigned* __restrict__ maxima, int32_t* __restrict__ rep,
-                                                         unsigned long long* __restrict__ copybits, int32_t* __restrict__ lastcopy, int blk, int abl) {
+                                                         unsigned long long* __restrict__ copybits, int32_t* __restrict__ lastcopy, int blk_shift, int abl) {
     constexpr int LPR = D / 8, RW = 2 * D + 16;
     const int lane = mf_lane();
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t r = t / LPR;
     const int c = (int)(t % LPR);
     const bool live = r < Nq;                                 // (whole groups: Nq LPR is a multiple of 64)
+    const bool real = live && r < N;
     typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // everything that depends on r alone is asked for at once: the row, its first column by item id, its norm and logQ
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    int64_t cf = r;
+    float nvr = 0.f, lqr = 0.f;
+    if (real) {
+        a = reinterpret_cast<const f32x4*>(v + r * D)[2 * c];
+        b = reinterpret_cast<const f32x4*>(v + r * D)[2 * c + 1];
+        if (colfirst) cf = (int64_t)colfirst[r];
+        if (c == 0) { nvr = nv[r]; lqr = lqn[r]; }
+    }
     u16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
     bool same = false;
     int64_t f = r;
-    if (live && r < N) {
-        const f32x4 a = reinterpret_cast<const f32x4*>(v + r * D)[2 * c], b = reinterpret_cast<const f32x4*>(v + r * D)[2 * c + 1];
+    if (real) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float x = i < 4 ? a[i] : b[i - 4];
             hi[i] = mbf_round(x);
             lo[i] = mbf_round(x - mbf_float(hi[i]));
         }
-        const int64_t cf = colfirst ? (int64_t)colfirst[r] : r;
         if (cf >= 0 && cf < r) {                              // an earlier column carries the same item id: the same row?
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 fa = reinterpret_cast<const u32x4*>(v + cf * D)[2 * c], fb = reinterpret_cast<const u32x4*>(v + cf * D)[2 * c + 1];
             const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
             same = ua[0] == fa[0] && ua[1] == fa[1] && ua[2] == fa[2] && ua[3] == fa[3] && ub[0] == fb[0] && ub[1] == fb[1] && ub[2] == fb[2] && ub[3] == fb[3];
@@ -157,16 +168,16 @@ __global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict
         *reinterpret_cast<u16x8*>(row + D + 8 * c) = lo;
         if (c == 0) {
             u16x8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
-            if (r < N && !dup) {
-                const float w = (0.5f * sigma) * nv[r], q = lqn[r];
+            if (real && !dup) {
+                const float w = (0.5f * sigma) * nvr;
                 unsigned short ws[3], qs[3];
                 mbf_split3(w, ws);
-                mbf_split3(q, qs);
+                mbf_split3(lqr, qs);
                 const unsigned short one = 0x3F80;
                 a0 = u16x8{ws[0], ws[1], ws[2], qs[0], qs[1], qs[2], one, one};
                 a1[0] = one;
-                mx_nv = nv[r];
-                mx_q = fabsf(q);
+                mx_nv = nvr;
+                mx_q = fabsf(lqr);
             } else {
                 a0[3] = 0x7E00;      // rows past N and copies: 2^125 in the first logQ slot -- their accumulators never pass |acc| <= half
             }
@@ -178,22 +189,25 @@ __global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict
 #else
             if (dup) {
 #endif
-                // (a popular item's copies all land on its representative's two words: look first -- after the first few, most
-                // find their bit set and a later copy recorded, and issue no atomic at all)
-                const unsigned long long bit = 1ull << (unsigned)(r / blk);
-                if (!(__hip_atomic_load(copybits + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(copybits + f, bit);
-                if (__hip_atomic_load(lastcopy + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int32_t)r) atomicMax(lastcopy + f, (int32_t)r);
+                // (fire and forget: a popular item's copies queue up at its representative's two words either way -- they all run at once)
+                atomicOr(copybits + f, 1ull << (unsigned)(r >> blk_shift));
+                atomicMax(lastcopy + f, (int32_t)r);
             }
         }
     }
-    // one atomic per wave and maximum (non-negative floats order like their bits; NaN ranks above everything: it reaches the bound)
+    // the block's maxima through LDS, then ONE pair of atomics per block, dealt over MBF_MAXSLOTS pairs of words a cache line
+    // apart (atomics on one line queue up at its L2 channel: 4096 waves on one pair of words were 95 of this kernel's 100 us;
+    // non-negative floats order like their bits, NaN above everything: it reaches the bound)
+    __shared__ unsigned blk_max[2][4];
     unsigned bn = __builtin_bit_cast(unsigned, mx_nv), bq = __builtin_bit_cast(unsigned, mx_q);
     bn = mf_wave_max_u32(bn);
     bq = mf_wave_max_u32(bq);
-    if (lane == 0) {         // (4096 waves at once: on ONE pair of words their atomics were 95 of this kernel's 100 us; 64 pairs, reduced by the reader)
-        const int slot = (int)((blockIdx.x * 4 + (threadIdx.x >> 6)) & (MBF_MAXSLOTS - 1));
-        atomicMax(maxima + 2 * slot, bn);
-        atomicMax(maxima + 2 * slot + 1, bq);
+    if (lane == 0) { blk_max[0][threadIdx.x >> 6] = bn; blk_max[1][threadIdx.x >> 6] = bq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int slot = (int)(blockIdx.x & (MBF_MAXSLOTS - 1)) * MBF_MAXSTRIDE;
+        atomicMax(maxima + slot, max(max(blk_max[0][0], blk_max[0][1]), max(blk_max[0][2], blk_max[0][3])));
+        atomicMax(maxima + slot + 1, max(max(blk_max[1][0], blk_max[1][1]), max(blk_max[1][2], blk_max[1][3])));
     }
 }
 
@@ -239,8 +253,8 @@ __global__ __launch_bounds__(256) void mine_users_kernel(MineUsers p) {
     if (j != 0) return;
     float nvmax_f = 0.f, qmax_f = 0.f;
     {
-        unsigned a = 0u, b = 0u;                             // (128 words, L2-resident; non-negative floats order like their bits, NaN above all)
-        for (int i = 0; i < MBF_MAXSLOTS; ++i) { a = max(a, p.maxima[2 * i]); b = max(b, p.maxima[2 * i + 1]); }
+        unsigned a = 0u, b = 0u;                             // (16 pairs, L2-resident; non-negative floats order like their bits, NaN above all)
+        for (int i = 0; i < MBF_MAXSLOTS; ++i) { a = max(a, p.maxima[MBF_MAXSTRIDE * i]); b = max(b, p.maxima[MBF_MAXSTRIDE * i + 1]); }
         nvmax_f = __builtin_bit_cast(float, a);
         qmax_f = __builtin_bit_cast(float, b);
     }
