@@ -306,7 +306,7 @@ struct MineScan {
     int32_t* spill_cnt;              // [Xq], zeroed by the host
     int32_t* gate;                   // set when a spill list overflows too
     unsigned long long* dbg;         // lab: [6] += entries spilled, [7] = max half (bits) of spilling rows
-    int abl;                         // lab (MF_MBF_ABL, -DMF_BF3_LAB builds): 1 = hits are not stored, 2 = no compares, 4 = no MFMAs, 8 = no barriers -- wrong results, timing only
+    int abl;                         // lab (MF_MBF_ABL, -DMF_BF3_LAB builds): 1 = hits are not stored, 2 = no compares, 4 = no MFMAs, 8 = no barriers, 64 = no LDS operand reads, 128 = no staging -- wrong results, timing only
 };
 template <int D>
 struct MineLds {
@@ -368,6 +368,9 @@ __global__ __launch_bounds__(64 * MBF_WAVES, 2) void mine_scan_kernel(MineScan p
     }
     auto stage = [&](int v) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef MF_BF3_LAB
+        if (p.abl & 128) return;                             // (lab: nothing is staged)
+#endif
         char* slot = smem + (v % NS) * L::TILEB;
         const int soff = v < nv ? (int)((int64_t)v * 32 * RW) : (int)MF_SRD_DEAD;
 #pragma unroll
@@ -423,12 +426,22 @@ __global__ __launch_bounds__(64 * MBF_WAVES, 2) void mine_scan_kernel(MineScan p
         const char* rowp = slot + c * L::ROWB;
         const int sw = L::swz(c);
         mbf16x8 ahi[KS], alo[KS];
+        mbf16x8 aaug;
+#ifdef MF_BF3_LAB
+        if (p.abl & 64) {                                    // (lab: the operands stay what they were -- no LDS reads)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            ahi[s] = *reinterpret_cast<const mbf16x8*>(rowp + (((2 * s + h) ^ sw) << 4));
-            alo[s] = *reinterpret_cast<const mbf16x8*>(rowp + L::SUB + (((2 * s + h) ^ sw) << 4));
+            for (int s = 0; s < KS; ++s) { ahi[s] = ubh[0][s]; alo[s] = ubl[0][s]; }
+            aaug = uaug[0];
+        } else
+#endif
+        {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                ahi[s] = *reinterpret_cast<const mbf16x8*>(rowp + (((2 * s + h) ^ sw) << 4));
+                alo[s] = *reinterpret_cast<const mbf16x8*>(rowp + L::SUB + (((2 * s + h) ^ sw) << 4));
+            }
+            aaug = *reinterpret_cast<const mbf16x8*>(slot + 2 * L::SUB + c * 32 + h * 16);
         }
-        const mbf16x8 aaug = *reinterpret_cast<const mbf16x8*>(slot + 2 * L::SUB + c * 32 + h * 16);
         const unsigned col0 = (unsigned)(t0 + v) * 32u + 4u * (unsigned)h;
 #pragma unroll
         for (int xt = 0; xt < MBF_XT; ++xt) {

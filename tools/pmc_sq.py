@@ -12,7 +12,7 @@ import sys
 
 KEEP = ("loss_fwd_dense_kernel", "loss_bwd_dense_kernel", "select_kernel<", "select_seed_kernel<", "gather_rows_kernel",
         "update_rows_kernel", "update_fused_kernel", "mask_sweep_kernel", "hits_kernel", "prep_kernel", "finish_kernel",
-        "gt_insert_kernel", "sum_parts_kernel", "bf3_scan_kernel", "bf3_bound_kernel", "bf3_final_kernel", "bf3_prep_kernel")
+        "gt_insert_kernel", "sum_parts_kernel", "bf3_scan_kernel", "bf3_bound_kernel", "bf3_final_kernel", "bf3_prep_kernel", "mine_")
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection "
                   "group by kernel_name, counter_name").fetchall()
