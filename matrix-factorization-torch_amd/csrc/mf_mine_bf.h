@@ -112,8 +112,8 @@ __device__ __forceinline__ void mbf_split3(float x, unsigned short (&o)[3]) {
 //
 // Duplicate columns.  A batch drawn by popularity repeats its popular items hundreds of times (Zipf(1) over 62,423 items, 8192
 // draws: ~700 copies of the first), and copies tie EXACTLY: whenever one is near a user's cut all are, and no list is long
-// enough.  But copies need no search: with rep(j) = the first column whose row is bit for bit column j's (found through the
-// mask builder's colfirst -- first column with j's item id -- and verified on the rows themselves), the copies of a column
+// enough.  But copies need no search: with rep(j) = the first column whose row AND logQ are bit for bit column j's (found through
+// the mask builder's colfirst -- first column with j's item id -- and verified on the values themselves), the copies of a column
 // rank directly behind it, in column order.  So only representatives are scanned (a copy's plane row is made unreachable like a
 // row past N), and the rescoring wave lists the copies of the few winners that have any: copybits[rep] has bit b set when a
 // copy lies in columns [b blk, (b + 1) blk) -- the wave reads rep[] only there (mine_copies).
@@ -156,6 +156,8 @@ __global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict
             const u32x4 fa = reinterpret_cast<const u32x4*>(v + cf * D)[2 * c], fb = reinterpret_cast<const u32x4*>(v + cf * D)[2 * c + 1];
             const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
             same = ua[0] == fa[0] && ua[1] == fa[1] && ua[2] == fa[2] && ua[3] == fa[3] && ub[0] == fb[0] && ub[1] == fb[1] && ub[2] == fb[2] && ub[3] == fb[3];
+            // (... and the same logQ: a table looked up by item id gives copies the same value, a per-column tensor need not)
+            if (c == 0) same = same && __builtin_bit_cast(unsigned, lqn[cf]) == __builtin_bit_cast(unsigned, lqr);
             f = cf;
         }
     }

@@ -3,7 +3,10 @@
     shapes -- Q, N (incl. N % 32 != 0 and tiny N), d, k, exclusion lists, idx_base, duplicate rows, scaled norms;
   * the one-launch training step against the multi-kernel step (torch.equal) on random small shapes;
   * sparse update: the one-launch path against the oracle's coalesced row-Adam on random id multisets (Zipf, uniform,
-    one dominant id, out-of-range ids), and bit-reproducibility of a repeated call.
+    one dominant id, out-of-range ids), and bit-reproducibility of a repeated call;
+  * mined losses: the split-bf16 candidate search against the fp32 streaming selection (the same mask bits, the same loss
+    and gradient bits) on random shapes it serves -- Zipf item ids with rows looked up by id (hundreds of exact copies),
+    logQ, large sigma, zero and negative targets, users that do not list their own positive, near-identical item rows.
     python tests/stress_gpu.py [seconds]      (test infrastructure: it checks the kernels against oracle/)"""
 import importlib
 import os
@@ -221,8 +224,50 @@ def small_step_case():
     return True
 
 
+def mining_case():
+    from tests import test_gpu_parity as tp
+
+    d = [64, 128][ri(0, 1)]
+    b = [ri(256, 600), ri(600, 1500)][ri(0, 1)]
+    n = max(b, [ri(2048, 3000), ri(3000, 7000)][ri(0, 1)])
+    k = [ri(1, 4), ri(5, 16), ri(17, 32)][ri(0, 2)]
+    sigma = [1.0, 0.3, 30.0, 1000.0][ri(0, 3)]
+    n_items = [n // 8, n // 2, 4 * n][ri(0, 2)]
+    t = tp._random_case(b, n, d, ri(1, 12), seed=ri(0, 10**6), n_items=n_items)
+    flavour = ri(0, 3)
+    if flavour >= 1:                                          # rows by id, Zipf popularity: exact copies
+        w = 1.0 / torch.arange(1, n_items + 1, dtype=torch.float64)
+        ids = torch.multinomial(w, n, replacement=True, generator=g) + 1
+        table = tp._unit(n_items + 1, d, g)
+        if flavour == 3:                                      # ... and nearly equal rows under different ids
+            table[1:n_items // 2] = table[1] + 1e-6 * torch.randn(n_items // 2 - 1, d, generator=g)
+        t["item_idx"], t["v"] = ids, table[ids].clone()
+        t["pos_idx"] = torch.randint(0, n_items + 1, t["pos_idx"].shape, generator=g)
+        t["pos_idx"][:, 0] = ids[:b]
+        if flavour == 2:
+            t["pos_idx"][::3, 0] = 0                          # these users do not list their own positive
+    logq = None if ri(0, 1) else torch.log(torch.rand(n, generator=g) * 0.9 + 0.05)
+    kind = ["PairwiseHingeLoss", "PairwiseLogisticLoss", "InfomationNoiseContrastiveEstimationLoss"][ri(0, 2)]
+    res = []
+    for mode in (0, 1):
+        lib.mf_set_mining_prefilter(mode)
+        mask = mf.losses.negative_mask(t["u"].to(dev), t["v"].to(dev), t["target"].to(dev), item_idx=t["item_idx"].to(dev),
+                                       pos_idx=t["pos_idx"].to(dev), num_negatives=k, sigma=sigma).cpu()
+        got, du, dv = tp._run_gpu(mf, kind, t, k, sigma, 0.5, logq)
+        res.append((mask, got, torch.from_numpy(du), torch.from_numpy(dv)))
+    lib.mf_set_mining_prefilter(1)
+    import gc
+    gc.collect()                                              # (the autograd contexts hold workspaces of hundreds of MB in reference cycles)
+    same = torch.equal(res[0][0], res[1][0]) and (res[0][1] == res[1][1] or (res[0][1] != res[0][1] and res[1][1] != res[1][1])) \
+        and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+    if not same:
+        print(f"MINING PREFILTER MISMATCH b={b} n={n} d={d} k={k} sigma={sigma} flavour={flavour} n_items={n_items} logq={logq is not None} "
+              f"kind={kind} mask rows off {int((res[0][0] != res[1][0]).any(1).sum())} loss {res[0][1]} vs {res[1][1]}", flush=True)
+    return same
+
+
 n_kink = 0
-CASES = {"topk": topk_case, "update": update_case, "loss": loss_case, "small": small_step_case}
+CASES = {"topk": topk_case, "update": update_case, "loss": loss_case, "small": small_step_case, "mining": mining_case}
 
 
 def run(budget: float, only: str | None = None, seed: int | None = None) -> tuple[int, int]:

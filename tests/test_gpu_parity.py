@@ -1105,3 +1105,13 @@ def test_mined_masks_through_the_bf16_prefilter_are_bit_exact(mf, cfg, tied):
         lib.mf_set_mining_prefilter(1)
     assert torch.equal(plain, want), int((plain != want).sum())
     assert torch.equal(got, want), (int((got != want).sum()), (got != want).any(1).nonzero().flatten()[:8].tolist())
+    if tied is True and k <= 9:
+        # a logQ tensor PER COLUMN: copies of an item may carry different values, and are then no copies to the search
+        # (the randomised stress found the first version treating them as such)
+        g = torch.Generator().manual_seed(11)
+        logq = torch.log(torch.rand(n, generator=g) * 0.9 + 0.05)
+        lgq = chain.logits(t["u"].numpy(), t["v"].numpy(), t["target"].numpy(), sigma, logq.numpy())
+        ref = float(ol.loss("PairwiseHingeLoss", t["u"], t["v"], t["target"], item_idx=t["item_idx"], pos_idx=t["pos_idx"], num_negatives=k,
+                            sigma=sigma, margin=0.5, logq=logq, mining_logits=lgq))
+        val = _run_gpu(mf, "PairwiseHingeLoss", t, k, sigma, 0.5, logq)[0]
+        assert abs(val - ref) <= gu.loss_tolerance(ref, sigma, t["target"].numpy()), (val, ref)
