@@ -955,18 +955,28 @@ __global__ __launch_bounds__(64) void mined_rows_kernel(MinedRowParams p) {
         const int d4 = p.d / 4;                  // <= 64 chunks of 16 bytes (d <= 256): one per lane
         f32x4 ur = {0.f, 0.f, 0.f, 0.f};
         if (lane < d4) ur = reinterpret_cast<const f32x4*>(p.u + i * p.d)[lane];
-        for (int t = 0; t < m; ++t) {
-            const int64_t j = (int64_t)mf_key_mining_col(sorted[t]);
-            float part = 0.f;
-            if (lane < d4) {
-                const f32x4 vr = reinterpret_cast<const f32x4*>(p.v + j * p.d)[lane];
-                part = ur[0] * vr[0] + ur[1] * vr[1] + ur[2] * vr[2] + ur[3] * vr[3];
+        // (four rows, their norms and logQ in flight at a time: one at a time was a memory round trip per selected negative)
+        for (int t0 = 0; t0 < m; t0 += 4) {
+            f32x4 vr[4];
+            float nvj[4], lqj[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t j = t0 + q < m ? (int64_t)mf_key_mining_col(sorted[t0 + q]) : 0;
+                vr[q] = (lane < d4 && t0 + q < m) ? reinterpret_cast<const f32x4*>(p.v + j * p.d)[lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+                nvj[q] = p.nv[j];
+                lqj[q] = p.nlogq[j];
             }
-            part = mf_wave_sum(part);
-            const float L = mf_logit(nu_i, p.nv[j], part, s_i, p.sigma, -p.nlogq[j]);
-            if (lane == 0) p.sel_L[i * KSEL_MAX + t] = L;
-            stats_add(st, p.need, L, sm, l, p.margin);
-            if (p.need & NEED_LSE) lse_merge(st.mx, st.se, L, 1.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (t0 + q < m) {                            // (wave-uniform)
+                    float part = ur[0] * vr[q][0] + ur[1] * vr[q][1] + ur[2] * vr[q][2] + ur[3] * vr[q][3];
+                    part = mf_wave_sum(part);
+                    const float L = mf_logit(nu_i, nvj[q], part, s_i, p.sigma, -lqj[q]);
+                    if (lane == 0) p.sel_L[i * KSEL_MAX + t0 + q] = L;
+                    stats_add(st, p.need, L, sm, l, p.margin);
+                    if (p.need & NEED_LSE) lse_merge(st.mx, st.se, L, 1.f);
+                }
+            }
         }
     }
     if (lane == 0) {
