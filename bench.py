@@ -827,6 +827,13 @@ def main() -> None:
         extras["mined"] = {"workload": "C3 shape, PairwiseHingeLoss, num_negatives=4 (reference default loss), row-adam",
                            **brief(leg, B, DIM)}
         del leg
+        # the same step captured in a hipGraph and replayed: with the search on the bf16 cores the eager step is bounded by the
+        # host's ~22 launches and Python, not by the GPU (spans cannot be recorded inside a replayed graph: none here)
+        leg = run_train_leg(mf, lib, device, batch=B, steps=40, warmup=5, loss="PairwiseHingeLoss", num_negatives=4, use_logq=False, reps=3,
+                            graph=True, spin=False)
+        extras["mined"]["graph_ms_per_step"] = round(leg["ms_per_step"], 4)
+        extras["mined"]["graph_pairs_per_s"] = round(leg["pairs_per_s"], 1)
+        del leg
         # config C2: MovieLens-1M shape, d = 64, in-batch sampled softmax
         leg = run_train_leg(mf, lib, device, batch=B, steps=40, warmup=5, num_users=6041, num_items=3884, dim=64, use_logq=False, reps=3)
         extras["c2_ml1m_d64"] = {"workload": "C2: MovieLens-1M shape (6,040 x 3,883), d=64, InfoNCE, row-adam", **brief(leg, B, 64)}
@@ -961,6 +968,7 @@ def main() -> None:
             "train_frac": dig(train_roof, "frac"), "train_tail_us": round((dt_train / K - sweeps_ms * 1e-3) * 1e6, 1) if sweeps_ms else None,
             "mined_frac": dig(extras, "mined", "roofline", "frac"), "mined_of_fp32_peak": dig(extras, "mined", "roofline", "of_fp32_mfma_peak"),
             "mined_ms_per_step": dig(extras, "mined", "ms_per_step"), "mined_pairs_per_s": dig(extras, "mined", "pairs_per_s"),
+            "mined_graph_ms_per_step": dig(extras, "mined", "graph_ms_per_step"),
             "c2_ms_per_step": dig(extras, "c2_ml1m_d64", "ms_per_step"),
             "cpu_pairs_per_s": dig(cpu, "value"), "cpu_topk_queries_per_s": dig(cpu, "topk_value"),
         })

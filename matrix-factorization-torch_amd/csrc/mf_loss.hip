@@ -940,50 +940,62 @@ struct MinedRowParams {
     int need;
     int32_t *sel, *sel_cnt;
     float *sel_L, *stats;
+    const int32_t* gate;         // not NULL: the launch does nothing unless *gate is set (behind the prefilter, whose rescoring waves
+                                 // finish their users themselves: MinedRowFinish)
+};
+// sorted[0 .. m) (LDS): user i's selected negatives in order -> sel, their logits, the row's statistics.  i >= B: only the
+// (empty) statistics are written.
+struct MinedRowFinish {
+    using Params = MinedRowParams;
+    static __device__ __forceinline__ void run(const MinedRowParams& p, int64_t i, int m, const unsigned long long* sorted) {
+        const int lane = mf_lane();
+        RowStats st;
+        stats_init(st);
+        if (i < p.B) {
+            if (lane < m) p.sel[i * KSEL_MAX + lane] = (int32_t)mf_key_mining_col(sorted[lane]);
+            if (lane == 0) p.sel_cnt[i] = m;
+            const float s_i = p.sgn[i], l = p.lii[i], sm = s_i * p.margin, nu_i = p.nu[i];
+            const int d4 = p.d / 4;                  // <= 64 chunks of 16 bytes (d <= 256): one per lane
+            f32x4 ur = {0.f, 0.f, 0.f, 0.f};
+            if (lane < d4) ur = reinterpret_cast<const f32x4*>(p.u + i * p.d)[lane];
+            // (four rows, their norms and logQ in flight at a time: one at a time was a memory round trip per selected negative)
+            for (int t0 = 0; t0 < m; t0 += 4) {
+                f32x4 vr[4];
+                float nvj[4], lqj[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t j = t0 + q < m ? (int64_t)mf_key_mining_col(sorted[t0 + q]) : 0;
+                    vr[q] = (lane < d4 && t0 + q < m) ? reinterpret_cast<const f32x4*>(p.v + j * p.d)[lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    nvj[q] = p.nv[j];
+                    lqj[q] = p.nlogq[j];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (t0 + q < m) {                            // (wave-uniform)
+                        float part = ur[0] * vr[q][0] + ur[1] * vr[q][1] + ur[2] * vr[q][2] + ur[3] * vr[q][3];
+                        part = mf_wave_sum(part);
+                        const float L = mf_logit(nu_i, nvj[q], part, s_i, p.sigma, -lqj[q]);
+                        if (lane == 0) p.sel_L[i * KSEL_MAX + t0 + q] = L;
+                        stats_add(st, p.need, L, sm, l, p.margin);
+                        if (p.need & NEED_LSE) lse_merge(st.mx, st.se, L, 1.f);
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            float* o = p.stats + i;
+            o[ST_CNT * p.Bp] = st.cnt; o[ST_A * p.Bp] = st.A; o[ST_MX * p.Bp] = st.mx; o[ST_SE * p.Bp] = st.se;
+            o[ST_H * p.Bp] = st.H; o[ST_HC * p.Bp] = st.Hc; o[ST_LG * p.Bp] = st.Lg; o[ST_LS * p.Bp] = st.Ls;
+        }
+    }
 };
 __global__ __launch_bounds__(64) void mined_rows_kernel(MinedRowParams p) {
     __shared__ unsigned long long win[64], sorted[64];
     const int64_t i = blockIdx.x;
-    const int lane = mf_lane();
-    RowStats st;
-    stats_init(st);
-    if (i < p.B) {
-        const int m = mf_row_topk<8>(p.cand + i * (int64_t)p.rowcap, p.cand_cnt[i], p.k, win, sorted);
-        if (lane < m) p.sel[i * KSEL_MAX + lane] = (int32_t)mf_key_mining_col(sorted[lane]);
-        if (lane == 0) p.sel_cnt[i] = m;
-        const float s_i = p.sgn[i], l = p.lii[i], sm = s_i * p.margin, nu_i = p.nu[i];
-        const int d4 = p.d / 4;                  // <= 64 chunks of 16 bytes (d <= 256): one per lane
-        f32x4 ur = {0.f, 0.f, 0.f, 0.f};
-        if (lane < d4) ur = reinterpret_cast<const f32x4*>(p.u + i * p.d)[lane];
-        // (four rows, their norms and logQ in flight at a time: one at a time was a memory round trip per selected negative)
-        for (int t0 = 0; t0 < m; t0 += 4) {
-            f32x4 vr[4];
-            float nvj[4], lqj[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t j = t0 + q < m ? (int64_t)mf_key_mining_col(sorted[t0 + q]) : 0;
-                vr[q] = (lane < d4 && t0 + q < m) ? reinterpret_cast<const f32x4*>(p.v + j * p.d)[lane] : f32x4{0.f, 0.f, 0.f, 0.f};
-                nvj[q] = p.nv[j];
-                lqj[q] = p.nlogq[j];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (t0 + q < m) {                            // (wave-uniform)
-                    float part = ur[0] * vr[q][0] + ur[1] * vr[q][1] + ur[2] * vr[q][2] + ur[3] * vr[q][3];
-                    part = mf_wave_sum(part);
-                    const float L = mf_logit(nu_i, nvj[q], part, s_i, p.sigma, -lqj[q]);
-                    if (lane == 0) p.sel_L[i * KSEL_MAX + t0 + q] = L;
-                    stats_add(st, p.need, L, sm, l, p.margin);
-                    if (p.need & NEED_LSE) lse_merge(st.mx, st.se, L, 1.f);
-                }
-            }
-        }
-    }
-    if (lane == 0) {
-        float* o = p.stats + i;
-        o[ST_CNT * p.Bp] = st.cnt; o[ST_A * p.Bp] = st.A; o[ST_MX * p.Bp] = st.mx; o[ST_SE * p.Bp] = st.se;
-        o[ST_H * p.Bp] = st.H; o[ST_HC * p.Bp] = st.Hc; o[ST_LG * p.Bp] = st.Lg; o[ST_LS * p.Bp] = st.Ls;
-    }
+    if (p.gate && __hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    int m = 0;
+    if (i < p.B) m = mf_row_topk<8>(p.cand + i * (int64_t)p.rowcap, p.cand_cnt[i], p.k, win, sorted);
+    MinedRowFinish::run(p, i, m, sorted);
 }
 
 __global__ __launch_bounds__(256) void mask_export_mined_kernel(const int32_t* __restrict__ sel,
@@ -1452,7 +1464,7 @@ static unsigned long long* g_mine_dbg = nullptr;
 #define MBF_TIMED(name, s, ...) do { __VA_ARGS__; } while (0)
 #endif
 template <int D>
-static void mine_bf_launch(const LossWs& w, const float* u, const float* v, int64_t B, int64_t N, int k, float sigma, hipStream_t s) {
+static void mine_bf_launch(const LossWs& w, const MinedRowParams& fin, const float* u, const float* v, int64_t B, int64_t N, int k, float sigma, hipStream_t s) {
     const MineBfPlan& m = w.mbf;
     int lab_abl = 0;
 #ifdef MF_BF3_LAB
@@ -1485,14 +1497,14 @@ static void mine_bf_launch(const LossWs& w, const float* u, const float* v, int6
         MineRescore mr{u, v, w.nu, w.nv, w.lii, w.sgn, w.logq, w.maskW, B, w.Bp, N, m.Xq, sigma, m.nlists, k,
                        w.mbf_plist, w.mbf_pcnt, w.mbf_flag, w.mbf_spill, w.mbf_spill_cnt, w.mbf_gate, w.mbf_rep, w.mbf_copybits, w.mbf_lastcopy, m.blk, w.cand, w.cand_cnt, w.plan.rowcap,
                        g_mine_dbg};
-        auto fn = mine_rescore_kernel<D>;
+        auto fn = mine_rescore_kernel<D, MinedRowFinish>;
         const int bytes = MineRescoreGeom<D>::BYTES;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); attr = true; }
-        MBF_TIMED("mining_rescore", s, (fn<<<dim3((unsigned)B), 64, bytes, s>>>(mr)));
+        MBF_TIMED("mining_rescore", s, (fn<<<dim3((unsigned)w.Bp), 64, bytes, s>>>(mr, fin)));
     }
 }
-static int mine_bf_run(const LossWs& w, const MiningPolicy::Params& mp, const SelectCommon& sc, const float* u, const float* v, int64_t B,
+static int mine_bf_run(const LossWs& w, const MiningPolicy::Params& mp, const SelectCommon& sc, const MinedRowParams& fin, const float* u, const float* v, int64_t B,
                        int64_t N, int d, int k, float sigma, hipStream_t s) {
 #ifdef MF_BF3_LAB
     const bool whole = false;
@@ -1501,8 +1513,8 @@ static int mine_bf_run(const LossWs& w, const MiningPolicy::Params& mp, const Se
 #endif
     if (whole) mf_timing_begin("mining_prefilter", s);
     MF_DISPATCH_D(d, { MBF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s, true))); });
-    if (d == 64) mine_bf_launch<64>(w, u, v, B, N, k, sigma, s);
-    else mine_bf_launch<128>(w, u, v, B, N, k, sigma, s);
+    if (d == 64) mine_bf_launch<64>(w, fin, u, v, B, N, k, sigma, s);
+    else mine_bf_launch<128>(w, fin, u, v, B, N, k, sigma, s);
     // behind it, gated on the device: a batch the prefilter gave up on (a spill list overflowed -- thousands of exact ties --,
     // a user without a bound, non-finite norms) is answered by the fp32 search; otherwise its workgroups leave at once
     SelectCommon scg = sc;
@@ -1613,13 +1625,16 @@ static int loss_fwd_impl(const char* what, int64_t B, int64_t N, int d, const Po
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
         SelectCommon sc{u, B, v, N, 0, (int)((N + 31) / 32), w.plan.tpc, w.Bp, num_negatives, w.plan.xw, w.gtau, w.priv, w.cand, w.cand_cnt, w.plan.rowcap};
         mf_zero_async(w.gtau, (size_t)((char*)(w.mbf.ok ? (void*)(w.mbf_gate + 4) : (void*)(w.mbf_max + MBF_MAXSLOTS * MBF_MAXSTRIDE)) - (char*)w.gtau), s);
+        MinedRowParams mr{w.cand, w.cand_cnt, w.plan.rowcap, num_negatives, u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, B, w.Bp, d,
+                          sigma, margin, need, w.sel, w.sel_cnt, w.sel_L, w.stats, nullptr};
         if (w.mbf.ok && mine_bf_enabled() && w.plan.YTa > 0 && w.plan.rowcap >= num_negatives) {
-            if (int rc2 = mine_bf_run(w, mp, sc, u, v, B, N, d, num_negatives, sigma, s)) return rc2;
+            // (the rescoring waves finish their users themselves; mined_rows_kernel behind them only runs for a batch handed
+            // to the fp32 search)
+            if (int rc2 = mine_bf_run(w, mp, sc, mr, u, v, B, N, d, num_negatives, sigma, s)) return rc2;
+            mr.gate = w.mbf_gate;
         } else {
             MF_DISPATCH_D(d, { MF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s))); });
         }
-        MinedRowParams mr{w.cand, w.cand_cnt, w.plan.rowcap, num_negatives, u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, B, w.Bp, d,
-                          sigma, margin, need, w.sel, w.sel_cnt, w.sel_L, w.stats};
         mined_rows_kernel<<<dim3((unsigned)w.Bp), 64, 0, s>>>(mr);
         if (out_mask_bits) {
             (void)hipMemsetAsync(out_mask_bits, 0, (size_t)B * ((N + 31) / 32) * 4, s);

@@ -610,9 +610,11 @@ __device__ __forceinline__ int mine_copies(const MineRescore& p, int64_t x, unsi
     return got;
 }
 
-// One wave (= one workgroup) per user.
-template <int D>
-__global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
+// One wave (= one workgroup) per user (grid: the padded user count).  The wave also FINISHES its user -- Fin::run: the selected
+// columns, their logits, the row's statistics (MinedRowFinish in mf_loss.hip; mined_rows_kernel's second half) --: the row lists
+// of the fp32 search (cand / cand_cnt) are not written on this path at all.
+template <int D, class Fin>
+__global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p, typename Fin::Params fp) {
     using G = MineRescoreGeom<D>;
     extern __shared__ __attribute__((aligned(1024))) char fsm[];
     const int lane = mf_lane();
@@ -622,11 +624,9 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
     unsigned long long* sorted = win + 64;
     float* xq = reinterpret_cast<float*>(sorted + 64);
     const int64_t x = blockIdx.x;
-    if (x >= p.B) return;
-    if (__hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {      // the fp32 search behind this kernel fills the lists
-        if (lane == 0) p.cand_cnt[x] = 0;
-        return;
-    }
+    // (the fp32 search behind this kernel fills the lists -- cand_cnt was cleared by the host -- and mined_rows_kernel finishes)
+    if (__hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (x >= p.B) { Fin::run(fp, x, 0, sorted); return; }    // padding users: empty statistics
     const unsigned long long below = (1ull << lane) - 1ull;
     // round trip 1: the user's scalars and row, the lengths of its lists (lane l owns list l = 2 chunk + lane half)
     const float nu = p.nu[x], lii = p.lii[x], s = p.sgn[x];
@@ -642,7 +642,6 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
 #pragma unroll
     for (int j = 0; j < (D + 63) / 64; ++j)
         if (lane + 64 * j < D) xq[lane + 64 * j] = xv[j];
-    unsigned long long* out = p.cand + x * (int64_t)p.rowcap;
     int n_out = 0;
     if (!flag) {
         // round trip 2: every list whole (a lane's 16 entries = 64 bytes), all loads in flight; 3: their mask words
@@ -755,10 +754,7 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
         else m = mf_row_topk<G::LMAX / 64, true>(keys, n, p.k, win, sorted);
         unsigned long long kt_l = 0ull, bits_l = 0ull;
         unsigned fr_l = 0u;
-        if (lane < m) {
-            kt_l = sorted[lane];
-            if (lane < p.rowcap) out[lane] = kt_l;
-        }
+        if (lane < m) kt_l = sorted[lane];
         if (__any(anycb)) {                                  // (LDS is the limit of this kernel's occupancy: no table of bitmaps, one more L2 round trip here)
             if (lane < m) {
                 const unsigned cw = mf_key_mining_col(kt_l);
@@ -767,19 +763,28 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
                 if (fr_l != cw) bits_l = p.copybits[fr_l];
             }
         }
-        n_out = m;
         unsigned long long todo = __ballot(bits_l != 0ull && lane < p.k - 1);      // a copy of the winner at position t sits at t + 1 or later
-        while (todo) {
-            const int t = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const unsigned long long kt = mine_shfl_u64(kt_l, t), bits = mine_shfl_u64(bits_l, t);
-            const unsigned fr = (unsigned)__shfl((int)fr_l, t, 64);
-            const int at = n_out;
-            n_out += mine_copies(p, x, fr, mf_key_mining_col(kt), bits, p.k - 1 - t, [&](unsigned cc, int i) {
-                if (at + i < p.rowcap) out[at + i] = (kt & ~0x3FFFFFFFull) | (unsigned long long)(0x3FFFFFFFu - cc);
-            });
+        if (todo) {
+            // the pool: the winners and, behind each, the copies a cut at k can reach (<= k (k + 1) / 2 keys, in keys[]: the
+            // candidates' keys are not needed any more); its k best, in order, are the user's selection
+            mf_row_topk_sync<true>();
+            if (lane < m) keys[lane] = kt_l;
+            int n_pool = m;
+            while (todo) {
+                const int t = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const unsigned long long kt = mine_shfl_u64(kt_l, t), bits = mine_shfl_u64(bits_l, t);
+                const unsigned fr = (unsigned)__shfl((int)fr_l, t, 64);
+                const int at = n_pool;
+                n_pool += mine_copies(p, x, fr, mf_key_mining_col(kt), bits, p.k - 1 - t, [&](unsigned cc, int i) {
+                    keys[at + i] = (kt & ~0x3FFFFFFFull) | (unsigned long long)(0x3FFFFFFFu - cc);
+                });
+            }
+            mf_row_topk_sync<true>();
+            if (n_pool <= 64) m = mf_row_topk<1, true>(keys, n_pool, p.k, win, sorted);
+            else m = mf_row_topk<G::LMAX / 64, true>(keys, n_pool, p.k, win, sorted);
         }
-        n_out = min(n_out, p.rowcap);
+        n_out = m;
     } else {
         // a zero target: the whole row by the exact formulas (no product needed), 64 columns a round; the k best keys so far ride along in win[]
         if (p.dbg && lane == 0) atomicAdd(p.dbg + 2, 1ull);
@@ -818,10 +823,18 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p) {
             carry = pos;
             mf_row_topk_sync<true>();
         }
-        if (lane < carry && lane < p.rowcap) out[lane] = win[lane];
-        n_out = min(carry, p.rowcap);
+        unsigned long long mine_k = 0ull;
+        if (lane < carry) mine_k = win[lane];
+        mf_row_topk_sync<true>();
+        if (lane < carry) {
+            int rk = 0;
+            for (int q = 0; q < carry; ++q) rk += win[q] > mine_k ? 1 : 0;
+            sorted[rk] = mine_k;
+        }
+        mf_row_topk_sync<true>();
+        n_out = carry;
     }
-    if (lane == 0) p.cand_cnt[x] = n_out;
+    Fin::run(fp, x, n_out, sorted);
 }
 
 #endif  // __HIPCC__
