@@ -29,6 +29,15 @@ python3 tools/pmc_traffic.py $(ls gpurun_out/pmcF_$R/*.db gpurun_out/pmcF_$R/*/*
 timeout -k 10 600 rocprofv3 --kernel-trace -d gpurun_out/tl_$R -o tl -- python3 bench.py --no-extras --no-cpu-baseline > $OUT/tl_stdout.log 2>&1 || exit 1
 python3 tools/step_timeline.py $(ls gpurun_out/tl_$R/*.db gpurun_out/tl_$R/*/*.db 2>/dev/null | head -1) > $OUT/${R}_step_timeline.txt || exit 1
 rm -rf gpurun_out/tl_$R
+# the reference's default loss (4 mined negatives): kernel timeline of one steady step, and the SQ counters of its kernels
+timeout -k 10 300 rocprofv3 --kernel-trace -d gpurun_out/tlm_$R -o m -- python3 tools/lab/mined_timeline.py > $OUT/tlm_stdout.log 2>&1 || exit 1
+python3 tools/lab/mined_timeline.py $(ls gpurun_out/tlm_$R/*.db gpurun_out/tlm_$R/*/*.db 2>/dev/null | head -1) > $OUT/${R}_mined_step_timeline.txt || exit 1
+grep "mined step" $OUT/tlm_stdout.log | sed 's/^/# (same run, under rocprofv3) /' >> $OUT/${R}_mined_step_timeline.txt
+rm -rf gpurun_out/tlm_$R
+timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS \
+    -d gpurun_out/pmcM_$R -o r -- python3 tools/lab/mined_timeline.py > $OUT/pmcM_stdout.log 2>&1 || exit 1
+python3 tools/pmc_sq.py $(ls gpurun_out/pmcM_$R/*.db gpurun_out/pmcM_$R/*/*.db 2>/dev/null | head -1) > $OUT/${R}_mined_pmc_sq.json || exit 1
+rm -rf gpurun_out/pmcM_$R
 # the raw rocprof databases are far beyond what travels back
 rm -rf gpurun_out/prof_$R gpurun_out/pmcS_$R gpurun_out/pmcF_$R gpurun_out/pmcW_$R
 ls -la $OUT

@@ -48,7 +48,7 @@ for i in range(100):
     tr.step(batches[i % 8])
 torch.cuda.synchronize()
 lib.mf_timing_enable(0)
-for name in (b"mining_prefilter", b"mining_select", b"mining_items", b"mining_users", b"mining_scan", b"mining_rescore", b"update_rows", b"gather_rows"):
+for name in (b"mining_prefilter", b"mining_select", b"mining_seed", b"mining_bound", b"mining_items", b"mining_users", b"mining_scan", b"mining_rescore", b"update_rows", b"gather_rows"):
     tot = ctypes.c_double(0.0)
     n = lib.mf_timing_get(name, ctypes.byref(tot))
     if n:
@@ -65,4 +65,4 @@ if os.environ.get("MF_MINE_DBG"):
             lib.mf_probe_mining_prefilter(buf, 0)
             half = struct.unpack("f", struct.pack("I", buf[7] & 0xFFFFFFFF))[0]
             print(f"batch {bi}: {buf[0] / max(buf[1], 1):.1f} candidates rescored per user over {buf[1]} users, {buf[2]} users walked exactly "
-                  f"(no bound {buf[3]}, non-finite {buf[4]}, zero target {buf[5]}; {buf[6]} entries in overflowing lane lists, largest half {half:.4g})", flush=True)
+                  f"(no bound {buf[3]}, hard-class bounds {buf[4]}, hit buffers overflowed {buf[5]}; {buf[6]} entries in overflowing lane lists, largest half {half:.4g})", flush=True)
