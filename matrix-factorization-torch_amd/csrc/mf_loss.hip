@@ -299,30 +299,54 @@ __device__ __forceinline__ unsigned bm_hash(long long id, int bits) {
 __global__ __launch_bounds__(64) void gt_insert_kernel(const int64_t* __restrict__ item_idx, int64_t N, int M,
                                                         long long* __restrict__ gtab, int32_t* __restrict__ gfirst,
                                                         int32_t* __restrict__ colslot, uint32_t* __restrict__ bmap, int bmbits) {
-    const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (j >= N) return;
-    const long long key = item_idx[j];
-    unsigned long long* tab = reinterpret_cast<unsigned long long*>(gtab);
-    const volatile unsigned long long* vtab = tab;
-    unsigned hpos = ht_hash(key, M - 1);
-    const unsigned b = bm_hash(key, bmbits);
-    const uint32_t bit = 1u << (b & 31);
-    unsigned long long old = vtab[hpos];                                   // three independent loads in flight
-    int32_t first_seen = *(const volatile int32_t*)&gfirst[hpos];
-    const uint32_t bm_seen = *(const volatile uint32_t*)&bmap[b >> 5];
-    for (int probe = 0; probe < M; ++probe) {
-        if (probe) {
-            old = vtab[hpos];
-            first_seen = *(const volatile int32_t*)&gfirst[hpos];
+    // Round 4: ONE lane per item and wave talks to the tables.  Every column of the batch runs at once, so "look before the
+    // atomic" saves nothing on the popular items (all 700 copies of the first one see an empty slot), and atomics on one word
+    // queue up at its L2 channel: 700 claims + 700 minima on two words were most of this kernel's 16.5 us.  The wave's 64
+    // columns elect, per item, their lowest lane (a 128-slot LDS table: the key, then the minimum lane among the lanes that
+    // find their own key there; two different items in one slot: the loser just acts for itself); the leader probes, claims,
+    // publishes the slot; its followers -- later columns of the same item: their minimum is not needed -- take it from LDS.
+    __shared__ unsigned long long e_key[128];
+    __shared__ int e_lane[128];
+    __shared__ unsigned e_hpos[128];
+    const int lane = threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = j < N;
+    const long long key = live ? item_idx[j] : 0;
+    const unsigned es = (unsigned)(((unsigned long long)key * 0x9E3779B97F4A7C15ull) >> 57);      // 7 bits
+    e_lane[lane] = 64; e_lane[lane + 64] = 64;
+    __syncthreads();
+    if (live) e_key[es] = (unsigned long long)key;          // (any one of the slot's writers stays)
+    __syncthreads();
+    const bool mine_slot = live && e_key[es] == (unsigned long long)key;
+    if (mine_slot) atomicMin(&e_lane[es], lane);
+    __syncthreads();
+    const bool leader = live && (!mine_slot || e_lane[es] == lane);
+    unsigned hpos = 0u;
+    if (leader) {
+        unsigned long long* tab = reinterpret_cast<unsigned long long*>(gtab);
+        const volatile unsigned long long* vtab = tab;
+        hpos = ht_hash(key, M - 1);
+        const unsigned b = bm_hash(key, bmbits);
+        const uint32_t bit = 1u << (b & 31);
+        unsigned long long old = vtab[hpos];                                   // three independent loads in flight
+        int32_t first_seen = *(const volatile int32_t*)&gfirst[hpos];
+        const uint32_t bm_seen = *(const volatile uint32_t*)&bmap[b >> 5];
+        for (int probe = 0; probe < M; ++probe) {
+            if (probe) {
+                old = vtab[hpos];
+                first_seen = *(const volatile int32_t*)&gfirst[hpos];
+            }
+            if (old == (unsigned long long)HT_EMPTY)
+                old = atomicCAS(&tab[hpos], (unsigned long long)HT_EMPTY, (unsigned long long)key);
+            if (old == (unsigned long long)HT_EMPTY || old == (unsigned long long)key) break;
+            hpos = (hpos + 1) & (M - 1);
         }
-        if (old == (unsigned long long)HT_EMPTY)
-            old = atomicCAS(&tab[hpos], (unsigned long long)HT_EMPTY, (unsigned long long)key);
-        if (old == (unsigned long long)HT_EMPTY || old == (unsigned long long)key) break;
-        hpos = (hpos + 1) & (M - 1);
+        if (first_seen > (int32_t)j) atomicMin(&gfirst[hpos], (int32_t)j);     // cleared to 0x7f7f7f7f
+        if (!(bm_seen & bit)) atomicOr(&bmap[b >> 5], bit);
+        if (mine_slot) e_hpos[es] = hpos;
     }
-    if (first_seen > (int32_t)j) atomicMin(&gfirst[hpos], (int32_t)j);     // cleared to 0x7f7f7f7f
-    if (!(bm_seen & bit)) atomicOr(&bmap[b >> 5], bit);
-    colslot[j] = (int32_t)hpos;
+    __syncthreads();
+    if (live) colslot[j] = (int32_t)(leader ? hpos : e_hpos[es]);
 }
 
 // colfirst[j] = first column with column j's item (-1: padding column)
