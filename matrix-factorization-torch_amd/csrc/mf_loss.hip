@@ -1340,50 +1340,102 @@ __global__ __launch_bounds__(1024) void dv_scale_kernel(const float* __restrict_
     }
 }
 
+// Round 4: a workgroup is 32 users (1024 threads), and its contributions to dV meet in LDS first -- 64-bit fixed point is
+// associative, so ANY grouping gives the same bits.  The mined columns of a Zipf batch are few and hot (the first copies of
+// the popular items are picked by thousands of users): 5.2 M global 64-bit atomics, thousands of them on the same words, were
+// this kernel's 60 us.  Now a column is claimed in a small LDS table (key by LDS compare-and-swap; a column that loses its
+// slot to another goes to global memory as before), the users add with LDS atomics, and the workgroup flushes every
+// occupied slot with one global atomic per feature.
 template <int D>
-__global__ __launch_bounds__(256) void mined_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
-                                                        const float* __restrict__ rowc, const int32_t* __restrict__ sel,
-                                                        const int32_t* __restrict__ sel_cnt,
-                                                        const float* __restrict__ sel_L, const float* __restrict__ grad_out,
-                                                        int64_t B, int64_t Bp,
-                                                        int gmode, float* __restrict__ du, long long* __restrict__ dvfix,
-                                                        const float* __restrict__ dvsc) {
+struct MinedBwdLds {
+    static constexpr int SLOTS = D <= 128 ? 48 : 24;        // 48 KB of accumulators at d = 128 (d x 8 bytes per slot)
+    static constexpr int BYTES = SLOTS * D * 8 + SLOTS * 4;
+};
+template <int D>
+__global__ __launch_bounds__(1024) void mined_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                         const float* __restrict__ rowc, const int32_t* __restrict__ sel,
+                                                         const int32_t* __restrict__ sel_cnt,
+                                                         const float* __restrict__ sel_L, const float* __restrict__ grad_out,
+                                                         int64_t B, int64_t Bp,
+                                                         int gmode, float* __restrict__ du, long long* __restrict__ dvfix,
+                                                         const float* __restrict__ dvsc) {
+    extern __shared__ __attribute__((aligned(16))) char bsm[];
+    using L = MinedBwdLds<D>;
+    unsigned long long* lacc = reinterpret_cast<unsigned long long*>(bsm);                  // [SLOTS][D]
+    int* lkey = reinterpret_cast<int*>(bsm + L::SLOTS * D * 8);                             // [SLOTS]: the column, -1 = free
     constexpr int LPR = 32, NE = D / LPR;            // lanes per row, features per lane (c, c + 32, ...)
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (int q = threadIdx.x; q < L::SLOTS * D; q += 1024) lacc[q] = 0ull;
+    if (threadIdx.x < L::SLOTS) lkey[threadIdx.x] = -1;
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     const int64_t i = t / LPR;
     const int c = (int)(t % LPR);
-    if (i >= B) return;
-    const float go = grad_out[0];
-    const float fix_scale = dvsc[0], fix_clamp = dvsc[1];
-    const float a = rowc[i], b = rowc[Bp + i], cg = go * rowc[2 * Bp + i], gd = go * rowc[3 * Bp + i];
-    float ui[NE], acc[NE];
+    if (i < B) {
+        const float go = grad_out[0];
+        const float fix_scale = dvsc[0], fix_clamp = dvsc[1];
+        const float a = rowc[i], b = rowc[Bp + i], cg = go * rowc[2 * Bp + i], gd = go * rowc[3 * Bp + i];
+        float ui[NE], acc[NE];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) { ui[e] = u[i * D + c + LPR * e]; acc[e] = 0.f; }
-    const int n = sel_cnt[i];
-    for (int s = -1; s < n; ++s) {
-        int64_t j;
-        float g;
-        if (s < 0) { j = i; g = gd; }
-        else { j = sel[i * KSEL_MAX + s]; g = cg * g_of(gmode, (sel_L[i * KSEL_MAX + s] - a) + b); }
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(dvfix) + j * D + c;
+        for (int e = 0; e < NE; ++e) { ui[e] = u[i * D + c + LPR * e]; acc[e] = 0.f; }
+        const int n = sel_cnt[i];
+        for (int s = -1; s < n; ++s) {
+            int64_t j;
+            float g;
+            if (s < 0) { j = i; g = gd; }
+            else { j = sel[i * KSEL_MAX + s]; g = cg * g_of(gmode, (sel_L[i * KSEL_MAX + s] - a) + b); }
+            // the user's own column is its alone (one diagonal per column): straight to memory; a mined column through LDS
+            int slot = -1;
+            if (s >= 0) {
+                const int want = (int)(((unsigned)j * 2654435761u) >> 16) % L::SLOTS;
+                int got = 0;
+                if (c == 0) {
+                    const int old = atomicCAS(&lkey[want], -1, (int)j);
+                    got = (old == -1 || old == (int)j) ? 1 : 0;
+                }
+                got = __shfl(got, threadIdx.x & 32, 64);     // (the group's lane 0: lane 0 or 32 of the wave)
+                slot = got ? want : -1;
+            }
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(dvfix) + j * D + c;
+            unsigned long long* lo = lacc + (slot < 0 ? 0 : slot) * D + c;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const float vj = v[j * D + c + LPR * e];
-            acc[e] += g * (vj - ui[e]);
-            const float dvj = g * (ui[e] - vj);
-            const long long q = dv_fix_term(dvj, fix_scale, fix_clamp);
-            atomicAdd(o + LPR * e, (unsigned long long)q);       // two's complement: the unsigned add IS the signed add
+            for (int e = 0; e < NE; ++e) {
+                const float vj = v[j * D + c + LPR * e];
+                acc[e] += g * (vj - ui[e]);
+                const float dvj = g * (ui[e] - vj);
+                const long long q = dv_fix_term(dvj, fix_scale, fix_clamp);
+                if (slot >= 0) atomicAdd(lo + LPR * e, (unsigned long long)q);      // two's complement: the unsigned add IS the signed add
+                else if (s >= 0) atomicAdd(o + LPR * e, (unsigned long long)q);
+                // (s < 0, the user's own column: ONE such term per column -- dv_fix_to_f32_kernel adds it, no atomic at all)
+            }
         }
-    }
 #pragma unroll
-    for (int e = 0; e < NE; ++e) du[i * D + c + LPR * e] = acc[e];
+        for (int e = 0; e < NE; ++e) du[i * D + c + LPR * e] = acc[e];
+    }
+    __syncthreads();
+    // flush: one global atomic per occupied slot and feature (zeros are skipped)
+    for (int q = threadIdx.x; q < L::SLOTS * D; q += 1024) {
+        const int slot = q / D, f = q % D;
+        const int j = lkey[slot];
+        const unsigned long long val = lacc[q];
+        if (j >= 0 && val != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(dvfix) + (int64_t)j * D + f, val);
+    }
 }
 
+// fixed point -> fp32, and the diagonal terms on the way: column j < B also receives gd_j (u_j - v_j) -- one term per column,
+// the same integer the backward kernel used to add atomically
 __global__ __launch_bounds__(256) void dv_fix_to_f32_kernel(const long long* __restrict__ dvfix, int64_t n, float* __restrict__ dv,
-                                                            const float* __restrict__ dvsc) {
+                                                            const float* __restrict__ dvsc, const float* __restrict__ u,
+                                                            const float* __restrict__ v, const float* __restrict__ rowc,
+                                                            const float* __restrict__ grad_out, int64_t B, int64_t Bp, int d) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
-    dv[t] = (float)((double)dvfix[t] * (double)dvsc[2]);
+    long long acc = dvfix[t];
+    const int64_t j = t / d;
+    if (j < B) {
+        const float gd = grad_out[0] * rowc[3 * Bp + j];
+        acc += dv_fix_term(gd * (u[t] - v[t]), dvsc[0], dvsc[1]);
+    }
+    dv[t] = (float)((double)acc * (double)dvsc[2]);
 }
 
 // ------------------------------------------------------------------ C ABI ------
@@ -1718,10 +1770,10 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
         dv_scale_kernel<<<dim3(1), 1024, 0, s>>>(w.rowc, grad_out, w.nu, w.nv, B, N, w.Bp, w.dvsc);
         MF_DISPATCH_D(d, {
             const int64_t nthreads = B * 32;
-            mined_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, w.sel, w.sel_cnt, w.sel_L, grad_out, B,
-                                                                                        w.Bp, gmode, du, w.dvfix, w.dvsc);
+            mined_bwd_kernel<D><<<dim3((unsigned)((nthreads + 1023) / 1024)), 1024, MinedBwdLds<D>::BYTES, s>>>(u, v, w.rowc, w.sel, w.sel_cnt, w.sel_L,
+                                                                                                              grad_out, B, w.Bp, gmode, du, w.dvfix, w.dvsc);
         });
-        dv_fix_to_f32_kernel<<<dim3((unsigned)((N * d + 255) / 256)), 256, 0, s>>>(w.dvfix, N * d, dv, w.dvsc);
+        dv_fix_to_f32_kernel<<<dim3((unsigned)((N * d + 255) / 256)), 256, 0, s>>>(w.dvfix, N * d, dv, w.dvsc, u, v, w.rowc, grad_out, B, w.Bp, d);
     } else {
         if ((size_t)w.tps_u * 32 * d * 4 > MF_SRD_MAX_BYTES || (size_t)w.tps_v * 32 * d * 4 > MF_SRD_MAX_BYTES)
             return mf_set_error(MF_ENOTSUP, "mf_loss_bwd: a sweep's share of the batch exceeds 4 GiB (buffer descriptor)");
