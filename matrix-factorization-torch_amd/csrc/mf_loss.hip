@@ -1319,7 +1319,13 @@ __global__ __launch_bounds__(256) void diag_bwd_kernel(const float* __restrict__
 // one atomic instruction covers 256 contiguous bytes of a row.
 __global__ __launch_bounds__(1024) void dv_scale_kernel(const float* __restrict__ rowc, const float* __restrict__ grad_out,
                                                         const float* __restrict__ nu, const float* __restrict__ nv, int64_t B, int64_t N,
-                                                        int64_t Bp, float* __restrict__ dvsc) {
+                                                        int64_t Bp, float* __restrict__ dvsc, uint4* __restrict__ zero16, int64_t n16) {
+    // (blocks 1 .. clear the fixed-point accumulator: one launch instead of two)
+    if (blockIdx.x > 0) {
+        const int64_t stride = (int64_t)(gridDim.x - 1) * 1024;
+        for (int64_t q = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; q < n16; q += stride) zero16[q] = uint4{0u, 0u, 0u, 0u};
+        return;
+    }
     // (maxima of magnitudes as unsigned bit patterns: exact, order-free, and the same rule as the one-launch step's)
     __shared__ unsigned red[3][16];
     const int tid = threadIdx.x, lane = mf_lane(), wave = mf_wave_id();
@@ -1766,8 +1772,12 @@ extern "C" int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives
             diag_bwd_kernel<D><<<dim3((unsigned)((nthreads + 255) / 256)), 256, 0, s>>>(u, v, w.rowc, grad_out, B, N, w.Bp, du, dv);
         });
     } else if (w.mined) {
-        mf_zero_async(w.dvfix, (size_t)N * d * 8, s);
-        dv_scale_kernel<<<dim3(1), 1024, 0, s>>>(w.rowc, grad_out, w.nu, w.nv, B, N, w.Bp, w.dvsc);
+        {
+            const int64_t n16 = N * d * 8 / 16;              // (d is a multiple of 32: whole 16-byte units)
+            int64_t zb = (n16 + 1023) / 1024;
+            if (zb > 1024) zb = 1024;
+            dv_scale_kernel<<<dim3((unsigned)(1 + zb)), 1024, 0, s>>>(w.rowc, grad_out, w.nu, w.nv, B, N, w.Bp, w.dvsc, reinterpret_cast<uint4*>(w.dvfix), n16);
+        }
         MF_DISPATCH_D(d, {
             const int64_t nthreads = B * 32;
             mined_bwd_kernel<D><<<dim3((unsigned)((nthreads + 1023) / 1024)), 1024, MinedBwdLds<D>::BYTES, s>>>(u, v, w.rowc, w.sel, w.sel_cnt, w.sel_L,
