@@ -552,7 +552,7 @@ template <int D>
 struct MineRescoreGeom {
     static constexpr int CPR = D / 4;                   // 16-byte chunks of an fp32 row
     static constexpr int RPI = 64 / CPR;                // rows per DMA instruction
-    static constexpr int RB = 32;                       // candidates per round (a user has ~20)
+    static constexpr int RB = 8;                        // candidates per round (a user has ~20: three rounds; LDS is this kernel's occupancy limit -- 32 per round: 69 us)
     static constexpr int NI = RB / RPI;
     static constexpr int LMAX = MBF_MAXLISTS * MBF_CAPL + MBF_SPILL;
     static constexpr int KEYS = LMAX + 8;                // (+ the stand-in of a masked diagonal)
