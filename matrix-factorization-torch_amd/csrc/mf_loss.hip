@@ -1672,9 +1672,15 @@ static int loss_fwd_impl(const char* what, int64_t B, int64_t N, int d, const Po
                       B, N, w.Bp, w.Np, d, sigma, w.nu, w.nv, w.lii, w.dii, w.sgn, w.logq, w.tgt,
                       nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, w.ticket};
         int nb = (int)((w.Np + 63) / 64);
-        if (scores_needed && !masks_ready) {
-            prep_clears(pp, w);
-            const int64_t want = (pp.gtab16 + pp.gfirst16 + pp.bmap16 + 64 * 8 - 1) / (64 * 8);       // ~8 stores per thread
+        if (scores_needed && !masks_ready) prep_clears(pp, w);
+        if (scores_needed && w.mined) {
+            // the mined path's counters and bounds (gtau .. cand_cnt, and behind them the prefilter's maxima, copy bitmaps, spill
+            // cursors and gate: one contiguous range of the workspace) are cleared here too -- it used to be a launch of its own
+            pp.ubits = reinterpret_cast<uint4*>(w.gtau);
+            pp.ubits16 = (int64_t)(((char*)(w.mbf.ok ? (void*)(w.mbf_gate + 4) : (void*)(w.mbf_max + MBF_MAXSLOTS * MBF_MAXSTRIDE)) - (char*)w.gtau) / 16);
+        }
+        {
+            const int64_t want = (pp.gtab16 + pp.gfirst16 + pp.ubits16 + pp.bmap16 + 64 * 8 - 1) / (64 * 8);       // ~8 stores per thread
             if (want > nb) nb = (int)(want < 8192 ? want : 8192);
         }
         MF_DISPATCH_D(d, { prep_kernel<D><<<dim3((unsigned)nb), 64, 0, s>>>(pp); });
@@ -1706,7 +1712,7 @@ static int loss_fwd_impl(const char* what, int64_t B, int64_t N, int d, const Po
     } else if (scores_needed) {
         MiningPolicy::Params mp{w.nu, w.nv, w.lii, w.sgn, logq_p, w.maskW, w.Bp, N, sigma};
         SelectCommon sc{u, B, v, N, 0, (int)((N + 31) / 32), w.plan.tpc, w.Bp, num_negatives, w.plan.xw, w.gtau, w.priv, w.cand, w.cand_cnt, w.plan.rowcap};
-        mf_zero_async(w.gtau, (size_t)((char*)(w.mbf.ok ? (void*)(w.mbf_gate + 4) : (void*)(w.mbf_max + MBF_MAXSLOTS * MBF_MAXSTRIDE)) - (char*)w.gtau), s);
+        // (gtau, cand_cnt and the prefilter's cleared range: prep_kernel did it)
         MinedRowParams mr{w.cand, w.cand_cnt, w.plan.rowcap, num_negatives, u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, B, w.Bp, d,
                           sigma, margin, need, w.sel, w.sel_cnt, w.sel_L, w.stats, nullptr};
         if (w.mbf.ok && mine_bf_enabled() && w.plan.YTa > 0 && w.plan.rowcap >= num_negatives) {
