@@ -1546,22 +1546,25 @@ static unsigned long long* g_mine_dbg = nullptr;
 #define MBF_TIMED(name, s, ...) do { __VA_ARGS__; } while (0)
 #endif
 template <int D>
-static void mine_bf_launch(const LossWs& w, const MinedRowParams& fin, const float* u, const float* v, int64_t B, int64_t N, int k, float sigma, hipStream_t s) {
+static void mine_bf_prepare(const LossWs& w, const float* u, const float* v, int64_t B, int64_t N, float sigma, hipStream_t s) {
     const MineBfPlan& m = w.mbf;
     int lab_abl = 0;
 #ifdef MF_BF3_LAB
     if (const char* e = getenv("MF_MBF_ABL")) lab_abl = atoi(e);
 #endif
+    const int item_blocks = (int)((m.Nq * (D / 8) + 255) / 256), user_blocks = (int)((m.Xq * (D / 8) + 255) / 256);
+    MineUserFrags uf{u, w.sgn, B, m.Xq, sigma, static_cast<mbf16x8*>(w.mbf_ufrag)};
+    MBF_TIMED("mining_items", s, (mine_items_kernel<D><<<dim3((unsigned)(item_blocks + user_blocks)), 256, 0, s>>>(
+        v, w.nv, w.logq, w.colfirst, N, m.Nq, sigma, w.mbf_plane, w.mbf_max, w.mbf_rep, w.mbf_copybits, w.mbf_lastcopy,
+        __builtin_ctz((unsigned)m.blk), lab_abl, item_blocks, uf)));
+}
+template <int D>
+static void mine_bf_launch(const LossWs& w, const MinedRowParams& fin, const float* u, const float* v, int64_t B, int64_t N, int k, float sigma, hipStream_t s) {
+    const MineBfPlan& m = w.mbf;
     {
-        const int64_t threads = m.Nq * (D / 8);
-        MBF_TIMED("mining_items", s, (mine_items_kernel<D><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(v, w.nv, w.logq, w.colfirst, N, m.Nq, sigma, w.mbf_plane, w.mbf_max,
-                                                                               w.mbf_rep, w.mbf_copybits, w.mbf_lastcopy, __builtin_ctz((unsigned)m.blk), lab_abl)));
-    }
-    {
-        MineUsers mu{u, w.nu, w.lii, w.sgn, w.gtau, w.mbf_max, B, m.Xq, sigma, static_cast<mbf16x8*>(w.mbf_ufrag),
-                     static_cast<f32x4*>(w.mbf_rowk), w.mbf_flag, w.mbf_gate, g_mine_dbg};
-        const int64_t threads = m.Xq * (D / 8);
-        MBF_TIMED("mining_users", s, (mine_users_kernel<D, MiningPolicy><<<dim3((unsigned)((threads + 255) / 256)), 256, 0, s>>>(mu)));
+        MineBound mb{w.seeds, w.plan.seeds_per_row, k, w.nu, w.lii, w.sgn, w.mbf_max, B, m.Xq, sigma, w.gtau, static_cast<f32x4*>(w.mbf_rowk),
+                     w.mbf_flag, w.mbf_gate, g_mine_dbg};
+        MBF_TIMED("mining_bound", s, (mine_bound_kernel<D, MiningPolicy><<<dim3((unsigned)(m.Xq / 4)), 256, 0, s>>>(mb)));
     }
     {
         MineScan ms{w.mbf_plane, m.Nq, m.NT, m.tpc, static_cast<const mbf16x8*>(w.mbf_ufrag), static_cast<const f32x4*>(w.mbf_rowk), m.Xq,
@@ -1594,7 +1597,10 @@ static int mine_bf_run(const LossWs& w, const MiningPolicy::Params& mp, const Se
     const bool whole = mf_timing_on();
 #endif
     if (whole) mf_timing_begin("mining_prefilter", s);
-    MF_DISPATCH_D(d, { MBF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s, true))); });
+    // item plane + user fragments (one launch) -> fp32 seeding pass -> bound + intervals (one launch) -> scan -> rescoring
+    if (d == 64) mine_bf_prepare<64>(w, u, v, B, N, sigma, s);
+    else mine_bf_prepare<128>(w, u, v, B, N, sigma, s);
+    MF_DISPATCH_D(d, { MBF_TIMED("mining_select", s, (mf_select_run<D, MiningPolicy>(w.plan, mp, sc, w.seeds, B, s, true, false, true))); });
     if (d == 64) mine_bf_launch<64>(w, fin, u, v, B, N, k, sigma, s);
     else mine_bf_launch<128>(w, fin, u, v, B, N, k, sigma, s);
     // behind it, gated on the device: a batch the prefilter gave up on (a spill list overflowed -- thousands of exact ties --,

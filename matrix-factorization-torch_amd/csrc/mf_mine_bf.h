@@ -21,7 +21,7 @@
 // MiningPolicy::key does; the row lists that come out feed mined_rows_kernel unchanged.  A user whose lists overflow (all
 // scores equal, a zero target, non-finite inputs) is answered by its rescoring wave walking the whole row exactly.
 //
-// Error bound (mine_users_kernel).  With P = |as| |u_i| max|v|, W = sigma max|v|^2 / 2, Q = max |lqn|, and
+// Error bound (mine_bound_kernel).  With P = |as| |u_i| max|v|, W = sigma max|v|^2 / 2, Q = max |lqn|, and
 // S = 1.01 P + W + Q + |rho| >= the sum of the absolute values of everything one accumulator adds up (nt = 3 d + 16 terms):
 //   * the matrix core's fp32 accumulation, any order, any grouping: <= nt 2^-23 S (twice the round-to-nearest bound);
 //   * the dropped products and the rounding of as u:                 <= 3.1 2^-18 P;
@@ -107,6 +107,40 @@ __device__ __forceinline__ void mbf_split3(float x, unsigned short (&o)[3]) {
     o[2] = mbf_round(r2);
 }
 
+// ------------------------------------------------------- user fragments ----
+// as u (as = sigma sign(target)) split in two bf16 numbers, in MFMA operand order (hi steps, then lo steps); one thread per
+// (user, 8 elements); users past B: zeros
+struct MineUserFrags {
+    const float *u, *sgn;
+    int64_t B, Xq;
+    float sigma;
+    mbf16x8* ufrag;          // [Xq / 32][2 KS][64]
+};
+template <int D>
+__device__ __forceinline__ void mine_user_frags(const MineUserFrags& p, int64_t t) {
+    constexpr int LPR = D / 8, KS = D / 16;
+    const int64_t x = t / LPR;
+    const int j = (int)(t % LPR);
+    if (x >= p.Xq) return;
+    const bool real = x < p.B;
+    const float as = p.sigma * (real ? p.sgn[x] : 0.f);
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    u16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
+    if (real) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(p.u + x * D)[2 * j], b = reinterpret_cast<const f32x4*>(p.u + x * D)[2 * j + 1];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float y = as * (i < 4 ? a[i] : b[i - 4]);
+            hi[i] = mbf_round(y);
+            lo[i] = mbf_round(y - mbf_float(hi[i]));
+        }
+    }
+    const int step = j >> 1, h = j & 1;
+    mbf16x8* f = p.ufrag + ((x >> 5) * (2 * KS)) * 64 + (x & 31) + 32 * h;
+    f[step * 64] = __builtin_bit_cast(mbf16x8, hi);
+    f[(KS + step) * 64] = __builtin_bit_cast(mbf16x8, lo);
+}
+
 // ------------------------------------------------------------- item plane ----
 // One d/8-lane group per item: [hi d | lo d | aug 16] bf16, plus the maxima the error bound needs.
 //
@@ -122,7 +156,12 @@ __global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict
                                                          const float* __restrict__ lqn, const int32_t* __restrict__ colfirst,
                                                          int64_t N, int64_t Nq, float sigma, unsigned short* __restrict__ plane,
                                                          unsigned* __restrict__ maxima, int32_t* __restrict__ rep,
-                                                         unsigned long long* __restrict__ copybits, int32_t* __restrict__ lastcopy, int blk_shift, int abl) {
+                                                         unsigned long long* __restrict__ copybits, int32_t* __restrict__ lastcopy, int blk_shift, int abl,
+                                                         int item_blocks, MineUserFrags uf) {
+    if ((int)blockIdx.x >= item_blocks) {                     // (the same launch converts the users' rows: blocks behind the items')
+        mine_user_frags<D>(uf, (int64_t)(blockIdx.x - item_blocks) * 256 + threadIdx.x);
+        return;
+    }
     constexpr int LPR = D / 8, RW = 2 * D + 16;
     const int lane = mf_lane();
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -213,61 +252,61 @@ __global__ __launch_bounds__(256) void mine_items_kernel(const float* __restrict
     }
 }
 
-// ------------------------------------------------------- user fragments ----
-// as u in MFMA operand order (hi steps, then lo steps), and per user {half, rho, s}: the interval test of the scan
-struct MineUsers {
-    const float *u, *nu, *lii, *sgn;
-    const unsigned* gtau;
+// --------------------------------------------- bound, interval, row constants ----
+// One wave per user, behind the fp32 seeding pass: its starting bound from its seed keys exactly as select_bound_kernel
+// (mf_select.h) finds it -- every lane reduces its share of the seeds to its best, the k-th largest of the 64 lane maxima by rank
+// counting -- and, in the same launch, what the scan needs of it: the interval of Dm the bound admits
+// (Policy::make_thr), its centre folded into rho, the error bound eps of the header, half = half width + eps.
+struct MineBound {
+    const unsigned long long* seeds;
+    int seeds_per_row, k;
+    const float *nu, *lii, *sgn;
     const unsigned* maxima;
     int64_t B, Xq;
     float sigma;
-    mbf16x8* ufrag;          // [Xq / 32][2 KS][64]
+    unsigned* gtau;          // [Bp]: the rank bound (the fp32 fallback search starts from it)
     f32x4* rowk;             // [Xq]: {half, rho, s, eps}
     int32_t* rowflag;        // [Xq]: 1 = a zero target: the rescoring wave walks the row (Dm does not depend on the embeddings)
     int32_t* gate;           // set: this batch is not for the prefilter (the fp32 search runs behind it)
     unsigned long long* dbg; // lab: [3] += no bound, [4] += non-finite, [5] += zero targets (NULL: off)
 };
 template <int D, class Policy>
-__global__ __launch_bounds__(256) void mine_users_kernel(MineUsers p) {
-    constexpr int LPR = D / 8, KS = D / 16;
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t x = t / LPR;
-    const int j = (int)(t % LPR);
-    if (x >= p.Xq) return;
+__global__ __launch_bounds__(256) void mine_bound_kernel(MineBound p) {
+    __shared__ unsigned lane_best[4][64];
+    const int lane = mf_lane(), wv = threadIdx.x >> 6;
+    const int64_t x = (int64_t)blockIdx.x * 4 + wv;           // (the grid covers Xq: a multiple of 4)
     const bool real = x < p.B;
-    const float s = real ? p.sgn[x] : 0.f;
-    const float as = p.sigma * s;
-    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-    u16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
+    unsigned best = 0u;
     if (real) {
-        const f32x4 a = reinterpret_cast<const f32x4*>(p.u + x * D)[2 * j], b = reinterpret_cast<const f32x4*>(p.u + x * D)[2 * j + 1];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float y = as * (i < 4 ? a[i] : b[i - 4]);
-            hi[i] = mbf_round(y);
-            lo[i] = mbf_round(y - mbf_float(hi[i]));
-        }
+        const unsigned long long* src = p.seeds + x * (int64_t)p.seeds_per_row;
+        for (int i = lane; i < p.seeds_per_row; i += 64) best = max(best, (unsigned)(src[i] >> 32));
     }
-    const int step = j >> 1, h = j & 1;
-    mbf16x8* f = p.ufrag + ((x >> 5) * (2 * KS)) * 64 + (x & 31) + 32 * h;
-    f[step * 64] = __builtin_bit_cast(mbf16x8, hi);
-    f[(KS + step) * 64] = __builtin_bit_cast(mbf16x8, lo);
-    if (j != 0) return;
-    float nvmax_f = 0.f, qmax_f = 0.f;
-    {
-        unsigned a = 0u, b = 0u;                             // (16 pairs, L2-resident; non-negative floats order like their bits, NaN above all)
-        for (int i = 0; i < MBF_MAXSLOTS; ++i) { a = max(a, p.maxima[MBF_MAXSTRIDE * i]); b = max(b, p.maxima[MBF_MAXSTRIDE * i + 1]); }
-        nvmax_f = __builtin_bit_cast(float, a);
-        qmax_f = __builtin_bit_cast(float, b);
+    lane_best[wv][lane] = best;
+    __syncthreads();
+    int above = 0;                    // lanes whose maximum beats mine (ties broken by lane: a strict order)
+    for (int q = 0; q < 64; ++q) {
+        const unsigned o = lane_best[wv][q];
+        above += (o > best || (o == best && q < lane)) ? 1 : 0;
     }
-    float half = -1.f, rho = 0.f, eps = 0.f;
+    const bool is_kth = real && above == p.k - 1 && best != 0u;
+    if (is_kth) p.gtau[x] = best;
+    const unsigned long long kb = __ballot(is_kth);
+    const unsigned bound = kb ? (unsigned)__shfl((int)best, __builtin_ctzll(kb), 64) : 0u;     // (0: fewer than k seeds in sight)
+    // the maxima the item launch left (16 pairs of words a cache line apart; non-negative floats order like their bits, NaN above all)
+    const int mi = lane & (MBF_MAXSLOTS - 1);
+    const float nvmax_f = __builtin_bit_cast(float, mf_wave_max_u32(p.maxima[MBF_MAXSTRIDE * mi]));
+    const float qmax_f = __builtin_bit_cast(float, mf_wave_max_u32(p.maxima[MBF_MAXSTRIDE * mi + 1]));
+    if (lane != 0) return;
+    float half = -1.f, rho = 0.f, eps = 0.f, s = 0.f;
     int flag = 0;
     if (real) {
+        s = p.sgn[x];
+        const float as = p.sigma * s;
         const double nvmax = (double)nvmax_f, Q = (double)qmax_f;
         const double nu = (double)p.nu[x], li = (double)p.lii[x], sg = (double)p.sigma, aas = fabs((double)as);
         const double P = aas * sqrt(nu * nvmax), W = 0.5 * fabs(sg) * nvmax, Hn = 0.5 * aas * nu;
         const double M = P + Hn + W + Q + fabs(li);
-        const typename Policy::Thr th = Policy::make_thr(p.gtau[x]);
+        const typename Policy::Thr th = Policy::make_thr(bound);
         const bool none = th.lo > th.hi;                                   // (thr_none: cannot happen for a real row; nothing passes)
         double lo_ = (double)th.lo, hi_ = (double)th.hi;
         const double big = 1.01 * M + 1e-30;
@@ -286,7 +325,7 @@ __global__ __launch_bounds__(256) void mine_users_kernel(MineUsers p) {
         half = (float)hf;
         if ((double)half < hf) half = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, half) + 1u);     // (positive, finite: the next float up)
         if (none) half = -1.f;
-        if ((p.gtau[x] >> 30) == 0u) { half = -1.f; *p.gate = 1; if (p.dbg) atomicAdd(p.dbg + 3, 1ull); }            // no bound (fewer than k seeds in sight): every column would pass
+        if ((bound >> 30) == 0u) { half = -1.f; *p.gate = 1; if (p.dbg) atomicAdd(p.dbg + 3, 1ull); }            // no bound (fewer than k seeds in sight): every column would pass
         if (!(hf < 1e37) || !(M < 1e37)) { half = -1.f; *p.gate = 1; if (p.dbg) atomicAdd(p.dbg + 4, 1ull); }        // non-finite inputs
         if (s == 0.f) { half = -1.f; flag = 1; if (p.dbg) atomicAdd(p.dbg + 5, 1ull); }                           // a zero target: Dm does not depend on the embeddings -- the exact walk is cheap
     }

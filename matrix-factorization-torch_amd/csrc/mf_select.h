@@ -681,7 +681,8 @@ static void mf_select_seed_t(const typename Policy::Params& pp, const SelectComm
 // cand_cnt zeroed; `seeds`: [Xp][plan.seeds_per_row] scratch
 template <int D, class Policy>
 static void mf_select_run(const SelectPlan& plan, const typename Policy::Params& pp, SelectCommon sc,
-                          unsigned long long* seeds, int64_t nX, hipStream_t s, bool seed_only = false, bool main_only = false) {
+                          unsigned long long* seeds, int64_t nX, hipStream_t s, bool seed_only = false, bool main_only = false,
+                          bool no_bound = false) {
     if (plan.YTa > 0 && !main_only) {
         sc.t_begin = 0; sc.t_end = plan.YTa; sc.tiles_per_chunk = plan.tpcA;
         sc.tstride = MF_SEED_DIV;                       // tile t of the sample is tile MF_SEED_DIV t (YTa = YT / MF_SEED_DIV)
@@ -694,7 +695,8 @@ static void mf_select_run(const SelectPlan& plan, const typename Policy::Params&
             case 16: mf_select_seed_t<D, 16, Policy>(pp, sc, seeds, plan.seeds_per_row, plan.nchunkA, plan.gx, s); break;
             default: mf_select_seed_t<D, 32, Policy>(pp, sc, seeds, plan.seeds_per_row, plan.nchunkA, plan.gx, s); break;
         }
-        select_bound_kernel<0><<<dim3((unsigned)((nX + 3) / 4)), 256, 0, s>>>(seeds, plan.seeds_per_row, sc.k, nX, sc.gtau);
+        if (!no_bound)       // (mf_mine_bf.h finds the bound in a launch of its own that also prepares the scan's intervals)
+            select_bound_kernel<0><<<dim3((unsigned)((nX + 3) / 4)), 256, 0, s>>>(seeds, plan.seeds_per_row, sc.k, nX, sc.gtau);
     }
     if (seed_only) return;          // (mf_mine_bf.h: the bound is all the prefilter wants from here)
     sc.tstride = 1;
