@@ -361,12 +361,12 @@ def train_roofline(spans: dict, batch: int, dim: int, world: int, optimizer: str
     ach = flops / (sweeps[dom] * 1e-3) / 1e12
     if dom == "mining_prefilter":
         # The mined losses' candidate search through the split-bf16 prefilter (csrc/mf_mine_bf.h): ONE event pair spans its
-        # launches -- fp32 seeding pass over 1/8 of the columns + bound, item plane, user fragments, the scan on the bf16 cores
+        # launches -- item plane + user fragments, fp32 seeding pass over 1/8 of the columns, bound + intervals, the scan on the bf16 cores
         # (three bf16 products per fp32 product + one augmented k-step: 3 + 16/d of the algorithmic flops are EXECUTED), exact
         # rescoring.  `achieved` counts the ALGORITHMIC 2 B N d only and is priced against the bf16 peak, the pipe the dominant
         # kernel runs on; `of_fp32_mfma_peak` is the same figure against the peak an all-fp32 search is bounded by.
         execd = (3.0 + 16.0 / dim) * ach
-        out = {"kernel": "select_seed_kernel + select_bound_kernel + mine_items/users_kernel + mine_scan_kernel + mine_rescore_kernel",
+        out = {"kernel": "mine_items_kernel + select_seed_kernel + mine_bound_kernel + mine_scan_kernel + mine_rescore_kernel",
                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None, "avg_ms": round(sweeps[dom], 4),
                "mfma_dtype": "bf16 x3 split (fp32 accumulate), exact fp32 rescoring", "executed_mfma_frac": round(execd / PEAK_BF16_MFMA_TFLOPS, 4),
