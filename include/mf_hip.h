@@ -172,11 +172,12 @@ int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sig
                 const float* grad_out, float* du, float* dv, mf_stream_t stream);
 
 /* The candidate search of the mined losses (0 < num_negatives < N) has two implementations with IDENTICAL results: the fp32
- * streaming selection, and -- for d in {64, 128}, B >= 256, N >= 2048, num_negatives <= 32 -- a split-bf16 prefilter on the
- * bf16 matrix cores with exact fp32 rescoring of the few columns that pass (csrc/mf_mine_bf.h).  The prefilter is the default
- * where it applies; mf_set_mining_prefilter(0) (or MF_MINE_BF=0 in the environment) selects the fp32 search everywhere --
- * what the parity tests use to compare the two.  Process-wide; not a per-stream setting. */
-void mf_set_mining_prefilter(int on);
+ * streaming selection, and a split-bf16 prefilter on the bf16 matrix cores with exact fp32 rescoring of the few columns that
+ * pass (csrc/mf_mine_bf.h; it can serve d in {64, 128}, B >= 256, N >= 2048, num_negatives <= 32).  mode 1 (default): the
+ * prefilter where it is the faster one (B >= 4096, num_negatives <= 8); mode 2: wherever it can serve (what the parity tests use
+ * to compare the two on small shapes); mode 0: the fp32 search everywhere.  MF_MINE_BF=0|1|2 in the environment sets the initial
+ * mode.  Process-wide; not a per-stream setting. */
+void mf_set_mining_prefilter(int mode);
 
 /* API parity with the public helper methods of EmbeddingLoss, on caller-provided tensors (not the
  * hot path): negative_masks (losses.py:92-110) -> out_mask[B,N] bytes, 1 = valid negative;

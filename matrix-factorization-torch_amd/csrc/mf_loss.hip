@@ -1624,8 +1624,8 @@ extern "C" int mf_probe_mining_prefilter(unsigned long long* out3, int enable) {
     g_mine_dbg = enable ? buf : nullptr;
     return 0;
 }
-// tests / tools: 1 = prefilter on (default), 0 = select_kernel only
-extern "C" void mf_set_mining_prefilter(int on) { g_mine_bf_mode = on ? 1 : 0; }
+// 1 = the prefilter where it pays (default), 2 = wherever it can serve (tests), 0 = select_kernel only
+extern "C" void mf_set_mining_prefilter(int mode) { g_mine_bf_mode = mode <= 0 ? 0 : (mode >= 2 ? 2 : 1); }
 
 static int pos_src_check(const char* what, const PosSrc& src) {
     if (src.pos_off) {
@@ -1721,7 +1721,7 @@ static int loss_fwd_impl(const char* what, int64_t B, int64_t N, int d, const Po
         // (gtau, cand_cnt and the prefilter's cleared range: prep_kernel did it)
         MinedRowParams mr{w.cand, w.cand_cnt, w.plan.rowcap, num_negatives, u, v, w.nu, w.nv, w.lii, w.sgn, logq_p, B, w.Bp, d,
                           sigma, margin, need, w.sel, w.sel_cnt, w.sel_L, w.stats, nullptr};
-        if (w.mbf.ok && mine_bf_enabled() && w.plan.YTa > 0 && w.plan.rowcap >= num_negatives) {
+        if (mine_bf_use(w.mbf) && w.plan.YTa > 0 && w.plan.rowcap >= num_negatives) {
             // (the rescoring waves finish their users themselves; mined_rows_kernel behind them only runs for a batch handed
             // to the fp32 search)
             if (int rc2 = mine_bf_run(w, mp, sc, mr, u, v, B, N, d, num_negatives, sigma, s)) return rc2;

@@ -51,7 +51,8 @@ static constexpr int MBF_SPILL = 128;                   // entries of a user's s
 static constexpr int MBF_MAXLISTS = 32;                 // lists per user the rescoring wave gathers (one per lane; 32 x 16 keys of LDS)
 
 struct MineBfPlan {
-    bool ok;                // the shape is served by this path
+    bool ok;                // the shape CAN be served by this path (its arrays exist in the workspace)
+    bool pays;              // ... and is served by default: where it is faster than the fp32 search (measured, tools/lab/mined_shapes.py)
     int NT;                 // 32-row item tiles
     int64_t Xq, Nq;         // users padded to a workgroup's 512, items to a tile's 32
     int gy;                 // user blocks
@@ -78,18 +79,24 @@ static inline MineBfPlan mine_bf_plan(int64_t B, int64_t N, int d, int k) {
     p.nlists = 2 * p.nchunk;
     // (the seeding pass of mf_select_plan exists from 64 tiles on; below that, and for short batches, select_kernel is fast anyway)
     p.ok = (d == 64 || d == 128) && B >= 256 && N >= 2048 && k >= 1 && k <= 32 && (int64_t)p.tpc * 32 * p.rowb <= (int64_t)MF_SRD_MAX_BYTES;
+    // B = 8192, N = 16,384, d = 128 (us per step, prefilter / fp32 search): k = 4: 389 / 677, k = 8: 456 / 737; from k = 16 on the
+    // seed's bound admits more columns than the lists hold (~8 k per user) and the batch goes to the fp32 search anyway (969 /
+    // 850); at B = 2048 there are too few user blocks to fill the chip (196 / 187)
+    p.pays = p.ok && B >= 4096 && k <= 8;
     return p;
 }
 
-// run-time switch (tests compare the two candidate searches; MF_MINE_BF=0 in the environment turns the prefilter off)
+// run-time switch: 1 = the prefilter where it pays (default), 2 = wherever it can serve (tests and the stress compare the two
+// searches on small shapes), 0 = the fp32 search everywhere; MF_MINE_BF in the environment sets the initial value
 static int g_mine_bf_mode = -1;
-static inline bool mine_bf_enabled() {
+static inline int mine_bf_mode() {
     if (g_mine_bf_mode < 0) {
         const char* e = getenv("MF_MINE_BF");
-        g_mine_bf_mode = (e && e[0] == '0') ? 0 : 1;
+        g_mine_bf_mode = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
     }
-    return g_mine_bf_mode != 0;
+    return g_mine_bf_mode;
 }
+static inline bool mine_bf_use(const MineBfPlan& p) { return p.ok && (mine_bf_mode() == 2 || (mine_bf_mode() == 1 && p.pays)); }
 
 #ifdef __HIPCC__
 

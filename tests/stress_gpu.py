@@ -249,7 +249,7 @@ def mining_case():
     logq = None if ri(0, 1) else torch.log(torch.rand(n, generator=g) * 0.9 + 0.05)
     kind = ["PairwiseHingeLoss", "PairwiseLogisticLoss", "InfomationNoiseContrastiveEstimationLoss"][ri(0, 2)]
     res = []
-    for mode in (0, 1):
+    for mode in (0, 2):                                       # (2: the prefilter wherever it can serve)
         lib.mf_set_mining_prefilter(mode)
         mask = mf.losses.negative_mask(t["u"].to(dev), t["v"].to(dev), t["target"].to(dev), item_idx=t["item_idx"].to(dev),
                                        pos_idx=t["pos_idx"].to(dev), num_negatives=k, sigma=sigma).cpu()

@@ -1099,7 +1099,7 @@ def test_mined_masks_through_the_bf16_prefilter_are_bit_exact(mf, cfg, tied):
     try:
         lib.mf_set_mining_prefilter(0)
         plain = _mined_mask(mf, t, k, sigma)
-        lib.mf_set_mining_prefilter(1)
+        lib.mf_set_mining_prefilter(2)                  # (2: wherever it can serve -- these shapes are below the default's B >= 4096)
         got = _mined_mask(mf, t, k, sigma)
     finally:
         lib.mf_set_mining_prefilter(1)
@@ -1113,5 +1113,9 @@ def test_mined_masks_through_the_bf16_prefilter_are_bit_exact(mf, cfg, tied):
         lgq = chain.logits(t["u"].numpy(), t["v"].numpy(), t["target"].numpy(), sigma, logq.numpy())
         ref = float(ol.loss("PairwiseHingeLoss", t["u"], t["v"], t["target"], item_idx=t["item_idx"], pos_idx=t["pos_idx"], num_negatives=k,
                             sigma=sigma, margin=0.5, logq=logq, mining_logits=lgq))
-        val = _run_gpu(mf, "PairwiseHingeLoss", t, k, sigma, 0.5, logq)[0]
+        try:
+            lib.mf_set_mining_prefilter(2)
+            val = _run_gpu(mf, "PairwiseHingeLoss", t, k, sigma, 0.5, logq)[0]
+        finally:
+            lib.mf_set_mining_prefilter(1)
         assert abs(val - ref) <= gu.loss_tolerance(ref, sigma, t["target"].numpy()), (val, ref)

@@ -21,7 +21,7 @@ for (b, n, d, k, sigma) in ((512, 2560, 64, 4, 1.0), (300, 4100, 128, 7, 1.0)):
         want = float(ol.loss(kind, t["u"], t["v"], t["target"], item_idx=t["item_idx"], pos_idx=t["pos_idx"], num_negatives=k, sigma=sigma,
                              margin=0.5, logq=logq, mining_logits=lg))
         out = []
-        for mode in (0, 1):
+        for mode in (0, 2):
             lib.mf_set_mining_prefilter(mode)
             out.append(tp._run_gpu(mf, kind, t, k, sigma, 0.5, logq)[0])
         lib.mf_set_mining_prefilter(1)
