@@ -43,7 +43,7 @@ static constexpr int MBF_WAVES = 8;                     // waves per scan workgr
 static constexpr int MBF_XT = 2;                        // user tiles (32 users) a wave keeps in registers
 static constexpr int MBF_BLOCK = 2;                     // item tiles between two meeting points of the workgroup
 static constexpr int MBF_CAPL = 16;                     // entries a rescoring lane takes: a user's list of one chunk holds 2 MBF_CAPL
-static constexpr int MBF_HCAP = 512;                    // hits a scan wave buffers in LDS per chunk (64 users; ~80 are usual)
+static constexpr int MBF_HCAP = 2048;                   // hits a scan wave buffers in LDS per chunk (64 users; ~80 are usual at num_negatives = 4, ~1000 at 16)
 static constexpr int MBF_ROWS_WG = 32 * MBF_XT * MBF_WAVES;      // 512 users per workgroup
 static constexpr int MBF_MAXSLOTS = 16;                 // pairs of words the item kernel's blocks spread their maxima over ...
 static constexpr int MBF_MAXSTRIDE = 32;                // ... one cache line apart (in words)
@@ -79,10 +79,11 @@ static inline MineBfPlan mine_bf_plan(int64_t B, int64_t N, int d, int k) {
     p.nlists = 2 * p.nchunk;
     // (the seeding pass of mf_select_plan exists from 64 tiles on; below that, and for short batches, select_kernel is fast anyway)
     p.ok = (d == 64 || d == 128) && B >= 256 && N >= 2048 && k >= 1 && k <= 32 && (int64_t)p.tpc * 32 * p.rowb <= (int64_t)MF_SRD_MAX_BYTES;
-    // B = 8192, N = 16,384, d = 128 (us per step, prefilter / fp32 search): k = 4: 389 / 677, k = 8: 456 / 737; from k = 16 on the
-    // seed's bound admits more columns than the lists hold (~8 k per user) and the batch goes to the fp32 search anyway (969 /
-    // 850); at B = 2048 there are too few user blocks to fill the chip (196 / 187)
-    p.pays = p.ok && B >= 4096 && k <= 8;
+    // B = 8192, N = 16,384, d = 128 (us per step, prefilter / fp32 search): k = 4: 389 / 677, k = 8: 456 / 737, k = 16: 614 / 855
+    // (with 2048 hits buffered per wave and chunk; 512 overflowed there); at k = 32 the ~8 k columns per user the seed's bound
+    // admits no longer fit the lists and the batch goes to the fp32 search anyway (1591 / 1373); at B = 2048 there are too few
+    // user blocks to fill the chip (196 / 187)
+    p.pays = p.ok && B >= 4096 && k <= 16;
     return p;
 }
 
