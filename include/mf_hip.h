@@ -174,7 +174,7 @@ int mf_loss_bwd(int64_t B, int64_t N, int d, int P, int num_negatives, float sig
 /* The candidate search of the mined losses (0 < num_negatives < N) has two implementations with IDENTICAL results: the fp32
  * streaming selection, and a split-bf16 prefilter on the bf16 matrix cores with exact fp32 rescoring of the few columns that
  * pass (csrc/mf_mine_bf.h; it can serve d in {64, 128}, B >= 256, N >= 2048, num_negatives <= 32).  mode 1 (default): the
- * prefilter where it is the faster one (B >= 4096, num_negatives <= 16); mode 2: wherever it can serve (what the parity tests use
+ * prefilter where it is the faster one (B >= 4096); mode 2: wherever it can serve (what the parity tests use
  * to compare the two on small shapes); mode 0: the fp32 search everywhere.  MF_MINE_BF=0|1|2 in the environment sets the initial
  * mode.  Process-wide; not a per-stream setting. */
 void mf_set_mining_prefilter(int mode);

@@ -152,7 +152,7 @@ static LossWs loss_ws(void* base, int64_t B, int64_t N, int d, int P, int num_ne
             w.mbf_ufrag = a.take<char>((size_t)w.mbf.Xq * d * 4);
             w.mbf_rowk = a.take<char>((size_t)w.mbf.Xq * 16);
             w.mbf_flag = a.take<int32_t>((size_t)w.mbf.Xq);
-            w.mbf_plist = a.take<uint32_t>((size_t)w.mbf.nchunk * w.mbf.Xq * 2 * MBF_CAPL);
+            w.mbf_plist = a.take<uint32_t>((size_t)w.mbf.nchunk * w.mbf.Xq * w.mbf.lpc * MBF_CAPL);
             w.mbf_pcnt = a.take<uint32_t>((size_t)w.mbf.nchunk * w.mbf.Xq);
         }
         w.dpart = nullptr;
@@ -1568,7 +1568,7 @@ static void mine_bf_launch(const LossWs& w, const MinedRowParams& fin, const flo
     }
     {
         MineScan ms{w.mbf_plane, m.Nq, m.NT, m.tpc, static_cast<const mbf16x8*>(w.mbf_ufrag), static_cast<const f32x4*>(w.mbf_rowk), m.Xq,
-                    w.mbf_plist, w.mbf_pcnt, w.mbf_spill, w.mbf_spill_cnt, w.mbf_gate, g_mine_dbg, 0};
+                    w.mbf_plist, m.lpc * MBF_CAPL, w.mbf_pcnt, w.mbf_spill, w.mbf_spill_cnt, w.mbf_gate, g_mine_dbg, 0};
 #ifdef MF_BF3_LAB
         if (const char* e = getenv("MF_MBF_ABL")) ms.abl = atoi(e);
 #endif
@@ -1580,12 +1580,10 @@ static void mine_bf_launch(const LossWs& w, const MinedRowParams& fin, const flo
     }
     {
         MineRescore mr{u, v, w.nu, w.nv, w.lii, w.sgn, w.logq, w.maskW, B, w.Bp, N, m.Xq, sigma, m.nlists, k,
-                       w.mbf_plist, w.mbf_pcnt, w.mbf_flag, w.mbf_spill, w.mbf_spill_cnt, w.mbf_gate, w.mbf_rep, w.mbf_copybits, w.mbf_lastcopy, m.blk, w.cand, w.cand_cnt, w.plan.rowcap,
+                       m.lpc, MineRescoreGeom<D>::keys_cap(m.nlists), w.mbf_plist, w.mbf_pcnt, w.mbf_flag, w.mbf_spill, w.mbf_spill_cnt, w.mbf_gate, w.mbf_rep, w.mbf_copybits, w.mbf_lastcopy, m.blk, w.cand, w.cand_cnt, w.plan.rowcap,
                        g_mine_dbg};
         auto fn = mine_rescore_kernel<D, MinedRowFinish>;
-        const int bytes = MineRescoreGeom<D>::BYTES;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); attr = true; }
+        const int bytes = MineRescoreGeom<D>::bytes(m.nlists);      // (at most 8 KB rows + 9.3 KB keys + 1.5 KB: below the 64 KB that need no attribute)
         MBF_TIMED("mining_rescore", s, (fn<<<dim3((unsigned)w.Bp), 64, bytes, s>>>(mr, fin)));
     }
 }

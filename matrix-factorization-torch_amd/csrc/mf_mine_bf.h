@@ -42,13 +42,13 @@ typedef __bf16 mbf16x8 __attribute__((ext_vector_type(8)));
 static constexpr int MBF_WAVES = 8;                     // waves per scan workgroup, two per SIMD
 static constexpr int MBF_XT = 2;                        // user tiles (32 users) a wave keeps in registers
 static constexpr int MBF_BLOCK = 2;                     // item tiles between two meeting points of the workgroup
-static constexpr int MBF_CAPL = 16;                     // entries a rescoring lane takes: a user's list of one chunk holds 2 MBF_CAPL
+static constexpr int MBF_CAPL = 16;                     // entries a rescoring lane takes: a user's list of one chunk holds lpc x MBF_CAPL (lpc = 2, or 4 for num_negatives > 16)
 static constexpr int MBF_HCAP = 2048;                   // hits a scan wave buffers in LDS per chunk (64 users; ~80 are usual at num_negatives = 4, ~1000 at 16)
 static constexpr int MBF_ROWS_WG = 32 * MBF_XT * MBF_WAVES;      // 512 users per workgroup
 static constexpr int MBF_MAXSLOTS = 16;                 // pairs of words the item kernel's blocks spread their maxima over ...
 static constexpr int MBF_MAXSTRIDE = 32;                // ... one cache line apart (in words)
 static constexpr int MBF_SPILL = 128;                   // entries of a user's spill list: hits beyond a lane's 16 (more: the fp32 search answers the batch)
-static constexpr int MBF_MAXLISTS = 32;                 // lists per user the rescoring wave gathers (one per lane; 32 x 16 keys of LDS)
+static constexpr int MBF_MAXLISTS = 64;                 // lanes of the rescoring wave that take list entries (lpc per chunk, at most 16 chunks)
 
 struct MineBfPlan {
     bool ok;                // the shape CAN be served by this path (its arrays exist in the workspace)
@@ -57,7 +57,7 @@ struct MineBfPlan {
     int64_t Xq, Nq;         // users padded to a workgroup's 512, items to a tile's 32
     int gy;                 // user blocks
     int nchunk, tpc;        // item chunks (grid.x) and tiles per chunk
-    int nlists;             // 2 nchunk lists per user
+    int lpc, nlists;        // rescoring lanes per chunk (a chunk's list holds 16 lpc columns), lpc x nchunk lanes in all
     int rowb;               // bytes of an item's row in the plane: (2 d + 16) bf16
     int blk;                // columns per bit of a representative's copy bitmap (64 bits span the batch; a power of two >= 256)
 };
@@ -71,19 +71,20 @@ static inline MineBfPlan mine_bf_plan(int64_t B, int64_t N, int d, int k) {
     p.blk = 256;
     while ((int64_t)p.blk * 64 < p.Nq) p.blk *= 2;
     int want = (256 + p.gy - 1) / p.gy;                  // one workgroup per CU
-    if (want > MBF_MAXLISTS / 2) want = MBF_MAXLISTS / 2;
+    if (want > 16) want = 16;
     if (want < 1) want = 1;
     p.tpc = (p.NT + want - 1) / want;
     p.tpc = (p.tpc + MBF_BLOCK - 1) / MBF_BLOCK * MBF_BLOCK;
     p.nchunk = (p.NT + p.tpc - 1) / p.tpc;
-    p.nlists = 2 * p.nchunk;
+    p.lpc = k > 16 ? 4 : 2;                              // (~4 k columns per user pass at k = 32, most of them among the batch's first half)
+    p.nlists = p.lpc * p.nchunk;
     // (the seeding pass of mf_select_plan exists from 64 tiles on; below that, and for short batches, select_kernel is fast anyway)
     p.ok = (d == 64 || d == 128) && B >= 256 && N >= 2048 && k >= 1 && k <= 32 && (int64_t)p.tpc * 32 * p.rowb <= (int64_t)MF_SRD_MAX_BYTES;
-    // B = 8192, N = 16,384, d = 128 (us per step, prefilter / fp32 search): k = 4: 389 / 677, k = 8: 456 / 737, k = 16: 614 / 855
-    // (with 2048 hits buffered per wave and chunk; 512 overflowed there); at k = 32 the ~8 k columns per user the seed's bound
-    // admits no longer fit the lists and the batch goes to the fp32 search anyway (1591 / 1373); at B = 2048 there are too few
-    // user blocks to fill the chip (196 / 187)
-    p.pays = p.ok && B >= 4096 && k <= 16;
+    // B = 8192, N = 16,384, d = 128 (us per step, prefilter / fp32 search; profiles/r04_mined_shapes.log): k = 4: 389 / 677,
+    // k = 8: 456 / 737, k = 16: 614 / 855 (2048 hits buffered per wave and chunk; 512 overflowed there), k = 32: 1043 / 1142 (four
+    // rescoring lanes per chunk and a quarter-sample seed: ~150 columns per user are rescored); at B = 2048 there are too few user
+    // blocks to fill the chip (196 / 187)
+    p.pays = p.ok && B >= 4096;
     return p;
 }
 
@@ -349,7 +350,8 @@ struct MineScan {
     const mbf16x8* ufrag;
     const f32x4* rowk;
     int64_t Xq;
-    uint32_t* plist;                 // [nchunk][Xq][2 MBF_CAPL]: columns
+    uint32_t* plist;                 // [nchunk][Xq][lcap]: columns
+    int lcap;                        // 16 lpc
     uint32_t* pcnt;                  // [nchunk][Xq]
     uint32_t* spill;                 // [Xq][MBF_SPILL]: a user's hits beyond its lists
     int32_t* spill_cnt;              // [Xq], zeroed by the host
@@ -558,8 +560,8 @@ __global__ __launch_bounds__(64 * MBF_WAVES, 2) void mine_scan_kernel(MineScan p
                 const uint32_t colv = ent & 0xFFFFFFu;
                 const int at = (int)atomicAdd(cur + ul, 1u);
                 const int64_t xr = x0 + ul;
-                if (at < 2 * MBF_CAPL) {
-                    p.plist[((int64_t)chunk * p.Xq + xr) * (2 * MBF_CAPL) + at] = colv;
+                if (at < p.lcap) {
+                    p.plist[((int64_t)chunk * p.Xq + xr) * p.lcap + at] = colv;
                 } else {                                                           // (rare: the user's spill list, behind a global cursor)
                     const int sa = atomicAdd(p.spill_cnt + xr, 1);
                     if (sa < MBF_SPILL) p.spill[xr * MBF_SPILL + sa] = colv;
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(64 * MBF_WAVES, 2) void mine_scan_kernel(MineScan p
             }
         }
         mf_wave_sync();
-        p.pcnt[(int64_t)chunk * p.Xq + x0 + lane] = min(cur[lane], (uint32_t)(2 * MBF_CAPL));
+        p.pcnt[(int64_t)chunk * p.Xq + x0 + lane] = min(cur[lane], (uint32_t)p.lcap);
     }
 }
 
@@ -580,6 +582,7 @@ struct MineRescore {
     int64_t B, Bp, N, Xq;
     float sigma;
     int nlists, k;
+    int lpc, keys_cap;               // lanes per chunk; capacity of keys[] (16 nlists + MBF_SPILL + 8)
     const uint32_t* plist;
     const uint32_t* pcnt;
     const int32_t* rowflag;
@@ -602,8 +605,8 @@ struct MineRescoreGeom {
     static constexpr int RB = 8;                        // candidates per round (a user has ~20: three rounds; LDS is this kernel's occupancy limit -- 32 per round: 69 us)
     static constexpr int NI = RB / RPI;
     static constexpr int LMAX = MBF_MAXLISTS * MBF_CAPL + MBF_SPILL;
-    static constexpr int KEYS = LMAX + 8;                // (+ the stand-in of a masked diagonal)
-    static constexpr int BYTES = RB * D * 4 + KEYS * 8 + 2 * 64 * 8 + D * 4;      // rows | keys | win, sorted | the user's row
+    static constexpr int keys_cap(int nlists) { return nlists * MBF_CAPL + MBF_SPILL + 8; }      // (+ the stand-in of a masked diagonal)
+    static constexpr int bytes(int nlists) { return RB * D * 4 + keys_cap(nlists) * 8 + 2 * 64 * 8 + D * 4; }      // rows | keys | win, sorted | the user's row
 };
 
 // the exact key of (user, column) from the chain product -- MiningPolicy::key, word for word
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p, typenam
     const int lane = mf_lane();
     float* rows_lds = reinterpret_cast<float*>(fsm);
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(fsm + G::RB * D * 4);      // columns first, their keys later
-    unsigned long long* win = keys + G::KEYS;
+    unsigned long long* win = keys + p.keys_cap;
     unsigned long long* sorted = win + 64;
     float* xq = reinterpret_cast<float*>(sorted + 64);
     const int64_t x = blockIdx.x;
@@ -679,9 +682,10 @@ __global__ __launch_bounds__(64) void mine_rescore_kernel(MineRescore p, typenam
     const float nu = p.nu[x], lii = p.lii[x], s = p.sgn[x];
     const int flag = p.rowflag[x];
     const int nsp = min(p.spill_cnt[x], MBF_SPILL);
-    // (a user's list of chunk c is taken by lanes 2 c and 2 c + 1, sixteen entries each)
-    const int64_t lbase = ((int64_t)(lane >> 1) * p.Xq + x) * 2 + (lane & 1);
-    int nl = (lane < p.nlists && !flag) ? (int)p.pcnt[(int64_t)(lane >> 1) * p.Xq + x] - MBF_CAPL * (lane & 1) : 0;
+    // (a user's list of chunk c is taken by lanes lpc c .. lpc c + lpc - 1, sixteen entries each)
+    const int lch = lane / p.lpc, lsub = lane % p.lpc;
+    const int64_t lbase = ((int64_t)lch * p.Xq + x) * p.lpc + lsub;
+    int nl = (lane < p.nlists && !flag) ? (int)p.pcnt[(int64_t)lch * p.Xq + x] - MBF_CAPL * lsub : 0;
     nl = nl < 0 ? 0 : (nl > MBF_CAPL ? MBF_CAPL : nl);
     float xv[(D + 63) / 64];
 #pragma unroll

@@ -598,7 +598,8 @@ __global__ __launch_bounds__(256) void select_bound_kernel(const unsigned long l
 // geometry shared by the two users of select_kernel
 struct SelectPlan {
     int T, CAP, xw, nsub, gx, YT;
-    int YTa, tpcA, nchunkA;      // seeding pass: tiles [0, YTa) in nchunkA chunks (YTa = 0: none)
+    int YTa, tpcA, nchunkA;      // seeding pass: YTa sampled tiles (every seed_div-th) in nchunkA chunks (YTa = 0: none)
+    int seed_div;
     int seeds_per_row;           // nchunkA * nsub * 2 T seed keys per row
     int tpc, nchunk;             // main pass: all YT tiles
     int nsets;                   // lane-private list sets of the main pass
@@ -625,7 +626,10 @@ static inline SelectPlan mf_select_plan(int64_t nX, int64_t nY, int d, int k) {
 #ifndef MF_SEED_DIV
 #define MF_SEED_DIV 8      // A/B knob: the seeding pass scans 1 / MF_SEED_DIV of Y
 #endif
-    s.YTa = (s.YT >= 64) ? s.YT / MF_SEED_DIV : 0;
+    // (a quarter instead of an eighth of Y for k > 16: the bound is the k-th best of the sample, ~ the (k x seed_div)-th best of the
+    // row -- at k = 32 an eighth let ~8 k = 256 columns per row through)
+    s.seed_div = k > 16 ? MF_SEED_DIV / 2 : MF_SEED_DIV;
+    s.YTa = (s.YT >= 64) ? s.YT / s.seed_div : 0;
     if (s.YTa > 0) {
         int na = want < s.YTa / 4 ? want : s.YTa / 4;        // >= 4 tiles per chunk
         if (na < 1) na = 1;
@@ -685,7 +689,7 @@ static void mf_select_run(const SelectPlan& plan, const typename Policy::Params&
                           bool no_bound = false) {
     if (plan.YTa > 0 && !main_only) {
         sc.t_begin = 0; sc.t_end = plan.YTa; sc.tiles_per_chunk = plan.tpcA;
-        sc.tstride = MF_SEED_DIV;                       // tile t of the sample is tile MF_SEED_DIV t (YTa = YT / MF_SEED_DIV)
+        sc.tstride = plan.seed_div;                     // tile t of the sample is tile seed_div t (YTa = YT / seed_div)
         switch (plan.T) {
             case 2: mf_select_seed_t<D, 2, Policy>(pp, sc, seeds, plan.seeds_per_row, plan.nchunkA, plan.gx, s); break;
             case 4: mf_select_seed_t<D, 4, Policy>(pp, sc, seeds, plan.seeds_per_row, plan.nchunkA, plan.gx, s); break;
